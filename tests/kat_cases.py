@@ -1,0 +1,531 @@
+"""Known-answer tests restated from the reference's own test-suite
+(``/root/reference/tests/TestSlicedNonbondedForce.h``; line ranges cited per case).
+
+Each case takes an *evaluator*  ``ev(force, positions, box=None, parameters=None,
+include_direct=True, include_reciprocal=True) -> dict(energy, forces, slice_energies, derivatives)``
+so the very same cases pin (a) the CPU oracle (``-m "not gpu"``) and (b) the HIP engine through the
+C-ABI (``-m gpu``).  Assertion helpers follow ``openmmapi/include/internal/AssertionUtilities.h:7-44``.
+"""
+import math
+
+import numpy as np
+
+ONE_4PI_EPS0 = 138.93545764438198
+SQRT_TWO = math.sqrt(2.0)
+TOL = 1e-4  # tests/TestSlicedNonbondedForce.h:27
+
+
+def assertEqualTo(expected, found, tol):
+    scale = max(abs(expected), 1.0)
+    assert abs(expected - found) / scale <= tol, "expected %r found %r (tol %g)" % (expected, found, tol)
+
+
+def assertEqualVec(expected, found, tol):
+    expected = np.asarray(expected, dtype=float); found = np.asarray(found, dtype=float)
+    norm = max(math.sqrt(float(expected @ expected)), 1.0)
+    diff = math.sqrt(float((expected - found) @ (expected - found)))
+    assert diff / norm <= tol, "expected %r found %r (tol %g)" % (expected, found, tol)
+
+
+def assertForces(f1, f2, tol):
+    for a, b in zip(np.asarray(f1), np.asarray(f2)):
+        assertEqualVec(a, b, tol)
+
+
+def cubic(L):
+    return np.diag([L, L, L]).astype(float)
+
+
+# --- :87-109 ------------------------------------------------------------------------------------
+def testCoulomb(ev, F, tol=TOL):
+    ff = F(1)
+    ff.addParticle(0.5, 1, 0)
+    ff.addParticle(-1.5, 1, 0)
+    assert not ff.usesPeriodicBoundaryConditions()
+    r = ev(ff, [[0, 0, 0], [2, 0, 0]])
+    force = ONE_4PI_EPS0 * (-0.75) / 4.0
+    assertEqualVec([-force, 0, 0], r["forces"][0], tol)
+    assertEqualVec([force, 0, 0], r["forces"][1], tol)
+    assertEqualTo(ONE_4PI_EPS0 * (-0.75) / 2.0, r["energy"], tol)
+
+
+# --- :111-135 -----------------------------------------------------------------------------------
+def testLJ(ev, F, tol=TOL):
+    ff = F(1)
+    ff.addParticle(0, 1.2, 1)
+    ff.addParticle(0, 1.4, 2)
+    r = ev(ff, [[0, 0, 0], [2, 0, 0]])
+    x = 1.3 / 2.0
+    eps = SQRT_TWO
+    force = 4.0 * eps * (12 * x ** 12 - 6 * x ** 6) / 2.0
+    assertEqualVec([-force, 0, 0], r["forces"][0], tol)
+    assertEqualVec([force, 0, 0], r["forces"][1], tol)
+    assertEqualTo(4.0 * eps * (x ** 12 - x ** 6), r["energy"], tol)
+
+
+def _chain5(F, method=None, cutoff=None, rf=None):
+    sliced = F(1)
+    if method is not None:
+        sliced.setNonbondedMethod(method)
+    for _ in range(5):
+        sliced.addParticle(0, 1.5, 0)
+    if cutoff is not None:
+        sliced.setCutoffDistance(cutoff)
+    if rf is not None:
+        sliced.setReactionFieldDielectric(rf)
+    sliced.createExceptionsFromBonds([(0, 1), (1, 2), (2, 3), (3, 4)], 0.0, 0.0)
+    first14 = second14 = None
+    for i in range(sliced.getNumExceptions()):
+        p1, p2, *_ = sliced.getExceptionParameters(i)
+        if {p1, p2} == {0, 3}:
+            first14 = i
+        if {p1, p2} == {1, 4}:
+            second14 = i
+    assert first14 is not None and second14 is not None
+    return sliced, first14, second14
+
+
+# --- :137-222 -----------------------------------------------------------------------------------
+def testExclusionsAnd14(ev, F, tol=TOL):
+    sliced, first14, second14 = _chain5(F)
+    for i in range(1, 5):
+        r_ = 1.0
+        positions = [[0, j, 0] for j in range(5)]
+        for j in range(5):
+            sliced.setParticleParameters(j, 0, 1.5, 0)
+        sliced.setParticleParameters(0, 0, 1.5, 1)
+        sliced.setParticleParameters(i, 0, 1.5, 1)
+        sliced.setExceptionParameters(first14, 0, 3, 0, 1.5, 0.5 if i == 3 else 0.0)
+        sliced.setExceptionParameters(second14, 1, 4, 0, 1.5, 0.0)
+        positions[i] = [r_, 0, 0]
+        res = ev(sliced, positions)
+        x = 1.5 / r_
+        force = 4.0 * (12 * x ** 12 - 6 * x ** 6) / r_
+        energy = 4.0 * (x ** 12 - x ** 6)
+        if i == 3:
+            force *= 0.5; energy *= 0.5
+        if i < 3:
+            force = 0; energy = 0
+        assertEqualVec([-force, 0, 0], res["forces"][0], tol)
+        assertEqualVec([force, 0, 0], res["forces"][i], tol)
+        assertEqualTo(energy, res["energy"], tol)
+        # Coulomb
+        sliced.setParticleParameters(0, 2, 1.5, 0)
+        sliced.setParticleParameters(i, 2, 1.5, 0)
+        sliced.setExceptionParameters(first14, 0, 3, 4 / 1.2 if i == 3 else 0, 1.5, 0)
+        sliced.setExceptionParameters(second14, 1, 4, 0, 1.5, 0)
+        res = ev(sliced, positions)
+        force = ONE_4PI_EPS0 * 4 / (r_ * r_)
+        energy = ONE_4PI_EPS0 * 4 / r_
+        if i == 3:
+            force /= 1.2; energy /= 1.2
+        if i < 3:
+            force = 0; energy = 0
+        assertEqualVec([-force, 0, 0], res["forces"][0], tol)
+        assertEqualVec([force, 0, 0], res["forces"][i], tol)
+        assertEqualTo(energy, res["energy"], tol)
+
+
+# --- :224-260 -----------------------------------------------------------------------------------
+def testCutoff(ev, F, tol=TOL):
+    ff = F(1)
+    for _ in range(3):
+        ff.addParticle(1.0, 1, 0)
+    ff.setNonbondedMethod(ff.CutoffNonPeriodic)
+    cutoff = 2.9
+    ff.setCutoffDistance(cutoff)
+    eps = 50.0
+    ff.setReactionFieldDielectric(eps)
+    r = ev(ff, [[0, 0, 0], [0, 2, 0], [0, 3, 0]])
+    krf = (1.0 / cutoff ** 3) * (eps - 1.0) / (2.0 * eps + 1.0)
+    crf = (1.0 / cutoff) * (3.0 * eps) / (2.0 * eps + 1.0)
+    force1 = ONE_4PI_EPS0 * (0.25 - 2.0 * krf * 2.0)
+    force2 = ONE_4PI_EPS0 * (1.0 - 2.0 * krf * 1.0)
+    assertEqualVec([0, -force1, 0], r["forces"][0], tol)
+    assertEqualVec([0, force1 - force2, 0], r["forces"][1], tol)
+    assertEqualVec([0, force2, 0], r["forces"][2], tol)
+    energy1 = ONE_4PI_EPS0 * (0.5 + krf * 4.0 - crf)
+    energy2 = ONE_4PI_EPS0 * (1.0 + krf * 1.0 - crf)
+    assertEqualTo(energy1 + energy2, r["energy"], tol)
+
+
+# --- :262-356 -----------------------------------------------------------------------------------
+def testCutoff14(ev, F, tol=TOL):
+    cutoff = 3.5
+    sliced, first14, second14 = _chain5(F, method=1, cutoff=cutoff, rf=30.0)
+    positions = [[i, 0, 0] for i in range(5)]
+    for i in range(1, 5):
+        sliced.setParticleParameters(0, 0, 1.5, 1)
+        for j in range(1, 5):
+            sliced.setParticleParameters(j, 0, 1.5, 0)
+        sliced.setParticleParameters(i, 0, 1.5, 1)
+        sliced.setExceptionParameters(first14, 0, 3, 0, 1.5, 0.5 if i == 3 else 0.0)
+        sliced.setExceptionParameters(second14, 1, 4, 0, 1.5, 0.0)
+        res = ev(sliced, positions)
+        r_ = positions[i][0]
+        x = 1.5 / r_
+        force = 4.0 * (12 * x ** 12 - 6 * x ** 6) / r_
+        energy = 4.0 * (x ** 12 - x ** 6)
+        if i == 3:
+            force *= 0.5; energy *= 0.5
+        if i < 3 or r_ > cutoff:
+            force = 0; energy = 0
+        assertEqualVec([-force, 0, 0], res["forces"][0], tol)
+        assertEqualVec([force, 0, 0], res["forces"][i], tol)
+        assertEqualTo(energy, res["energy"], tol)
+        q = 0.7
+        sliced.setParticleParameters(0, q, 1.5, 0)
+        sliced.setParticleParameters(i, q, 1.5, 0)
+        sliced.setExceptionParameters(first14, 0, 3, q * q / 1.2 if i == 3 else 0, 1.5, 0)
+        sliced.setExceptionParameters(second14, 1, 4, 0, 1.5, 0)
+        res = ev(sliced, positions)
+        force = ONE_4PI_EPS0 * q * q / (r_ * r_)
+        energy = ONE_4PI_EPS0 * q * q / r_
+        if i == 3:
+            force /= 1.2; energy /= 1.2
+        if i < 3 or r_ > cutoff:
+            force = 0; energy = 0
+        assertEqualVec([-force, 0, 0], res["forces"][0], tol)
+        assertEqualVec([force, 0, 0], res["forces"][i], tol)
+        assertEqualTo(energy, res["energy"], tol)
+
+
+# --- :358-392 -----------------------------------------------------------------------------------
+def testPeriodic(ev, F, tol=TOL):
+    sliced = F(1)
+    for _ in range(3):
+        sliced.addParticle(1.0, 1, 0)
+    sliced.addException(0, 1, 0.0, 1.0, 0.0)
+    sliced.setNonbondedMethod(sliced.CutoffPeriodic)
+    cutoff = 2.0
+    sliced.setCutoffDistance(cutoff)
+    assert sliced.usesPeriodicBoundaryConditions()
+    r = ev(sliced, [[0, 0, 0], [2, 0, 0], [3, 0, 0]], cubic(4))
+    eps = 78.3
+    krf = (1.0 / cutoff ** 3) * (eps - 1.0) / (2.0 * eps + 1.0)
+    crf = (1.0 / cutoff) * (3.0 * eps) / (2.0 * eps + 1.0)
+    force = ONE_4PI_EPS0 * (1.0 - 2.0 * krf * 1.0)
+    assertEqualVec([force, 0, 0], r["forces"][0], tol)
+    assertEqualVec([-force, 0, 0], r["forces"][1], tol)
+    assertEqualVec([0, 0, 0], r["forces"][2], tol)
+    assertEqualTo(2 * ONE_4PI_EPS0 * (1.0 + krf * 1.0 - crf), r["energy"], tol)
+
+
+# --- :394-430 -----------------------------------------------------------------------------------
+def testPeriodicExceptions(ev, F, tol=TOL):
+    sliced = F(1)
+    sliced.addParticle(1.0, 1, 0)
+    sliced.addParticle(1.0, 1, 0)
+    sliced.addException(0, 1, 1.0, 1.0, 0.0)
+    sliced.setNonbondedMethod(sliced.CutoffPeriodic)
+    sliced.setCutoffDistance(2.0)
+    pos = [[0, 0, 0], [3, 0, 0]]
+    r = ev(sliced, pos, cubic(4))
+    force = ONE_4PI_EPS0 / (3 * 3)
+    assertEqualVec([-force, 0, 0], r["forces"][0], tol)
+    assertEqualVec([force, 0, 0], r["forces"][1], tol)
+    assertEqualTo(ONE_4PI_EPS0 / 3, r["energy"], tol)
+    sliced.setExceptionsUsePeriodicBoundaryConditions(True)
+    r = ev(sliced, pos, cubic(4))
+    force = ONE_4PI_EPS0 / (1 * 1)
+    assertEqualVec([force, 0, 0], r["forces"][0], tol)
+    assertEqualVec([-force, 0, 0], r["forces"][1], tol)
+    assertEqualTo(ONE_4PI_EPS0 / 1, r["energy"], tol)
+
+
+# --- :432-492 (SFMT stream replaced by a seeded NumPy generator) ----------------------------------
+def testTriclinic(ev, F, tol=1e-4, iterations=50):
+    a = np.array([3.1, 0, 0]); b = np.array([0.4, 3.5, 0]); c = np.array([-0.1, -0.5, 4.0])
+    box = np.array([a, b, c])
+    sliced = F(1)
+    sliced.addParticle(1.0, 1, 0)
+    sliced.addParticle(1.0, 1, 0)
+    sliced.setNonbondedMethod(sliced.CutoffPeriodic)
+    cutoff = 1.5
+    sliced.setCutoffDistance(cutoff)
+    rng = np.random.default_rng(0)
+    eps = 78.3
+    krf = (1.0 / cutoff ** 3) * (eps - 1.0) / (2.0 * eps + 1.0)
+    crf = (1.0 / cutoff) * (3.0 * eps) / (2.0 * eps + 1.0)
+    for _ in range(iterations):
+        u = rng.random(6)
+        p0 = a * u[0] + b * u[1] + c * u[2]
+        p1 = a * u[3] + b * u[4] + c * u[5]
+        delta = None; d2 = 100.0
+        for i in (-1, 0, 1):
+            for j in (-1, 0, 1):
+                for k in (-1, 0, 1):
+                    d = p1 - p0 + a * i + b * j + c * k
+                    if d @ d < d2:
+                        delta = d; d2 = float(d @ d)
+        dist = math.sqrt(d2)
+        r = ev(sliced, [p0, p1], box)
+        if dist >= cutoff:
+            assert r["energy"] == 0.0
+            assertEqualVec([0, 0, 0], r["forces"][0], 0)
+            assertEqualVec([0, 0, 0], r["forces"][1], 0)
+        else:
+            force = delta * ONE_4PI_EPS0 * (-1.0 / dist ** 3 + 2.0 * krf)
+            assertEqualTo(ONE_4PI_EPS0 * (1.0 / dist + krf * dist * dist - crf), r["energy"], tol)
+            assertEqualVec(force, r["forces"][0], tol)
+            assertEqualVec(-force, r["forces"][1], tol)
+
+
+# --- :614-681 -----------------------------------------------------------------------------------
+def testDispersionCorrection(ev, F, tol=TOL):
+    gridSize = 5
+    numParticles = gridSize ** 3
+    boxSize = gridSize * 0.7
+    cutoff = boxSize / 3
+    sliced = F(1)
+    positions = []
+    for i in range(gridSize):
+        for j in range(gridSize):
+            for k in range(gridSize):
+                sliced.addParticle(0, 1.1, 0.5)
+                positions.append([i * boxSize / gridSize, j * boxSize / gridSize, k * boxSize / gridSize])
+    sliced.setNonbondedMethod(sliced.CutoffPeriodic)
+    sliced.setCutoffDistance(cutoff)
+    box = cubic(boxSize)
+    energy1 = ev(sliced, positions, box)["energy"]
+    sliced.setUseDispersionCorrection(False)
+    energy2 = ev(sliced, positions, box)["energy"]
+    term1 = (0.5 * 1.1 ** 12 / cutoff ** 9) / 9
+    term2 = (0.5 * 1.1 ** 6 / cutoff ** 3) / 3
+    expected = 8 * math.pi * numParticles * numParticles * (term1 - term2) / boxSize ** 3
+    assertEqualTo(expected, energy1 - energy2, tol)
+    numType2 = 0
+    for i in range(0, numParticles, 2):
+        sliced.setParticleParameters(i, 0, 1, 1)
+        numType2 += 1
+    numType1 = numParticles - numType2
+    energy2 = ev(sliced, positions, box)["energy"]
+    sliced.setUseDispersionCorrection(True)
+    energy1 = ev(sliced, positions, box)["energy"]
+    term1 = ((numType1 * (numType1 + 1)) // 2) * (0.5 * 1.1 ** 12 / cutoff ** 9) / 9
+    term2 = ((numType1 * (numType1 + 1)) // 2) * (0.5 * 1.1 ** 6 / cutoff ** 3) / 3
+    term1 += ((numType2 * (numType2 + 1)) // 2) * (1 * 1.0 ** 12 / cutoff ** 9) / 9
+    term2 += ((numType2 * (numType2 + 1)) // 2) * (1 * 1.0 ** 6 / cutoff ** 3) / 3
+    combinedSigma = 0.5 * (1 + 1.1)
+    combinedEpsilon = math.sqrt(1 * 0.5)
+    term1 += (numType1 * numType2) * (combinedEpsilon * combinedSigma ** 12 / cutoff ** 9) / 9
+    term2 += (numType1 * numType2) * (combinedEpsilon * combinedSigma ** 6 / cutoff ** 3) / 3
+    term1 /= (numParticles * (numParticles + 1)) // 2
+    term2 /= (numParticles * (numParticles + 1)) // 2
+    expected = 8 * math.pi * numParticles * numParticles * (term1 - term2) / boxSize ** 3
+    assertEqualTo(expected, energy1 - energy2, tol)
+
+
+# --- :760-813 -----------------------------------------------------------------------------------
+def testSwitchingFunction(ev, F, method, pme=None, tol=TOL, fd_tol=1e-3):
+    sliced = F(1)
+    sliced.addParticle(0, 1.2, 1)
+    sliced.addParticle(0, 1.4, 2)
+    sliced.setNonbondedMethod(method)
+    sliced.setCutoffDistance(2.0)
+    sliced.setUseSwitchingFunction(True)
+    sliced.setSwitchingDistance(1.5)
+    sliced.setUseDispersionCorrection(False)
+    if pme is not None:
+        sliced.setPMEParameters(*pme)
+    box = cubic(6)
+    eps = SQRT_TWO
+    r_ = 1.0
+    while r_ < 2.5:
+        res = ev(sliced, [[0, 0, 0], [r_, 0, 0]], box)
+        x = 1.3 / r_
+        expectedEnergy = 4.0 * eps * (x ** 12 - x ** 6)
+        if r_ <= 1.5:
+            sw = 1
+        elif r_ >= 2.0:
+            sw = 0
+        else:
+            t = (r_ - 1.5) / 0.5
+            sw = 1 + t * t * t * (-10 + t * (15 - t * 6))
+        assertEqualTo(sw * expectedEnergy, res["energy"], tol)
+        delta = 1e-3
+        e1 = ev(sliced, [[0, 0, 0], [r_ - delta, 0, 0]], box)["energy"]
+        e2 = ev(sliced, [[0, 0, 0], [r_ + delta, 0, 0]], box)["energy"]
+        assertEqualTo((e2 - e1) / (2 * delta), res["forces"][0][0], fd_tol)
+        r_ += 0.1
+
+
+# --- :815-871 (each force evaluated separately: force groups are the caller's concern) -------------
+def testTwoForces(ev, F, tol=TOL):
+    nb1 = F(1); nb1.addParticle(-1.5, 1, 1.2); nb1.addParticle(0.5, 1, 1.0)
+    nb2 = F(1); nb2.addParticle(0.4, 1.4, 0.5); nb2.addParticle(0.3, 1.8, 1.0)
+    pos = [[0, 0, 0], [1.5, 0, 0]]
+    assertEqualTo(ONE_4PI_EPS0 * (-1.5 * 0.5) / 1.5 + 4.0 * math.sqrt(1.2 * 1.0) * ((1.0 / 1.5) ** 12 - (1.0 / 1.5) ** 6), ev(nb1, pos)["energy"], tol)
+    assertEqualTo(ONE_4PI_EPS0 * (0.4 * 0.3) / 1.5 + 4.0 * math.sqrt(0.5 * 1.0) * ((1.6 / 1.5) ** 12 - (1.6 / 1.5) ** 6), ev(nb2, pos)["energy"], tol)
+    nb1.setParticleParameters(0, -1.2, 1.1, 1.4)
+    nb2.setParticleParameters(0, 0.5, 1.6, 0.6)
+    assertEqualTo(ONE_4PI_EPS0 * (-1.2 * 0.5) / 1.5 + 4.0 * math.sqrt(1.4 * 1.0) * ((1.05 / 1.5) ** 12 - (1.05 / 1.5) ** 6), ev(nb1, pos)["energy"], tol)
+    assertEqualTo(ONE_4PI_EPS0 * (0.5 * 0.3) / 1.5 + 4.0 * math.sqrt(0.6 * 1.0) * ((1.7 / 1.5) ** 12 - (1.7 / 1.5) ** 6), ev(nb2, pos)["energy"], tol)
+
+
+# --- :883-945 -----------------------------------------------------------------------------------
+def testParameterOffsets(ev, F, tol=1e-4):
+    force = F(1)
+    force.addParticle(0.0, 1.0, 0.5)
+    force.addParticle(1.0, 0.5, 0.6)
+    force.addParticle(-1.0, 2.0, 0.7)
+    force.addParticle(0.5, 2.0, 0.8)
+    force.addException(0, 3, 0.0, 1.0, 0.0)
+    force.addException(2, 3, 0.5, 1.0, 1.5)
+    force.addException(0, 1, 1.0, 1.5, 1.0)
+    force.addGlobalParameter("p1", 0.0)
+    force.addGlobalParameter("p2", 1.0)
+    force.addParticleParameterOffset("p1", 0, 3.0, 0.5, 0.5)
+    force.addParticleParameterOffset("p2", 1, 1.0, 1.0, 2.0)
+    force.addExceptionParameterOffset("p1", 1, 0.5, 0.5, 1.5)
+    positions = [[i, 0, 0] for i in range(4)]
+    params = {"p1": 0.5, "p2": 1.5}
+    particleCharge = [0.0 + 3.0 * 0.5, 1.0 + 1.0 * 1.5, -1.0, 0.5]
+    particleSigma = [1.0 + 0.5 * 0.5, 0.5 + 1.0 * 1.5, 2.0, 2.0]
+    particleEpsilon = [0.5 + 0.5 * 0.5, 0.6 + 2.0 * 1.5, 0.7, 0.8]
+    qq = {}; sg = {}; ep = {}
+    for i in range(4):
+        for j in range(i + 1, 4):
+            qq[i, j] = particleCharge[i] * particleCharge[j]
+            sg[i, j] = 0.5 * (particleSigma[i] + particleSigma[j])
+            ep[i, j] = math.sqrt(particleEpsilon[i] * particleEpsilon[j])
+    qq[0, 3] = 0.0; sg[0, 3] = 1.0; ep[0, 3] = 0.0
+    qq[2, 3] = 0.5 + 0.5 * 0.5; sg[2, 3] = 1.0 + 0.5 * 0.5; ep[2, 3] = 1.5 + 1.5 * 0.5
+    qq[0, 1] = 1.0; sg[0, 1] = 1.5; ep[0, 1] = 1.0
+    energy = 0.0
+    for i in range(4):
+        for j in range(i + 1, 4):
+            dist = j - i
+            x = sg[i, j] / dist
+            energy += ONE_4PI_EPS0 * qq[i, j] / dist + 4.0 * ep[i, j] * (x ** 12 - x ** 6)
+    assertEqualTo(energy, ev(force, positions, None, params)["energy"], tol)
+
+
+_POS4 = [[0, 0, 0], [1.5, 0, 0], [0, 0.5, 0.5], [0.2, 1.3, 0]]
+
+
+# --- :947-985 (explicit PME parameters: auto-selection is OpenMM's, a13) ---------------------------
+def testEwaldExceptions(ev, F, pme=(3.0, 24, 24, 24), ljpme=(3.0, 24, 24, 24), tol=1e-4):
+    force = F(1)
+    force.setNonbondedMethod(force.LJPME)
+    force.setCutoffDistance(1.0)
+    force.setPMEParameters(*pme)
+    force.setLJPMEParameters(*ljpme)
+    force.addParticle(1.0, 0.5, 1.0)
+    force.addParticle(1.0, 0.5, 1.0)
+    force.addParticle(-1.0, 0.5, 1.0)
+    force.addParticle(-1.0, 0.5, 1.0)
+    box = cubic(2)
+    e1 = ev(force, _POS4, box)["energy"]
+    force.addException(0, 1, 0.2, 0.8, 2.0)
+    force.setExceptionsUsePeriodicBoundaryConditions(True)
+    e2 = ev(force, _POS4, box)["energy"]
+    r = 0.5
+    expectedChange = ONE_4PI_EPS0 * (0.2 - 1.0) / r + 4 * 2.0 * ((0.8 / r) ** 12 - (0.8 / r) ** 6) - 4 * 1.0 * ((0.5 / r) ** 12 - (0.5 / r) ** 6)
+    assertEqualTo(expectedChange, e2 - e1, tol)
+
+
+# --- :987-1029 ----------------------------------------------------------------------------------
+def testDirectAndReciprocal(ev, F, pme=(3.0, 24, 24, 24), tol=1e-4):
+    force = F(1)
+    force.setNonbondedMethod(force.PME)
+    force.setCutoffDistance(1.0)
+    force.setPMEParameters(*pme)
+    force.addParticle(1.0, 0.5, 1.0)
+    force.addParticle(1.0, 0.5, 1.0)
+    force.addParticle(-1.0, 0.5, 1.0)
+    force.addParticle(-1.0, 0.5, 1.0)
+    force.addException(0, 2, -2.0, 0.5, 3.0)
+    box = cubic(2)
+    e1 = ev(force, _POS4, box)["energy"]
+    e2 = ev(force, _POS4, box, None, True, False)["energy"]
+    e3 = ev(force, _POS4, box, None, False, True)["energy"]
+    assertEqualTo(e1, e2 + e3, tol)
+    assert e2 != 0 and e3 != 0
+    force.setIncludeDirectSpace(False)
+    e4 = ev(force, _POS4, box)["energy"]
+    assertEqualTo(e3, e4, tol)
+
+
+# --- construction of testNonbondedSlicing (:1031-1318): lambda emulated in an n=1 force by scaling q and eps
+def dimer_lattice(numMolecules, L):
+    """Lattice generator shared by testLargeSystem/testNonbondedSlicing (:1059-1076)."""
+    M = int(numMolecules ** (1.0 / 3.0))
+    if M * M * M < numMolecules:
+        M += 1
+    pos = []
+    for k in range(numMolecules):
+        iz = k // (M * M); iy = (k - iz * M * M) // M; ix = k - M * (iy + iz * M)
+        center = np.array([ix + 0.5, iy + 0.5, iz + 0.5]) * L / M
+        delta = np.array([0.5 - ix % 2, 0.5 - iy % 2, 0.5 - iz % 2]) / 2
+        pos.append(center + delta); pos.append(center - delta)
+    return np.array(pos)
+
+
+def testNonbondedSlicing(ev, F, method, exceptions, lj, tol=TOL, pme=None, ljpme=None, seed=0):
+    includeLJ = lj; includeCoulomb = not lj
+    numMolecules = 100; numParticles = 200
+    cutoff = 3.5
+    L = 7.0 if exceptions else 10.0
+    box = cubic(L)
+    positions = dimer_lattice(numMolecules, L)
+    rng = np.random.default_rng(seed)
+    subset = rng.integers(0, 2, numParticles)
+    q = lambda k: 1 - 2 * (k % 2)
+    eps = 1.0
+
+    def make(n):
+        f = F(n)
+        f.setNonbondedMethod(method)
+        f.setCutoffDistance(cutoff)
+        f.setUseDispersionCorrection(True)
+        if pme is not None:
+            f.setPMEParameters(*pme)
+        if ljpme is not None:
+            f.setLJPMEParameters(*ljpme)
+        return f
+
+    def fill(f, lam, sliced):
+        # plain force: subset-1 atoms carry q*lam (Coulomb run) or eps*lam^2 (LJ run); sliced: lambdas do it
+        for k in range(numParticles):
+            s = int(subset[k])
+            qs = (lam if (s == 1 and includeCoulomb) else 1.0) if not sliced else 1.0
+            es = (lam * lam if (s == 1 and includeLJ) else 1.0) if not sliced else 1.0
+            f.addParticle(q(k) * qs, 1, eps * es)
+        if exceptions:
+            for m in range(numMolecules):
+                i, j = 2 * m, 2 * m + 1
+                sc = 1.0
+                if not sliced:
+                    n1 = int(subset[i]) + int(subset[j])
+                    sc = lam ** n1
+                f.addException(i, j, q(i) * q(j) * (sc if includeCoulomb else 1.0), 1, eps * (sc if includeLJ else 1.0))
+
+    results = {}
+    for lam in (1.0, 0.0, 0.5):
+        plain = make(1); fill(plain, lam, False)
+        sliced = make(2); fill(sliced, lam, True)
+        for k in range(numParticles):
+            sliced.setParticleSubset(k, int(subset[k]))
+        sliced.addGlobalParameter("lambda", lam)
+        sliced.addGlobalParameter("lambdaSq", lam * lam)
+        sliced.addScalingParameter("lambda", 0, 1, includeCoulomb, includeLJ)
+        sliced.addScalingParameter("lambdaSq", 1, 1, includeCoulomb, includeLJ)
+        sliced.addEnergyParameterDerivative("lambda")
+        sliced.addEnergyParameterDerivative("lambdaSq")
+        for dirflag, recflag in ((True, False), (False, True), (True, True)):
+            r1 = ev(plain, positions, box, None, dirflag, recflag)
+            r2 = ev(sliced, positions, box, None, dirflag, recflag)
+            assertEqualTo(r1["energy"], r2["energy"], tol)
+            assertForces(r1["forces"], r2["forces"], tol)
+        results[lam] = (r1, r2)
+    # E(lambda=1) - E(lambda=0) = sum of dE/dlambda (:1281-1286); slice energies are lambda-independent
+    e1 = results[1.0][1]["energy"]; e0 = results[0.0][1]["energy"]
+    d = results[0.0][1]["derivatives"]
+    assertEqualTo(e1 - e0, d["lambda"] + d["lambdaSq"], tol)
+    # E = sum lambda dE/dlambda + (slice 00) (:1310-1317, :1419-1423)
+    r = results[0.5][1]
+    total = float((r["lambdas"] * r["slice_energies"]).sum())
+    assertEqualTo(r["energy"], total, tol)
+    # sum of all slices at lambda=1 equals the unsliced energy
+    assertEqualTo(results[1.0][0]["energy"], float(results[1.0][1]["slice_energies"].sum()), tol)
