@@ -1,0 +1,152 @@
+/*
+ * snb.h -- C ABI of the MI355X-native SlicedNonbondedForce engine (libsnb_hip.so).
+ *
+ * This is the drop-in boundary.  It replaces, for the force/energy hot path, what the reference puts
+ * behind  NonbondedSlicing::CalcSlicedNonbondedForceKernel
+ *   (openmmapi/include/NonbondedSlicingKernels.h:27-85):
+ *     initialize(system, force)                      :48   -> snb_create + snb_set_particles/_exceptions/_lambdas/...
+ *     execute(context, forces, energy, direct, recip):59   -> snb_set_box/_positions + snb_execute + snb_get_forces
+ *     copyParametersToContext(context, force)        :66   -> snb_set_particles/_exceptions/_dispersion_coefficients
+ *     getPMEParameters(alpha,nx,ny,nz)               :75   -> snb_get_pme_parameters
+ *     getLJPMEParameters(alpha,nx,ny,nz)             :84   -> snb_get_ljpme_parameters
+ * and the device work the reference enqueues from CommonCalcSlicedNonbondedForceKernel::execute
+ *   (platforms/common/src/CommonNonbondedSlicingKernels.cpp:846-1402).
+ *
+ * Plain pointers and sizes only: no C++ types, no torch types.  Caller owns every host array;
+ * the engine owns all device memory.  One handle = one device = one HIP stream; a handle is not
+ * thread-safe.  Errors are status codes; snb_last_error() gives the message an adapter rethrows as
+ * OpenMM::OpenMMException (INTEGRATION.md shows the adapter).
+ */
+#ifndef SNB_H_
+#define SNB_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNB_ABI_VERSION 1
+
+typedef struct snb_engine* snb_handle;
+
+typedef enum {
+    SNB_OK = 0,
+    SNB_ERR_INVALID_ARGUMENT = 1,
+    SNB_ERR_HIP = 2,              /* a HIP runtime call failed (no GPU, out of memory, ...)          */
+    SNB_ERR_BOX_TOO_SMALL = 3,    /* "The periodic box size has decreased to less than twice the nonbonded cutoff."
+                                     (ReferenceNonbondedSlicingKernels.cpp:202-204)                     */
+    SNB_ERR_NOT_PME = 4,          /* getPMEParametersInContext on a non-PME engine (CommonNonbondedSlicingKernels.cpp:1571-1581) */
+    SNB_ERR_STATE = 5,            /* call order violated (e.g. execute before positions were set)     */
+    SNB_ERR_UNSUPPORTED = 6
+} snb_status;
+
+/* Values of CalcSlicedNonbondedForceKernel::NonbondedMethod (NonbondedSlicingKernels.h:29-36). */
+typedef enum {
+    SNB_NoCutoff = 0, SNB_CutoffNonPeriodic = 1, SNB_CutoffPeriodic = 2, SNB_Ewald = 3, SNB_PME = 4, SNB_LJPME = 5
+} snb_method;
+
+typedef enum { SNB_SINGLE = 0, SNB_DOUBLE = 1 } snb_precision;
+
+typedef struct {
+    int32_t abi_version;        /* SNB_ABI_VERSION                                                      */
+    int32_t n_atoms;
+    int32_t n_subsets;
+    int32_t method;             /* snb_method                                                           */
+    int32_t precision;          /* snb_precision: arithmetic type of every kernel                       */
+    int32_t use_switch;         /* LJ switching function (ignored for NoCutoff and LJPME, Quirk Q2)     */
+    int32_t exceptions_periodic;
+    int32_t device;             /* HIP device ordinal                                                   */
+    double  cutoff;
+    double  switch_distance;
+    double  rf_dielectric;
+    double  alpha;              /* Ewald/PME separation parameter (explicit; > 0 for Ewald/PME/LJPME)   */
+    int32_t grid[3];            /* requested PME mesh; rounded up to the next size the FFT supports     */
+    int32_t kmax[3];            /* Ewald: numRx, numRy, numRz (ReferenceSlicedLJCoulombIxn.cpp:115-121) */
+    double  alpha_d;            /* LJPME dispersion separation parameter                                */
+    int32_t dgrid[3];           /* LJPME dispersion mesh                                                */
+    double  neighbor_padding;   /* nm added to the cutoff when building tiles (0 = rebuild every call)  */
+    int32_t rebuild_interval;   /* rebuild tiles every this many executes (<=1: every execute)          */
+    int32_t shard_rank;         /* multi-GPU: this engine owns PME subsets J with J % shard_count == shard_rank */
+    int32_t shard_count;        /*            and direct-space work items w with w % shard_count == shard_rank; 1 = unsharded */
+    void*   stream;             /* hipStream_t to enqueue on, or NULL for an engine-owned stream        */
+} snb_config;
+
+/* Aggregate counters for measurement (bench.py / DESIGN.md byte model). */
+typedef struct {
+    int64_t n_tiles;            /* 32x32 tiles processed per evaluation by this engine (T)             */
+    int64_t n_blocks;           /* 32-atom blocks (padded atoms / 32)                                   */
+    int64_t n_padded_atoms;
+    int64_t n_exclusion_tiles;  /* tiles that carry an exclusion mask                                   */
+    int64_t n_exclusions;       /* excluded pairs (exceptions)                                          */
+    int64_t n_14;               /* exceptions with non-zero parameters (Q6)                             */
+    int64_t n_rebuilds;
+    int32_t grid[3];            /* PME mesh actually used                                               */
+    int32_t dgrid[3];
+    double  last_direct_ms;     /* HIP-event time of the last direct-space pair kernel launch           */
+    double  last_recip_ms;      /* HIP-event time of the last reciprocal pipeline (all its kernels)     */
+    double  last_total_ms;      /* HIP-event time of the last snb_execute (all kernels)                 */
+    double  last_rebuild_ms;    /* wall time of the last neighbour rebuild                              */
+} snb_stats;
+
+/* -- lifetime ---------------------------------------------------------------------------------- */
+snb_status snb_create(const snb_config* cfg, snb_handle* out);
+void       snb_destroy(snb_handle h);
+const char* snb_last_error(snb_handle h);        /* h may be NULL: error of the last failed snb_create */
+
+/* -- parameters (host arrays; effective values, i.e. after parameter offsets) ------------------ */
+/* charge[N], sigma[N], epsilon[N] as NonbondedForce::getParticleParameters; subset[N] in [0,n_subsets). */
+snb_status snb_set_particles(snb_handle h, const double* charge, const double* sigma, const double* epsilon, const int32_t* subset);
+/* All exceptions: pairs[m][2], chargeProd[m], sigma[m], epsilon[m].  Every exception is an exclusion; those with
+ * chargeProd != 0 or epsilon != 0 or force14[k] != 0 are also 1-4 interactions (Quirk Q6,
+ * ReferenceNonbondedSlicingKernels.cpp:99-112).  force14 may be NULL. */
+snb_status snb_set_exceptions(snb_handle h, int32_t m, const int32_t* pairs, const double* charge_prod, const double* sigma,
+                              const double* epsilon, const int32_t* force14);
+/* lambdas[S][2] = (Coulomb, vdW) per slice, S = n(n+1)/2, slice(i,j) = max(max+1)/2+min (SlicedNonbondedForce.h:22). */
+snb_status snb_set_lambdas(snb_handle h, const double* lambdas);
+/* Per-slice dispersion-correction coefficients (SlicedNonbondedForceImpl.cpp:263-354); NULL = none. */
+snb_status snb_set_dispersion_coefficients(snb_handle h, const double* coef);
+/* Host helper (no GPU work): the coefficients themselves, restating calcDispersionCorrections. out[S]. */
+snb_status snb_compute_dispersion_coefficients(int32_t n_atoms, int32_t n_subsets, const double* sigma, const double* epsilon,
+                                               const int32_t* subset, double cutoff, int32_t use_switch, double switch_distance,
+                                               double* out);
+
+/* -- per-step state ---------------------------------------------------------------------------- */
+snb_status snb_set_box(snb_handle h, const double* box9);   /* rows a, b, c (reduced, lower triangular) */
+/* pos: [N][3] (is_double=1: double, else float) or, when stride4 != 0, [N][4] (OpenMM posq layout).  is_device != 0:
+ * a device pointer valid on the engine's device. */
+snb_status snb_set_positions(snb_handle h, const void* pos, int32_t is_device, int32_t is_double, int32_t stride4);
+snb_status snb_rebuild_neighbors(snb_handle h);             /* force a tile rebuild at the next execute */
+
+/* -- the hot path ------------------------------------------------------------------------------ */
+/* Enqueues one evaluation.  energy (may be NULL) receives sum_slices lambda*E when include_energy != 0
+ * (this synchronises the stream); forces stay on the device until snb_get_forces. */
+snb_status snb_execute(snb_handle h, int32_t include_forces, int32_t include_energy, int32_t include_direct,
+                       int32_t include_reciprocal, double* energy);
+/* out: [N][3] in the type selected by is_double; accumulate != 0 adds to what is there (the reference
+ * accumulates into the platform's force buffer). */
+snb_status snb_get_forces(snb_handle h, void* out, int32_t is_device, int32_t is_double, int32_t accumulate);
+/* Raw (unscaled) energies of the last execute with include_energy: out[S][2] = (Coulomb, vdW). */
+snb_status snb_get_slice_energies(snb_handle h, double* out);
+snb_status snb_synchronize(snb_handle h);
+
+/* -- queries ----------------------------------------------------------------------------------- */
+snb_status snb_get_pme_parameters(snb_handle h, double* alpha, int32_t grid[3]);
+snb_status snb_get_ljpme_parameters(snb_handle h, double* alpha, int32_t grid[3]);
+snb_status snb_get_stats(snb_handle h, snb_stats* out);
+/* Smallest FFT-legal mesh size >= n (radices 2,3,5,7). */
+int32_t    snb_legal_grid_size(int32_t n);
+int32_t    snb_abi_version(void);
+
+/* -- unit-test hooks for the reciprocal building blocks (used by tests/ only; they run the same
+ *    kernels the pipeline uses) --------------------------------------------------------------- */
+/* Batched 3D real-to-complex forward FFT followed by the inverse, through the engine's own FFT kernels:
+ * in[batch][nx][ny][nz] (host, double) -> spectrum[batch][nx][ny][nz/2+1][2] and roundtrip[batch][nx][ny][nz]
+ * (unnormalised, like the reference's FFT3D: roundtrip = nx*ny*nz * in).  precision selects the kernel type. */
+snb_status snb_test_fft3d(int32_t precision, int32_t device, int32_t batch, int32_t nx, int32_t ny, int32_t nz,
+                          const double* in, double* spectrum, double* roundtrip);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNB_H_ */

@@ -1,0 +1,857 @@
+// engine.hip -- host side of the MI355X SlicedNonbondedForce engine and its C ABI (include/snb.h).
+//
+// Functionally it stands where the reference has CommonCalcSlicedNonbondedForceKernel
+// (platforms/common/src/CommonNonbondedSlicingKernels.cpp: commonInitialize :256-844, execute :846-1402,
+// copyParametersToContext :1404-1568) plus the OpenMM utilities that class leans on (NonbondedUtilities'
+// neighbour list and tile driver, BondedUtilities, ComputeSort) -- but none of its structure: there is no JIT, no
+// ComputeContext; a handle owns plain HIP buffers and enqueues precompiled gfx950 kernels on one stream.
+#include "../../include/snb.h"
+#include "snb_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <set>
+#include <tuple>
+
+namespace snb {
+
+static thread_local std::string g_createError;
+
+struct HipError { std::string msg; };
+#define HIPCHECK(expr)                                                                                         \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) throw HipError{std::string(#expr) + ": " + hipGetErrorString(e_)};               \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void resize(size_t m) {
+        if (m <= n && p) return;
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = m > 0 ? m : 1;
+        HIPCHECK(hipMalloc((void**)&p, sizeof(T) * n));
+    }
+    void upload(const std::vector<T>& h, hipStream_t s) {
+        resize(h.size());
+        if (!h.empty()) HIPCHECK(hipMemcpyAsync(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, s));
+    }
+};
+
+struct EngineBase {
+    snb_config cfg;
+    std::string err;
+    virtual ~EngineBase() {}
+    virtual void setParticles(const double*, const double*, const double*, const int32_t*) = 0;
+    virtual void setExceptions(int32_t, const int32_t*, const double*, const double*, const double*, const int32_t*) = 0;
+    virtual void setLambdas(const double*) = 0;
+    virtual void setDispersion(const double*) = 0;
+    virtual void setBox(const double*) = 0;
+    virtual void setPositions(const void*, int, int, int) = 0;
+    virtual void requestRebuild() = 0;
+    virtual void execute(int, int, int, int, double*) = 0;
+    virtual void getForces(void*, int, int, int) = 0;
+    virtual void getSliceEnergies(double*) = 0;
+    virtual void sync() = 0;
+    virtual void getStats(snb_stats*) = 0;
+    virtual void getPme(double*, int32_t*, bool dispersion) = 0;
+};
+
+// ---- dispersion coefficients (SlicedNonbondedForceImpl.cpp:150-185, 263-354), doubles throughout ----
+static double evalIntegral(double r, double rs, double rc, double sigma) {
+    double A = 1 / (rc - rs), A2 = A * A, A3 = A2 * A;
+    double sig2 = sigma * sigma, sig6 = sig2 * sig2 * sig2;
+    double rs2 = rs * rs, rs3 = rs * rs2;
+    double r2 = r * r, r3 = r * r2, r4 = r * r3, r5 = r * r4, r6 = r * r5, r9 = r3 * r6;
+    return sig6 * A3 *
+           ((sig6 * (+rs3 * 28 * (6 * rs2 * A2 + 15 * rs * A + 10) - r * rs2 * 945 * (rs2 * A2 + 2 * rs * A + 1) +
+                     r2 * rs * 1080 * (2 * rs2 * A2 + 3 * rs * A + 1) - r3 * 420 * (6 * rs2 * A2 + 6 * rs * A + 1) + r4 * 756 * (2 * rs * A2 + A) -
+                     r5 * 378 * A2) -
+             r6 * (+rs3 * 84 * (6 * rs2 * A2 + 15 * rs * A + 10) - r * rs2 * 3780 * (rs2 * A2 + 2 * rs * A + 1) +
+                   r2 * rs * 7560 * (2 * rs2 * A2 + 3 * rs * A + 1))) /
+                (252 * r9) -
+            std::log(r) * 10 * (6 * rs2 * A2 + 6 * rs * A + 1) + r * 15 * (2 * rs * A2 + A) - r2 * 3 * A2);
+}
+
+static void dispersionCoefficients(int n, int nsub, const double* sigma, const double* epsilon, const int32_t* subset, double cutoff,
+                                   int useSwitch, double switchDist, double* out) {
+    const int S = nsub * (nsub + 1) / 2;
+    std::map<std::tuple<double, double, int>, double> classes;
+    for (int i = 0; i < n; i++) classes[std::make_tuple(sigma[i], epsilon[i], (int)subset[i])] += 1.0;
+    std::vector<double> s1(S, 0.0), s2(S, 0.0), s3(S, 0.0);
+    auto sl = [](int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
+    for (auto& c : classes) {
+        double sg = std::get<0>(c.first), ep = std::get<1>(c.first); int s = std::get<2>(c.first);
+        double count = c.second * (c.second + 1) / 2;
+        double q = sg * sg, s6 = q * q * q;
+        int slice = s * (s + 3) / 2;
+        s1[slice] += count * ep * s6 * s6; s2[slice] += count * ep * s6;
+        if (useSwitch) s3[slice] += count * ep * (evalIntegral(cutoff, switchDist, cutoff, sg) - evalIntegral(switchDist, switchDist, cutoff, sg));
+    }
+    for (auto a = classes.begin(); a != classes.end(); ++a)
+        for (auto b = classes.begin(); b != a; ++b) {
+            double sg = 0.5 * (std::get<0>(a->first) + std::get<0>(b->first));
+            double ep = std::sqrt(std::get<1>(a->first) * std::get<1>(b->first));
+            int slice = sl(std::get<2>(a->first), std::get<2>(b->first));
+            double count = a->second * b->second;
+            double q = sg * sg, s6 = q * q * q;
+            s1[slice] += count * ep * s6 * s6; s2[slice] += count * ep * s6;
+            if (useSwitch) s3[slice] += count * ep * (evalIntegral(cutoff, switchDist, cutoff, sg) - evalIntegral(switchDist, switchDist, cutoff, sg));
+        }
+    double N = n, numInteractions = (N * (N + 1)) / 2;
+    for (int s = 0; s < S; s++)
+        out[s] = 8 * N * N * SNB_PI * ((s1[s] / numInteractions) / (9 * std::pow(cutoff, 9)) - (s2[s] / numInteractions) / (3 * std::pow(cutoff, 3)) + s3[s] / numInteractions);
+}
+
+// ---- B-spline moduli (ReferencePME.cpp:88-183) ----
+static void bsplineModuli(int n, int order, std::vector<double>& out) {
+    std::vector<double> data(order, 0.0), bsp(std::max(n, order + 1), 0.0);
+    data[order - 1] = 0; data[1] = 0; data[0] = 1;
+    for (int k = 3; k < order; k++) {
+        double div = 1.0 / (k - 1.0);
+        data[k - 1] = 0;
+        for (int l = 1; l < (k - 1); l++) data[k - l - 1] = div * (l * data[k - l - 2] + (k - l) * data[k - l - 1]);
+        data[0] = div * data[0];
+    }
+    double div = 1.0 / (order - 1);
+    data[order - 1] = 0;
+    for (int l = 1; l < (order - 1); l++) data[order - l - 1] = div * (l * data[order - l - 2] + (order - l) * data[order - l - 1]);
+    data[0] = div * data[0];
+    for (int i = 1; i <= order; i++) bsp[i] = data[i - 1];
+    out.assign(n, 0.0);
+    for (int i = 0; i < n; i++) {
+        double sc = 0, ss = 0;
+        for (int j = 0; j < n && j <= order; j++) { double arg = (2.0 * SNB_PI * i * j) / n; sc += bsp[j] * std::cos(arg); ss += bsp[j] * std::sin(arg); }
+        out[i] = sc * sc + ss * ss;
+    }
+    for (int i = 0; i < n; i++)
+        if (out[i] < 1.0e-7) out[i] = (out[(i - 1 + n) % n] + out[(i + 1) % n]) / 2;
+}
+
+template <typename Real> struct PmePlan {
+    PmePlanDims d;
+    double alpha = 0;
+    bool dispersion = false;
+    DevBuf<Real> gridReal;
+    DevBuf<typename Vec<Real>::T2> gridCplx, twx, twy, twz;
+    DevBuf<Real> modx, mody, modz;
+    void init(const int g[3], int nGrids, hipStream_t s) {
+        d.nx = g[0]; d.ny = g[1]; d.nz = g[2]; d.nzc = g[2] / 2 + 1;
+        if (!factorize(d.nx, d.fx, &d.nfx) || !factorize(d.ny, d.fy, &d.nfy) || !factorize(d.nz, d.fz, &d.nfz)) throw HipError{"PME mesh size is not FFT-legal"};
+        gridReal.resize((size_t)nGrids * d.nx * d.ny * d.nz);
+        gridCplx.resize((size_t)nGrids * d.nx * d.ny * d.nzc);
+        auto tw = [&](int n, DevBuf<typename Vec<Real>::T2>& buf) {
+            std::vector<typename Vec<Real>::T2> h(n);
+            for (int k = 0; k < n; k++) { double a = -2.0 * SNB_PI * k / n; h[k].x = (Real)std::cos(a); h[k].y = (Real)std::sin(a); }
+            buf.upload(h, s);
+        };
+        tw(d.nx, twx); tw(d.ny, twy); tw(d.nz, twz);
+        auto md = [&](int n, DevBuf<Real>& buf) {
+            std::vector<double> m; bsplineModuli(n, SNB_PME_ORDER, m);
+            std::vector<Real> h(m.begin(), m.end());
+            buf.upload(h, s);
+        };
+        md(d.nx, modx); md(d.ny, mody); md(d.nz, modz);
+        HIPCHECK(hipStreamSynchronize(s));
+    }
+};
+
+template <typename Real> class Engine : public EngineBase {
+    using T4 = typename Vec<Real>::T4;
+    using T2 = typename Vec<Real>::T2;
+public:
+    int N, nsub, S;
+    hipStream_t stream = nullptr; bool ownStream = false;
+    hipEvent_t evStart, evDirect0, evDirect1, evRecip0, evRecip1, evEnd;
+    // host-side definition
+    std::vector<double> charge, sigma, epsilon; std::vector<int32_t> subset;
+    std::vector<int32_t> excPairs; std::vector<double> excQQ, excSigma, excEps; std::vector<int32_t> excForce14;
+    std::vector<double> lambdas, dispCoef;
+    double box[9] = {0}; bool haveBox = false, haveParticles = false;
+    // positions
+    const void* devUserPos = nullptr; int posIsDouble = 1, posStride4 = 0; bool havePositions = false;
+    DevBuf<unsigned char> ownedPos;
+    // sorted state
+    int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0; bool wrapMode = false;
+    std::vector<int> sortedToUser, userToSorted;
+    DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> fx, fy, fz, fpx, fpy, fpz, imageOffset, dLambdas;
+    DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, workOrder, tileJ, atomSubset, atomGrid, gridSubset;
+    DevBuf<int2> blockTiles, pairs14, pairsExcl; DevBuf<int4> tileInfo; DevBuf<unsigned> masks;
+    DevBuf<T4> params14, paramsExcl; int n14 = 0, nExcl = 0;
+    DevBuf<double> sliceE;
+    std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
+    PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
+    bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
+    bool lastRecip = false;
+    snb_stats stats;
+
+    Engine(const snb_config& c) {
+        cfg = c; N = c.n_atoms; nsub = c.n_subsets; S = nsub * (nsub + 1) / 2;
+        std::memset(&stats, 0, sizeof(stats));
+        HIPCHECK(hipSetDevice(c.device));
+        if (c.stream) stream = (hipStream_t)c.stream; else { HIPCHECK(hipStreamCreate(&stream)); ownStream = true; }
+        for (hipEvent_t* e : {&evStart, &evDirect0, &evDirect1, &evRecip0, &evRecip1, &evEnd}) HIPCHECK(hipEventCreate(e));
+        charge.assign(N, 0.0); sigma.assign(N, 1.0); epsilon.assign(N, 0.0); subset.assign(N, 0);
+        lambdas.assign((size_t)S * 2, 1.0); dispCoef.assign(S, 0.0); hostSliceE.assign((size_t)S * 2, 0.0);
+        sliceE.resize((size_t)S * 2);
+        if (cfg.shard_count < 1) cfg.shard_count = 1;
+        for (int s = 0; s < nsub; s++) if (s % cfg.shard_count == cfg.shard_rank) ownedSubsets.push_back(s);
+        nGrids = cfg.shard_count == 1 ? nsub : (int)ownedSubsets.size();
+        if (isPme()) {
+            for (int d = 0; d < 3; d++) cfg.grid[d] = legalGridSize(cfg.grid[d]);
+            pme.alpha = cfg.alpha; pme.dispersion = false;
+            if (nGrids > 0) pme.init(cfg.grid, nGrids, stream); else { pme.d.nx = cfg.grid[0]; pme.d.ny = cfg.grid[1]; pme.d.nz = cfg.grid[2]; }
+            if (cfg.method == SNB_LJPME) {
+                for (int d = 0; d < 3; d++) cfg.dgrid[d] = legalGridSize(cfg.dgrid[d]);
+                dpme.alpha = cfg.alpha_d; dpme.dispersion = true;
+                if (nGrids > 0) dpme.init(cfg.dgrid, nGrids, stream); else { dpme.d.nx = cfg.dgrid[0]; dpme.d.ny = cfg.dgrid[1]; dpme.d.nz = cfg.dgrid[2]; }
+            }
+            std::vector<int> gs = cfg.shard_count == 1 ? std::vector<int>() : ownedSubsets;
+            if (cfg.shard_count == 1) { gs.resize(nsub); std::iota(gs.begin(), gs.end(), 0); }
+            gridSubset.upload(gs, stream);
+        }
+    }
+    ~Engine() override {
+        (void)hipStreamSynchronize(stream);
+        for (hipEvent_t e : {evStart, evDirect0, evDirect1, evRecip0, evRecip1, evEnd}) (void)hipEventDestroy(e);
+        if (ownStream) (void)hipStreamDestroy(stream);
+    }
+    bool isPme() const { return cfg.method == SNB_PME || cfg.method == SNB_LJPME; }
+    bool isPeriodic() const { return cfg.method >= SNB_CutoffPeriodic; }
+
+    void setParticles(const double* q, const double* sg, const double* ep, const int32_t* sub) override {
+        for (int i = 0; i < N; i++) {
+            if (sub[i] < 0 || sub[i] >= nsub) throw HipError{"subset out of range"};
+            if (subset[i] != sub[i] || sigma[i] != sg[i] || epsilon[i] != ep[i]) needRebuild = true;   // subsets change the sort; sigma/eps ride along
+        }
+        charge.assign(q, q + N); sigma.assign(sg, sg + N); epsilon.assign(ep, ep + N); subset.assign(sub, sub + N);
+        haveParticles = true; paramsDirty = true;
+    }
+    void setExceptions(int32_t m, const int32_t* pairs, const double* qq, const double* sg, const double* ep, const int32_t* f14) override {
+        for (int k = 0; k < m; k++)
+            if (pairs[2 * k] < 0 || pairs[2 * k] >= N || pairs[2 * k + 1] < 0 || pairs[2 * k + 1] >= N || pairs[2 * k] == pairs[2 * k + 1]) throw HipError{"exception particle index out of range"};
+        std::vector<int32_t> np(pairs, pairs + 2 * (size_t)m);
+        if (np != excPairs) needRebuild = true;   // the exclusion masks live in the tiles
+        excPairs.swap(np); excQQ.assign(qq, qq + m); excSigma.assign(sg, sg + m); excEps.assign(ep, ep + m);
+        if (f14) excForce14.assign(f14, f14 + m); else excForce14.assign(m, 0);
+        paramsDirty = true;
+    }
+    void setLambdas(const double* l) override {
+        lambdas.assign(l, l + (size_t)S * 2);
+        std::vector<Real> h(lambdas.begin(), lambdas.end());
+        dLambdas.upload(h, stream);
+        HIPCHECK(hipStreamSynchronize(stream));
+    }
+    void setDispersion(const double* c) override { if (c) dispCoef.assign(c, c + S); else dispCoef.assign(S, 0.0); }
+    void setBox(const double* b) override {
+        if (b[1] != 0 || b[2] != 0 || b[5] != 0) throw HipError{"box vectors must be in reduced (lower triangular) form"};
+        bool changed = !haveBox;
+        for (int i = 0; i < 9; i++) { if (box[i] != b[i]) changed = true; box[i] = b[i]; }
+        haveBox = true;
+        if (changed) needRebuild = true;
+    }
+    void setPositions(const void* pos, int isDevice, int isDouble, int stride4) override {
+        posIsDouble = isDouble; posStride4 = stride4;
+        const size_t bytes = (size_t)N * (stride4 ? 4 : 3) * (isDouble ? 8 : 4);
+        if (isDevice) devUserPos = pos;
+        else {
+            ownedPos.resize(bytes);
+            HIPCHECK(hipMemcpyAsync(ownedPos.p, pos, bytes, hipMemcpyHostToDevice, stream));
+            HIPCHECK(hipStreamSynchronize(stream));   // the caller's array may be freed on return
+            devUserPos = ownedPos.p;
+        }
+        havePositions = true;
+    }
+    void requestRebuild() override { needRebuild = true; }
+    void sync() override { HIPCHECK(hipStreamSynchronize(stream)); }
+
+    // ------------------------------------------------------------------------------------------
+    // Neighbour structure: sort, blocks, per-atom gathered j-tiles, exclusion masks (host, v1).
+    // ------------------------------------------------------------------------------------------
+    static inline bool owns(int I, int J) { return ((I + J) & 1) ? (I > J) : (I < J); }
+
+    void rebuild() {
+        auto t0 = std::chrono::steady_clock::now();
+        // 1. host copy of the user positions
+        std::vector<double> hp((size_t)N * 3);
+        {
+            const int st = posStride4 ? 4 : 3;
+            if (posIsDouble) {
+                std::vector<double> tmp((size_t)N * st);
+                HIPCHECK(hipMemcpy(tmp.data(), devUserPos, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+                for (int i = 0; i < N; i++) for (int d = 0; d < 3; d++) hp[3 * (size_t)i + d] = tmp[(size_t)i * st + d];
+            } else {
+                std::vector<float> tmp((size_t)N * st);
+                HIPCHECK(hipMemcpy(tmp.data(), devUserPos, sizeof(float) * tmp.size(), hipMemcpyDeviceToHost));
+                for (int i = 0; i < N; i++) for (int d = 0; d < 3; d++) hp[3 * (size_t)i + d] = tmp[(size_t)i * st + d];
+            }
+        }
+        const bool periodic = isPeriodic();
+        const double R = (cfg.method == SNB_NoCutoff) ? 1e300 : cfg.cutoff + cfg.neighbor_padding;
+        const bool rect = box[3] == 0 && box[6] == 0 && box[7] == 0;
+        // 2. wrap into the primary cell (fractional coordinates; lower-triangular box)
+        std::vector<double> wp(hp), off((size_t)N * 3, 0.0);
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        if (periodic) {
+            for (int i = 0; i < N; i++) {
+                double* x = &wp[3 * (size_t)i];
+                double s2 = std::floor(x[2] / box[8]); x[0] -= s2 * box[6]; x[1] -= s2 * box[7]; x[2] -= s2 * box[8];
+                double s1 = std::floor(x[1] / box[4]); x[0] -= s1 * box[3]; x[1] -= s1 * box[4];
+                double s0 = std::floor(x[0] / box[0]); x[0] -= s0 * box[0];
+                for (int d = 0; d < 3; d++) off[3 * (size_t)i + d] = x[d] - hp[3 * (size_t)i + d];
+            }
+            lo[0] = lo[1] = lo[2] = 0; hi[0] = box[0]; hi[1] = box[4]; hi[2] = box[8];
+            if (!rect) { lo[0] = std::min(0.0, box[3]) + std::min(0.0, box[6]); hi[0] = box[0] + std::max(0.0, box[3]) + std::max(0.0, box[6]); lo[1] = std::min(0.0, box[7]); hi[1] = box[4] + std::max(0.0, box[7]); }
+        } else {
+            for (int i = 0; i < N; i++) for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], wp[3 * (size_t)i + d]); hi[d] = std::max(hi[d], wp[3 * (size_t)i + d]); }
+            if (N == 0) { lo[0] = lo[1] = lo[2] = 0; hi[0] = hi[1] = hi[2] = 1; }
+            for (int d = 0; d < 3; d++) { hi[d] += 1e-6 + 1e-9 * std::fabs(hi[d]); }
+        }
+        double ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        for (int d = 0; d < 3; d++) if (!(ext[d] > 1e-9)) ext[d] = 1e-9;
+        // 3. sort: (subset, serpentine xy column, z up/down)
+        const double volume = ext[0] * ext[1] * ext[2];
+        const double aTarget = std::cbrt(32.0 * volume / std::max(N, 1));
+        int ncx = std::max(1, std::min(2048, (int)std::lround(ext[0] / aTarget)));
+        int ncy = std::max(1, std::min(2048, (int)std::lround(ext[1] / aTarget)));
+        std::vector<uint64_t> key(N);
+        for (int i = 0; i < N; i++) {
+            const double* x = &wp[3 * (size_t)i];
+            int cx = std::min(ncx - 1, std::max(0, (int)((x[0] - lo[0]) / ext[0] * ncx)));
+            int cy = std::min(ncy - 1, std::max(0, (int)((x[1] - lo[1]) / ext[1] * ncy)));
+            int col = cx * ncy + ((cx & 1) ? (ncy - 1 - cy) : cy);
+            double zf = std::min(1.0, std::max(0.0, (x[2] - lo[2]) / ext[2]));
+            if (col & 1) zf = 1.0 - zf;
+            uint64_t zq = (uint64_t)(zf * 1048575.0);
+            key[i] = ((uint64_t)subset[i] << 44) | ((uint64_t)col << 20) | zq;
+        }
+        std::vector<int> order(N);
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+        sortedToUser.clear(); userToSorted.assign(N, -1);
+        std::vector<int> blkSubset;
+        {
+            size_t k = 0;
+            for (int s = 0; s < nsub; s++) {
+                size_t start = sortedToUser.size();
+                while (k < (size_t)N && subset[order[k]] == s) { userToSorted[order[k]] = (int)sortedToUser.size(); sortedToUser.push_back(order[k]); k++; }
+                while ((sortedToUser.size() - start) % 32) sortedToUser.push_back(-1);
+                for (size_t b = start / 32; b < sortedToUser.size() / 32; b++) blkSubset.push_back(s);
+            }
+        }
+        Npad = (int)sortedToUser.size(); numBlocks = Npad / 32;
+        if (Npad >= (1 << SNB_JSHIFT_BITS) - 1) throw HipError{"too many atoms for the 27-bit tile index"};
+        // 4. sorted parameter arrays
+        std::vector<T4> hPosq(Npad); std::vector<T2> hSigeps(Npad); std::vector<Real> hOff((size_t)Npad * 3, Real(0));
+        std::vector<int> hAtomSubset(Npad, -1), hAtomGrid(Npad, -1);
+        std::vector<int> slotOfSubset(nsub, -1);
+        if (cfg.shard_count == 1) std::iota(slotOfSubset.begin(), slotOfSubset.end(), 0);
+        else for (size_t g = 0; g < ownedSubsets.size(); g++) slotOfSubset[ownedSubsets[g]] = (int)g;
+        for (int s = 0; s < Npad; s++) {
+            int u = sortedToUser[s];
+            if (u >= 0) {
+                hPosq[s].x = (Real)wp[3 * (size_t)u]; hPosq[s].y = (Real)wp[3 * (size_t)u + 1]; hPosq[s].z = (Real)wp[3 * (size_t)u + 2]; hPosq[s].w = (Real)charge[u];
+                hSigeps[s].x = (Real)(0.5 * sigma[u]); hSigeps[s].y = (Real)(2.0 * std::sqrt(epsilon[u]));
+                for (int d = 0; d < 3; d++) hOff[3 * (size_t)s + d] = (Real)off[3 * (size_t)u + d];
+                hAtomSubset[s] = subset[u]; hAtomGrid[s] = slotOfSubset[subset[u]];
+            } else {   // parked padding atom: zero parameters, far away, distinct
+                hPosq[s].x = (Real)(1e9 + 1e6 * (s & 4095)); hPosq[s].y = (Real)2e9; hPosq[s].z = (Real)-3e9; hPosq[s].w = 0;
+                hSigeps[s].x = 0; hSigeps[s].y = 0;
+            }
+        }
+        // 5. block bounding boxes (real atoms only)
+        std::vector<double> bc((size_t)numBlocks * 3, 0.0), bh((size_t)numBlocks * 3, 0.0);
+        double maxFullExt[3] = {0, 0, 0};
+        for (int b = 0; b < numBlocks; b++) {
+            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+            for (int k = 0; k < 32; k++) {
+                int u = sortedToUser[b * 32 + k]; if (u < 0) continue;
+                for (int d = 0; d < 3; d++) { mn[d] = std::min(mn[d], wp[3 * (size_t)u + d]); mx[d] = std::max(mx[d], wp[3 * (size_t)u + d]); }
+            }
+            for (int d = 0; d < 3; d++) { bc[3 * (size_t)b + d] = 0.5 * (mn[d] + mx[d]); bh[3 * (size_t)b + d] = 0.5 * (mx[d] - mn[d]); maxFullExt[d] = std::max(maxFullExt[d], mx[d] - mn[d]); }
+        }
+        // 6. tiles
+        wrapMode = false;
+        bool allPairs = (cfg.method == SNB_NoCutoff);
+        if (periodic) {
+            if (!rect) { wrapMode = true; allPairs = true; }
+            else for (int d = 0; d < 3; d++) if (!(maxFullExt[d] + 2 * R < box[4 * d])) { wrapMode = true; allPairs = true; }
+        }
+        std::vector<int> hTileJ; std::vector<int4> hTileInfo; std::vector<int2> hBlockTiles(numBlocks);
+        std::vector<unsigned> hMasks;
+        // exclusion CSR over user indices
+        std::vector<int> exStart(N + 1, 0), exList;
+        {
+            const size_t m = excPairs.size() / 2;
+            for (size_t k = 0; k < m; k++) { exStart[excPairs[2 * k] + 1]++; exStart[excPairs[2 * k + 1] + 1]++; }
+            for (int i = 0; i < N; i++) exStart[i + 1] += exStart[i];
+            exList.resize(exStart[N]);
+            std::vector<int> fill(N, 0);
+            for (size_t k = 0; k < m; k++) { int a = excPairs[2 * k], b = excPairs[2 * k + 1]; exList[exStart[a] + fill[a]++] = b; exList[exStart[b] + fill[b]++] = a; }
+        }
+        // cell grid over sorted real atoms (rectangular domains only; allPairs mode does not need it)
+        int nc[3] = {1, 1, 1}; std::vector<int> cellStart, cellAtoms;
+        double csz[3] = {ext[0], ext[1], ext[2]};
+        if (!allPairs) {
+            const double target = std::max(aTarget, R / 3.0);
+            for (int d = 0; d < 3; d++) { nc[d] = std::max(1, std::min(512, (int)(ext[d] / target))); csz[d] = ext[d] / nc[d]; }
+            const size_t ncell = (size_t)nc[0] * nc[1] * nc[2];
+            cellStart.assign(ncell + 1, 0);
+            std::vector<int> cellOf(Npad, -1);
+            for (int s = 0; s < Npad; s++) {
+                int u = sortedToUser[s]; if (u < 0) continue;
+                int c[3];
+                for (int d = 0; d < 3; d++) c[d] = std::min(nc[d] - 1, std::max(0, (int)((wp[3 * (size_t)u + d] - lo[d]) / csz[d])));
+                cellOf[s] = (c[0] * nc[1] + c[1]) * nc[2] + c[2];
+                cellStart[cellOf[s] + 1]++;
+            }
+            for (size_t c = 0; c < ncell; c++) cellStart[c + 1] += cellStart[c];
+            cellAtoms.resize(cellStart[ncell]);
+            std::vector<int> fill(ncell, 0);
+            for (int s = 0; s < Npad; s++) if (cellOf[s] >= 0) cellAtoms[cellStart[cellOf[s]] + fill[cellOf[s]]++] = s;
+        }
+        std::vector<int> slotOf(Npad, -1);            // sorted j index -> position in this block's candidate list
+        std::vector<std::pair<int, int>> cand;        // (key = sj<<27 | index, code)
+        std::vector<int> tileMask;                    // per tile of the current block: mask index or -1
+        numMaskTiles = 0;
+        for (int I = 0; I < numBlocks; I++) {
+            cand.clear();
+            const double* c = &bc[3 * (size_t)I]; const double* h = &bh[3 * (size_t)I];
+            bool emptyBlock = true;
+            for (int k = 0; k < 32; k++) if (sortedToUser[I * 32 + k] >= 0) emptyBlock = false;
+            if (!emptyBlock) {
+                if (allPairs) {
+                    for (int J = 0; J < numBlocks; J++) {
+                        if (J == I || !owns(I, J)) continue;
+                        for (int k = 0; k < 32; k++) if (sortedToUser[J * 32 + k] >= 0) cand.push_back({J * 32 + k, 13});
+                    }
+                } else {
+                    int cmin[3], cmax[3];
+                    for (int d = 0; d < 3; d++) {
+                        cmin[d] = (int)std::floor((c[d] - h[d] - R - lo[d]) / csz[d]);
+                        cmax[d] = (int)std::floor((c[d] + h[d] + R - lo[d]) / csz[d]);
+                        if (!periodic) { cmin[d] = std::max(cmin[d], 0); cmax[d] = std::min(cmax[d], nc[d] - 1); }
+                    }
+                    for (int ix = cmin[0]; ix <= cmax[0]; ix++) for (int iy = cmin[1]; iy <= cmax[1]; iy++) for (int iz = cmin[2]; iz <= cmax[2]; iz++) {
+                        int cc[3] = {ix, iy, iz}, img[3] = {0, 0, 0};
+                        for (int d = 0; d < 3; d++) { img[d] = (int)std::floor((double)cc[d] / nc[d]); cc[d] -= img[d] * nc[d]; }
+                        if (std::abs(img[0]) > 1 || std::abs(img[1]) > 1 || std::abs(img[2]) > 1) continue;
+                        const double sh[3] = {img[0] * box[0], img[1] * box[4], img[2] * box[8]};
+                        const int code = (img[0] + 1) * 9 + (img[1] + 1) * 3 + (img[2] + 1);
+                        const int cell = (cc[0] * nc[1] + cc[1]) * nc[2] + cc[2];
+                        for (int a = cellStart[cell]; a < cellStart[cell + 1]; a++) {
+                            const int sj = cellAtoms[a]; const int J = sj >> 5;
+                            if (J == I || !owns(I, J)) continue;
+                            const int u = sortedToUser[sj];
+                            double d2 = 0;
+                            for (int d = 0; d < 3; d++) { double dd = std::fabs(wp[3 * (size_t)u + d] + sh[d] - c[d]) - h[d]; if (dd > 0) d2 += dd * dd; }
+                            if (d2 < R * R) cand.push_back({sj, code});
+                        }
+                    }
+                }
+            }
+            // group by j subset, ascending index inside a group
+            std::sort(cand.begin(), cand.end(), [&](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+                int sa = blkSubset[a.first >> 5], sb = blkSubset[b.first >> 5];
+                return sa != sb ? sa < sb : a.first < b.first;
+            });
+            const int firstTile = (int)hTileInfo.size();
+            // diagonal tile first
+            tileMask.clear();
+            {
+                for (int k = 0; k < 32; k++) hTileJ.push_back((sortedToUser[I * 32 + k] >= 0) ? ((I * 32 + k) | (13 << SNB_JSHIFT_BITS)) : -1);
+                int mi = (int)(hMasks.size() / 32);
+                hMasks.resize(hMasks.size() + 32, 0u);
+                for (int i = 0; i < 32; i++) { unsigned m = 0; for (int j = 0; j <= i; j++) m |= 1u << j; hMasks[(size_t)mi * 32 + i] = m; }   // keep j > i only
+                hTileInfo.push_back(make_int4(blkSubset[I], mi, 0, 0));
+                tileMask.push_back(mi);
+                for (int k = 0; k < 32; k++) slotOf[I * 32 + k] = k;    // slots 0..31 = diagonal tile
+            }
+            size_t pos = 0;
+            while (pos < cand.size()) {
+                const int sjSub = blkSubset[cand[pos].first >> 5];
+                int cnt = 0;
+                const int tIndex = (int)hTileInfo.size() - firstTile;
+                while (pos < cand.size() && cnt < 32 && blkSubset[cand[pos].first >> 5] == sjSub) {
+                    hTileJ.push_back(cand[pos].first | (cand[pos].second << SNB_JSHIFT_BITS));
+                    slotOf[cand[pos].first] = tIndex * 32 + cnt;
+                    cnt++; pos++;
+                }
+                for (; cnt < 32; cnt++) hTileJ.push_back(-1);
+                hTileInfo.push_back(make_int4(sjSub, -1, 0, 0));
+                tileMask.push_back(-1);
+            }
+            // exclusion masks
+            for (int k = 0; k < 32; k++) {
+                int u = sortedToUser[I * 32 + k]; if (u < 0) continue;
+                for (int e = exStart[u]; e < exStart[u + 1]; e++) {
+                    const int sj = userToSorted[exList[e]];
+                    const int sl = slotOf[sj];
+                    if (sl < 0) continue;
+                    const int t = sl >> 5, bit = sl & 31;
+                    if (tileMask[t] < 0) { tileMask[t] = (int)(hMasks.size() / 32); hMasks.resize(hMasks.size() + 32, 0u); hTileInfo[firstTile + t].y = tileMask[t]; }
+                    hMasks[(size_t)tileMask[t] * 32 + k] |= 1u << bit;
+                }
+            }
+            for (int t = 0; t < (int)tileMask.size(); t++) if (tileMask[t] >= 0) numMaskTiles++;
+            // reset the scratch map
+            for (int k = 0; k < 32; k++) slotOf[I * 32 + k] = -1;
+            for (auto& cd : cand) slotOf[cd.first] = -1;
+            hBlockTiles[I] = make_int2(firstTile, (int)hTileInfo.size() - firstTile);
+            if (emptyBlock) { hBlockTiles[I].y = 0; }
+        }
+        numTiles = (int64_t)hTileInfo.size();
+        std::vector<int> hWork(numBlocks);
+        std::iota(hWork.begin(), hWork.end(), 0);
+        std::stable_sort(hWork.begin(), hWork.end(), [&](int a, int b) { return hBlockTiles[a].y > hBlockTiles[b].y; });
+        // 7. upload
+        posq.upload(hPosq, stream); sigeps.upload(hSigeps, stream); imageOffset.upload(hOff, stream);
+        dSortedToUser.upload(sortedToUser, stream); dUserToSorted.upload(userToSorted, stream);
+        blockSubset.upload(blkSubset, stream); blockTiles.upload(hBlockTiles, stream); workOrder.upload(hWork, stream);
+        tileJ.upload(hTileJ, stream); tileInfo.upload(hTileInfo, stream); masks.upload(hMasks, stream);
+        atomSubset.upload(hAtomSubset, stream); atomGrid.upload(hAtomGrid, stream);
+        fx.resize(Npad); fy.resize(Npad); fz.resize(Npad); fpx.resize(Npad); fpy.resize(Npad); fpz.resize(Npad);
+        buildPairLists();
+        HIPCHECK(hipStreamSynchronize(stream));
+        needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;
+        stats.n_rebuilds++;
+        stats.last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+    // 1-4 and exclusion-correction lists in sorted indices (Q6: ReferenceNonbondedSlicingKernels.cpp:99-112, 129-131)
+    void buildPairLists() {
+        const size_t m = excPairs.size() / 2;
+        std::vector<int2> p14, pex; std::vector<T4> q14, qex;
+        auto sl = [](int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
+        for (size_t k = 0; k < m; k++) {
+            const int a = excPairs[2 * k], b = excPairs[2 * k + 1];
+            const int sa = userToSorted[a], sb = userToSorted[b];
+            const int slice = sl(subset[a], subset[b]);
+            if (excQQ[k] != 0.0 || excEps[k] != 0.0 || excForce14[k]) {
+                p14.push_back(make_int2(sa, sb));
+                T4 v; v.x = (Real)excSigma[k]; v.y = (Real)(4.0 * excEps[k]); v.z = (Real)(SNB_ONE_4PI_EPS0 * excQQ[k]); v.w = (Real)slice;
+                q14.push_back(v);
+            }
+            pex.push_back(make_int2(sa, sb));
+            T4 v; v.x = (Real)(SNB_ONE_4PI_EPS0 * charge[a] * charge[b]);
+            const double c6a = 8.0 * std::pow(0.5 * sigma[a], 3.0) * 2.0 * std::sqrt(epsilon[a]), c6b = 8.0 * std::pow(0.5 * sigma[b], 3.0) * 2.0 * std::sqrt(epsilon[b]);
+            v.y = (Real)(c6a * c6b); v.z = 0; v.w = (Real)slice;
+            qex.push_back(v);
+        }
+        n14 = (int)p14.size(); nExcl = (int)pex.size();
+        pairs14.upload(p14, stream); params14.upload(q14, stream); pairsExcl.upload(pex, stream); paramsExcl.upload(qex, stream);
+        stats.n_14 = n14; stats.n_exclusions = nExcl;
+    }
+
+    // parameters changed but the sort is still valid: refresh the sorted parameter arrays in place
+    void refreshParameters() {
+        std::vector<T2> hSigeps(Npad); std::vector<Real> hq(Npad, Real(0));
+        for (int s = 0; s < Npad; s++) {
+            int u = sortedToUser[s];
+            if (u >= 0) { hSigeps[s].x = (Real)(0.5 * sigma[u]); hSigeps[s].y = (Real)(2.0 * std::sqrt(epsilon[u])); hq[s] = (Real)charge[u]; }
+            else { hSigeps[s].x = 0; hSigeps[s].y = 0; }
+        }
+        sigeps.upload(hSigeps, stream);
+        // charges live in posq.w: strided copy
+        HIPCHECK(hipMemcpy2DAsync(reinterpret_cast<char*>(posq.p) + 3 * sizeof(Real), sizeof(T4), hq.data(), sizeof(Real), sizeof(Real), Npad, hipMemcpyHostToDevice, stream));
+        buildPairLists();
+        HIPCHECK(hipStreamSynchronize(stream));
+        paramsDirty = false;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    void fillPme(PmeParams<Real>& p, PmePlan<Real>& plan, bool wantEnergy) {
+        p.d = plan.d; p.nsub = nGrids; p.natoms = Npad; p.posq = posq.p; p.sigeps = sigeps.p; p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p;
+        p.gridReal = plan.gridReal.p; p.gridCplx = plan.gridCplx.p; p.twx = plan.twx.p; p.twy = plan.twy.p; p.twz = plan.twz.p;
+        p.modx = plan.modx.p; p.mody = plan.mody.p; p.modz = plan.modz.p;
+        const double det = box[0] * box[4] * box[8], sc = 1.0 / det;
+        const double r[9] = {box[4] * box[8] * sc, 0, 0, -box[3] * box[8] * sc, box[0] * box[8] * sc, 0,
+                             (box[3] * box[7] - box[4] * box[6]) * sc, -box[0] * box[7] * sc, box[0] * box[4] * sc};
+        for (int i = 0; i < 9; i++) p.recip[i] = (Real)r[i];
+        p.alpha = (Real)plan.alpha; p.volume = (Real)det; p.dispersion = plan.dispersion ? 1 : 0;
+        p.lambdas = dLambdas.p; p.gridSubset = gridSubset.p; p.nsubTotal = nsub; p.mix = cfg.shard_count == 1 ? 1 : 0;
+        p.sliceE = sliceE.p; p.fpx = fpx.p; p.fpy = fpy.p; p.fpz = fpz.p; p.wantEnergy = wantEnergy ? 1 : 0;
+    }
+
+    void execute(int includeForces, int includeEnergy, int includeDirect, int includeRecip, double* energyOut) override {
+        (void)includeForces;
+        if (!haveParticles) throw HipError{"snb_execute: particles were not set"};
+        if (!havePositions) throw HipError{"snb_execute: positions were not set"};
+        if (isPeriodic()) {
+            if (!haveBox) throw HipError{"snb_execute: box was not set"};
+            const double minAllowed = 1.999999 * cfg.cutoff;
+            if (box[0] < minAllowed || box[4] < minAllowed || box[8] < minAllowed) { err = "The periodic box size has decreased to less than twice the nonbonded cutoff."; throw (int)SNB_ERR_BOX_TOO_SMALL; }
+        }
+        if (cfg.method == SNB_Ewald && includeRecip) { err = "classic Ewald reciprocal sum is not implemented in the HIP engine yet (use PME)"; throw (int)SNB_ERR_UNSUPPORTED; }
+        if (dLambdas.p == nullptr) setLambdas(lambdas.data());
+        if (needRebuild || cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval || cfg.neighbor_padding <= 0) rebuild();
+        else if (paramsDirty) refreshParameters();
+        stepsSinceRebuild++;
+        const bool energy = includeEnergy != 0;
+        HIPCHECK(hipEventRecord(evStart, stream));
+        launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, stream);
+        HIPCHECK(hipMemsetAsync(fx.p, 0, sizeof(Real) * Npad, stream));
+        HIPCHECK(hipMemsetAsync(fy.p, 0, sizeof(Real) * Npad, stream));
+        HIPCHECK(hipMemsetAsync(fz.p, 0, sizeof(Real) * Npad, stream));
+        if (energy) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2, stream));
+        const bool ew = cfg.method >= SNB_Ewald;
+        HIPCHECK(hipEventRecord(evDirect0, stream));
+        if (includeDirect) {
+            DirectParams<Real> p;
+            std::memset(&p, 0, sizeof(p));
+            p.posq = posq.p; p.sigeps = sigeps.p; p.blockSubset = blockSubset.p; p.blockTiles = blockTiles.p; p.workOrder = workOrder.p;
+            p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.sliceE = sliceE.p; p.lambdas = dLambdas.p;
+            const int r = cfg.shard_rank, c = cfg.shard_count;
+            p.workStart = r; p.workStride = c; p.numWork = numBlocks > r ? (numBlocks - r + c - 1) / c : 0;
+            p.nsub = nsub;
+            p.cutoff2 = (Real)(cfg.cutoff * cfg.cutoff);
+            p.krf = (Real)(std::pow(cfg.cutoff, -3.0) * (cfg.rf_dielectric - 1.0) / (2.0 * cfg.rf_dielectric + 1.0));
+            p.crf = (Real)((1.0 / cfg.cutoff) * (3.0 * cfg.rf_dielectric) / (2.0 * cfg.rf_dielectric + 1.0));
+            p.alpha = (Real)cfg.alpha; p.alphaD = (Real)cfg.alpha_d; p.k4pe = (Real)SNB_ONE_4PI_EPS0;
+            const double ic2 = 1.0 / (cfg.cutoff * cfg.cutoff), ic6 = ic2 * ic2 * ic2;
+            const double dar2 = cfg.alpha_d * cfg.alpha_d * cfg.cutoff * cfg.cutoff;
+            p.invCut6 = (Real)ic6; p.multShift6 = (Real)(ic6 * (1.0 - std::exp(-dar2) * (1.0 + dar2 + 0.5 * dar2 * dar2)));
+            const bool sw = cfg.use_switch && cfg.method != SNB_NoCutoff && cfg.method != SNB_LJPME;
+            p.useSwitch = sw ? 1 : 0; p.switchDist = (Real)cfg.switch_distance;
+            p.invSwitchWidth = (Real)(sw ? 1.0 / (cfg.cutoff - cfg.switch_distance) : 0.0);
+            for (int i = 0; i < 9; i++) p.box[i] = (Real)box[i];
+            if (isPeriodic()) { p.invBoxDiag[0] = (Real)(1.0 / box[0]); p.invBoxDiag[1] = (Real)(1.0 / box[4]); p.invBoxDiag[2] = (Real)(1.0 / box[8]); }
+            for (int a = -1; a <= 1; a++) for (int b = -1; b <= 1; b++) for (int cc = -1; cc <= 1; cc++) {
+                const int code = (a + 1) * 9 + (b + 1) * 3 + (cc + 1);
+                p.shifts[code * 3] = (Real)(a * box[0]); p.shifts[code * 3 + 1] = (Real)(b * box[4]); p.shifts[code * 3 + 2] = (Real)(cc * box[8]);
+            }
+            int mc = MC_NOCUTOFF;
+            if (cfg.method == SNB_CutoffNonPeriodic || cfg.method == SNB_CutoffPeriodic) mc = MC_RF;
+            else if (cfg.method == SNB_Ewald || cfg.method == SNB_PME) mc = MC_EWALD;
+            else if (cfg.method == SNB_LJPME) mc = MC_LJPME;
+            launchDirect<Real>(p, mc, wrapMode, energy, stream);
+        }
+        HIPCHECK(hipEventRecord(evDirect1, stream));
+        if (includeDirect && cfg.shard_rank == 0) {   // O(N) pair lists: rank 0 only when sharded
+            PairListParams<Real> q;
+            std::memset(&q, 0, sizeof(q));
+            q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.sliceE = sliceE.p; q.lambdas = dLambdas.p;
+            const bool exPeriodic = (cfg.method == SNB_NoCutoff || cfg.method == SNB_CutoffNonPeriodic) ? false : cfg.exceptions_periodic != 0;
+            q.periodic = exPeriodic ? 1 : 0;
+            for (int i = 0; i < 9; i++) q.box[i] = (Real)box[i];
+            q.alpha = (Real)cfg.alpha; q.alphaD = (Real)cfg.alpha_d; q.ljpme = cfg.method == SNB_LJPME;
+            q.pairs = pairs14.p; q.params = params14.p; q.n = n14;
+            launchExceptions<Real>(q, energy, stream);
+            if (ew) { q.pairs = pairsExcl.p; q.params = paramsExcl.p; q.n = nExcl; launchExclusionCorrection<Real>(q, energy, stream); }
+        }
+        HIPCHECK(hipEventRecord(evRecip0, stream));
+        lastRecip = false;
+        if (includeRecip && isPme()) {
+            lastRecip = true;
+            if (nGrids > 0) {
+                PmeParams<Real> pp;
+                std::memset(&pp, 0, sizeof(pp));
+                fillPme(pp, pme, energy);
+                runPme(pp);
+                if (cfg.method == SNB_LJPME) { fillPme(pp, dpme, energy); runPme(pp); }
+            } else {
+                HIPCHECK(hipMemsetAsync(fpx.p, 0, sizeof(Real) * Npad, stream)); HIPCHECK(hipMemsetAsync(fpy.p, 0, sizeof(Real) * Npad, stream)); HIPCHECK(hipMemsetAsync(fpz.p, 0, sizeof(Real) * Npad, stream));
+            }
+        }
+        HIPCHECK(hipEventRecord(evRecip1, stream));
+        HIPCHECK(hipEventRecord(evEnd, stream));
+        if (energy) {
+            std::vector<double> dev((size_t)S * 2);
+            HIPCHECK(hipMemcpyAsync(dev.data(), sliceE.p, sizeof(double) * S * 2, hipMemcpyDeviceToHost, stream));
+            HIPCHECK(hipStreamSynchronize(stream));
+            hostSliceE = dev;
+            addHostTerms(includeDirect != 0, includeRecip != 0);
+            if (energyOut) { double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }
+        } else if (energyOut) *energyOut = 0.0;
+    }
+
+    void runPme(PmeParams<Real>& pp) {
+        launchPmeSpread<Real>(pp, stream);
+        launchPmeForwardFFT<Real>(pp, stream);
+        launchPmeConvolution<Real>(pp, stream);
+        launchPmeInverseFFT<Real>(pp, stream);
+        launchPmeInterpolate<Real>(pp, stream);
+    }
+
+    // Self energy, neutralising background (ReferenceSlicedLJCoulombIxn.cpp:203-222) and dispersion correction
+    // (ReferenceNonbondedSlicingKernels.cpp:244-249): closed-form host scalars, as the reference GPU path keeps them
+    // (CommonNonbondedSlicingKernels.cpp:618-638, 1129-1139).  When sharded only rank 0 adds them.
+    void addHostTerms(bool direct, bool recip) {
+        if (cfg.shard_rank != 0) return;
+        const double volume = box[0] * box[4] * box[8];
+        if (recip && cfg.method >= SNB_Ewald) {
+            std::vector<double> Q(nsub, 0.0);
+            for (int i = 0; i < N; i++) {
+                const int s = subset[i]; Q[s] += charge[i];
+                const int slice = s * (s + 3) / 2;
+                hostSliceE[2 * slice] -= SNB_ONE_4PI_EPS0 * charge[i] * charge[i] * cfg.alpha / std::sqrt(SNB_PI);
+                if (cfg.method == SNB_LJPME) hostSliceE[2 * slice + 1] += std::pow(cfg.alpha_d, 6.0) * 64.0 * std::pow(0.5 * sigma[i], 6.0) * std::pow(2.0 * std::sqrt(epsilon[i]), 2.0) / 12.0;
+            }
+            const double factor = (-1.0 / (4 * cfg.alpha * cfg.alpha)) / (2 * SNB_EPSILON0 * volume);
+            for (int i = 0; i < nsub; i++) for (int j = i; j < nsub; j++) hostSliceE[2 * (j * (j + 1) / 2 + i)] += (i == j ? 1 : 2) * Q[i] * Q[j] * factor;
+        }
+        if (direct && (cfg.method == SNB_CutoffPeriodic || cfg.method == SNB_Ewald || cfg.method == SNB_PME))
+            for (int s = 0; s < S; s++) hostSliceE[2 * s + 1] += dispCoef[s] / volume;
+    }
+
+    void getForces(void* out, int isDevice, int isDouble, int accumulate) override {
+        const size_t bytes = (size_t)N * 3 * (isDouble ? 8 : 4);
+        const Real* px = lastRecip ? fpx.p : nullptr;
+        if (isDevice) { launchFinishForces<Real>(fx.p, fy.p, fz.p, px, fpy.p, fpz.p, dUserToSorted.p, N, out, isDouble, accumulate, stream); return; }
+        DevBuf<unsigned char> tmp; tmp.resize(bytes);
+        if (accumulate) HIPCHECK(hipMemcpyAsync(tmp.p, out, bytes, hipMemcpyHostToDevice, stream));
+        launchFinishForces<Real>(fx.p, fy.p, fz.p, px, fpy.p, fpz.p, dUserToSorted.p, N, tmp.p, isDouble, accumulate, stream);
+        HIPCHECK(hipMemcpyAsync(out, tmp.p, bytes, hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+    }
+    void getSliceEnergies(double* out) override { std::memcpy(out, hostSliceE.data(), sizeof(double) * S * 2); }
+    void getStats(snb_stats* o) override {
+        HIPCHECK(hipStreamSynchronize(stream));
+        stats.n_tiles = 0;
+        // tiles processed by this shard
+        stats.n_tiles = numTiles; stats.n_blocks = numBlocks; stats.n_padded_atoms = Npad; stats.n_exclusion_tiles = numMaskTiles;
+        for (int d = 0; d < 3; d++) { stats.grid[d] = isPme() ? pme.d.nx * (d == 0) + pme.d.ny * (d == 1) + pme.d.nz * (d == 2) : 0; stats.dgrid[d] = cfg.method == SNB_LJPME ? dpme.d.nx * (d == 0) + dpme.d.ny * (d == 1) + dpme.d.nz * (d == 2) : 0; }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, evDirect0, evDirect1) == hipSuccess) stats.last_direct_ms = ms;
+        if (hipEventElapsedTime(&ms, evRecip0, evRecip1) == hipSuccess) stats.last_recip_ms = ms;
+        if (hipEventElapsedTime(&ms, evStart, evEnd) == hipSuccess) stats.last_total_ms = ms;
+        *o = stats;
+    }
+    void getPme(double* alpha, int32_t* g, bool dispersion) override {
+        if (dispersion) { *alpha = cfg.alpha_d; g[0] = dpme.d.nx; g[1] = dpme.d.ny; g[2] = dpme.d.nz; }
+        else { *alpha = cfg.alpha; g[0] = pme.d.nx; g[1] = pme.d.ny; g[2] = pme.d.nz; }
+    }
+};
+
+template <typename Real> static void testFFT(int device, int batch, int nx, int ny, int nz, const double* in, double* spectrum, double* roundtrip) {
+    HIPCHECK(hipSetDevice(device));
+    hipStream_t s; HIPCHECK(hipStreamCreate(&s));
+    {
+        PmePlan<Real> plan; int g[3] = {nx, ny, nz};
+        plan.init(g, batch, s);
+        PmeParams<Real> p; std::memset(&p, 0, sizeof(p));
+        p.d = plan.d; p.nsub = batch; p.gridReal = plan.gridReal.p; p.gridCplx = plan.gridCplx.p; p.twx = plan.twx.p; p.twy = plan.twy.p; p.twz = plan.twz.p;
+        const size_t nr = (size_t)batch * nx * ny * nz, ncx = (size_t)batch * nx * ny * (nz / 2 + 1);
+        std::vector<Real> h(nr);
+        for (size_t i = 0; i < nr; i++) h[i] = (Real)in[i];
+        HIPCHECK(hipMemcpyAsync(plan.gridReal.p, h.data(), sizeof(Real) * nr, hipMemcpyHostToDevice, s));
+        launchPmeForwardFFT<Real>(p, s);
+        launchPmeFFTX<Real>(p, -1, s);
+        std::vector<typename Vec<Real>::T2> hc(ncx);
+        HIPCHECK(hipMemcpyAsync(hc.data(), plan.gridCplx.p, sizeof(typename Vec<Real>::T2) * ncx, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < ncx; i++) { spectrum[2 * i] = hc[i].x; spectrum[2 * i + 1] = hc[i].y; }
+        launchPmeFFTX<Real>(p, +1, s);
+        launchPmeInverseFFT<Real>(p, s);
+        HIPCHECK(hipMemcpyAsync(h.data(), plan.gridReal.p, sizeof(Real) * nr, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < nr; i++) roundtrip[i] = h[i];
+    }
+    HIPCHECK(hipStreamDestroy(s));
+}
+
+}  // namespace snb
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+using namespace snb;
+
+struct snb_engine { EngineBase* impl; };
+
+template <typename F> static snb_status guard(snb_handle h, F&& f) {
+    if (!h || !h->impl) return SNB_ERR_INVALID_ARGUMENT;
+    try { f(); return SNB_OK; }
+    catch (HipError& e) { h->impl->err = e.msg; return e.msg.find("hip") == 0 ? SNB_ERR_HIP : SNB_ERR_INVALID_ARGUMENT; }
+    catch (int code) { return (snb_status)code; }
+    catch (std::exception& e) { h->impl->err = e.what(); return SNB_ERR_INVALID_ARGUMENT; }
+}
+
+extern "C" {
+
+int32_t snb_abi_version(void) { return SNB_ABI_VERSION; }
+int32_t snb_legal_grid_size(int32_t n) { return legalGridSize(n); }
+
+snb_status snb_create(const snb_config* cfg, snb_handle* out) {
+    if (!cfg || !out) { g_createError = "null argument"; return SNB_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (cfg->abi_version != SNB_ABI_VERSION) { g_createError = "snb_config.abi_version mismatch"; return SNB_ERR_INVALID_ARGUMENT; }
+    if (cfg->n_atoms < 0 || cfg->n_subsets < 1 || cfg->method < 0 || cfg->method > 5 || (cfg->precision != SNB_SINGLE && cfg->precision != SNB_DOUBLE)) {
+        g_createError = "invalid n_atoms / n_subsets / method / precision"; return SNB_ERR_INVALID_ARGUMENT;
+    }
+    if (cfg->method != SNB_NoCutoff && !(cfg->cutoff > 0)) { g_createError = "cutoff must be positive"; return SNB_ERR_INVALID_ARGUMENT; }
+    if (cfg->method >= SNB_Ewald && !(cfg->alpha > 0)) { g_createError = "alpha must be given explicitly for Ewald/PME/LJPME"; return SNB_ERR_INVALID_ARGUMENT; }
+    if ((cfg->method == SNB_PME || cfg->method == SNB_LJPME) && (cfg->grid[0] < 1 || cfg->grid[1] < 1 || cfg->grid[2] < 1)) { g_createError = "PME grid must be given explicitly"; return SNB_ERR_INVALID_ARGUMENT; }
+    if (cfg->method == SNB_LJPME && (!(cfg->alpha_d > 0) || cfg->dgrid[0] < 1 || cfg->dgrid[1] < 1 || cfg->dgrid[2] < 1)) { g_createError = "LJPME dispersion alpha/grid must be given explicitly"; return SNB_ERR_INVALID_ARGUMENT; }
+    if (cfg->shard_count > 1 && (cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_count)) { g_createError = "invalid shard_rank"; return SNB_ERR_INVALID_ARGUMENT; }
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_createError = "hip: no HIP device available (the engine has no CPU fallback)"; return SNB_ERR_HIP; }
+        if (cfg->device < 0 || cfg->device >= ndev) { g_createError = "invalid device ordinal"; return SNB_ERR_INVALID_ARGUMENT; }
+        EngineBase* e = cfg->precision == SNB_DOUBLE ? (EngineBase*)new Engine<double>(*cfg) : (EngineBase*)new Engine<float>(*cfg);
+        *out = new snb_engine{e};
+        return SNB_OK;
+    } catch (HipError& e) { g_createError = e.msg; return SNB_ERR_HIP; }
+    catch (std::exception& e) { g_createError = e.what(); return SNB_ERR_INVALID_ARGUMENT; }
+}
+
+void snb_destroy(snb_handle h) { if (h) { delete h->impl; delete h; } }
+const char* snb_last_error(snb_handle h) { return h && h->impl ? h->impl->err.c_str() : g_createError.c_str(); }
+
+snb_status snb_set_particles(snb_handle h, const double* q, const double* s, const double* e, const int32_t* sub) {
+    if (!q || !s || !e || !sub) return SNB_ERR_INVALID_ARGUMENT;
+    return guard(h, [&] { h->impl->setParticles(q, s, e, sub); });
+}
+snb_status snb_set_exceptions(snb_handle h, int32_t m, const int32_t* pairs, const double* qq, const double* s, const double* e, const int32_t* f14) {
+    if (m < 0 || (m > 0 && (!pairs || !qq || !s || !e))) return SNB_ERR_INVALID_ARGUMENT;
+    return guard(h, [&] { h->impl->setExceptions(m, pairs, qq, s, e, f14); });
+}
+snb_status snb_set_lambdas(snb_handle h, const double* l) { if (!l) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->setLambdas(l); }); }
+snb_status snb_set_dispersion_coefficients(snb_handle h, const double* c) { return guard(h, [&] { h->impl->setDispersion(c); }); }
+snb_status snb_compute_dispersion_coefficients(int32_t n, int32_t nsub, const double* sigma, const double* epsilon, const int32_t* subset, double cutoff,
+                                               int32_t useSwitch, double switchDist, double* out) {
+    if (n < 0 || nsub < 1 || !out || (n > 0 && (!sigma || !epsilon || !subset))) return SNB_ERR_INVALID_ARGUMENT;
+    dispersionCoefficients(n, nsub, sigma, epsilon, subset, cutoff, useSwitch, switchDist, out);
+    return SNB_OK;
+}
+snb_status snb_set_box(snb_handle h, const double* b) { if (!b) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->setBox(b); }); }
+snb_status snb_set_positions(snb_handle h, const void* pos, int32_t isDevice, int32_t isDouble, int32_t stride4) {
+    if (!pos) return SNB_ERR_INVALID_ARGUMENT;
+    return guard(h, [&] { h->impl->setPositions(pos, isDevice, isDouble, stride4); });
+}
+snb_status snb_rebuild_neighbors(snb_handle h) { return guard(h, [&] { h->impl->requestRebuild(); }); }
+snb_status snb_execute(snb_handle h, int32_t f, int32_t e, int32_t d, int32_t r, double* energy) { return guard(h, [&] { h->impl->execute(f, e, d, r, energy); }); }
+snb_status snb_get_forces(snb_handle h, void* out, int32_t isDevice, int32_t isDouble, int32_t acc) {
+    if (!out) return SNB_ERR_INVALID_ARGUMENT;
+    return guard(h, [&] { h->impl->getForces(out, isDevice, isDouble, acc); });
+}
+snb_status snb_get_slice_energies(snb_handle h, double* out) { if (!out) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->getSliceEnergies(out); }); }
+snb_status snb_synchronize(snb_handle h) { return guard(h, [&] { h->impl->sync(); }); }
+snb_status snb_get_pme_parameters(snb_handle h, double* alpha, int32_t grid[3]) {
+    if (!h || !h->impl || !alpha || !grid) return SNB_ERR_INVALID_ARGUMENT;
+    if (h->impl->cfg.method != SNB_PME && h->impl->cfg.method != SNB_LJPME) { h->impl->err = "getPMEParametersInContext: This Context is not using PME or LJPME"; return SNB_ERR_NOT_PME; }
+    return guard(h, [&] { h->impl->getPme(alpha, grid, false); });
+}
+snb_status snb_get_ljpme_parameters(snb_handle h, double* alpha, int32_t grid[3]) {
+    if (!h || !h->impl || !alpha || !grid) return SNB_ERR_INVALID_ARGUMENT;
+    if (h->impl->cfg.method != SNB_LJPME) { h->impl->err = "getPMEParametersInContext: This Context is not using LJPME"; return SNB_ERR_NOT_PME; }
+    return guard(h, [&] { h->impl->getPme(alpha, grid, true); });
+}
+snb_status snb_get_stats(snb_handle h, snb_stats* out) { if (!out) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->getStats(out); }); }
+
+snb_status snb_test_fft3d(int32_t precision, int32_t device, int32_t batch, int32_t nx, int32_t ny, int32_t nz, const double* in, double* spectrum, double* roundtrip) {
+    if (!in || !spectrum || !roundtrip || batch < 1) return SNB_ERR_INVALID_ARGUMENT;
+    if (legalGridSize(nx) != nx || legalGridSize(ny) != ny || legalGridSize(nz) != nz) return SNB_ERR_UNSUPPORTED;
+    try {
+        if (precision == SNB_DOUBLE) testFFT<double>(device, batch, nx, ny, nz, in, spectrum, roundtrip);
+        else testFFT<float>(device, batch, nx, ny, nz, in, spectrum, roundtrip);
+        return SNB_OK;
+    } catch (HipError& e) { g_createError = e.msg; return SNB_ERR_HIP; }
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// misc.hip -- per-step data movement kernels of the engine: positions user order -> sorted posq, forces sorted
+// accumulators -> user order.  Pure HBM streaming (16 B/lane where the layout allows).
+#include "snb_internal.h"
+
+namespace snb {
+
+// posq[s].xyz = userPos[sortedToUser[s]] + imageOffset[s]; charge (.w) is kept.  Padding slots (sortedToUser < 0)
+// keep their parked far-away coordinates.
+template <typename Real, typename In>
+__global__ void k_gatherPositions(const In* __restrict__ userPos, int stride, const int* __restrict__ sortedToUser,
+                                  const Real* __restrict__ imageOffset, typename Vec<Real>::T4* __restrict__ posq, int nPadded) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nPadded) return;
+    const int u = sortedToUser[s];
+    if (u < 0) return;
+    auto v = posq[s];
+    v.x = (Real)userPos[(size_t)u * stride] + imageOffset[3 * s];
+    v.y = (Real)userPos[(size_t)u * stride + 1] + imageOffset[3 * s + 1];
+    v.z = (Real)userPos[(size_t)u * stride + 2] + imageOffset[3 * s + 2];
+    posq[s] = v;
+}
+
+template <typename Real>
+void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
+                           typename Vec<Real>::T4* posq, int nPadded, hipStream_t s) {
+    if (nPadded <= 0) return;
+    dim3 grid((nPadded + 255) / 256), block(256);
+    const int stride = stride4 ? 4 : 3;
+    if (isDouble) hipLaunchKernelGGL((k_gatherPositions<Real, double>), grid, block, 0, s, (const double*)userPos, stride, sortedToUser, imageOffset, posq, nPadded);
+    else hipLaunchKernelGGL((k_gatherPositions<Real, float>), grid, block, 0, s, (const float*)userPos, stride, sortedToUser, imageOffset, posq, nPadded);
+}
+
+template <typename Real, typename Out>
+__global__ void k_finishForces(const Real* __restrict__ fx, const Real* __restrict__ fy, const Real* __restrict__ fz,
+                               const Real* __restrict__ fpx, const Real* __restrict__ fpy, const Real* __restrict__ fpz,
+                               const int* __restrict__ userToSorted, int nAtoms, Out* __restrict__ out, int accumulate) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nAtoms) return;
+    const int s = userToSorted[u];
+    Out x = (Out)fx[s], y = (Out)fy[s], z = (Out)fz[s];
+    if (fpx) { x += (Out)fpx[s]; y += (Out)fpy[s]; z += (Out)fpz[s]; }
+    if (accumulate) { x += out[3 * (size_t)u]; y += out[3 * (size_t)u + 1]; z += out[3 * (size_t)u + 2]; }
+    out[3 * (size_t)u] = x; out[3 * (size_t)u + 1] = y; out[3 * (size_t)u + 2] = z;
+}
+
+template <typename Real>
+void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, const Real* fpx, const Real* fpy, const Real* fpz,
+                        const int* userToSorted, int nAtoms, void* out, int isDouble, int accumulate, hipStream_t s) {
+    if (nAtoms <= 0) return;
+    dim3 grid((nAtoms + 255) / 256), block(256);
+    if (isDouble) hipLaunchKernelGGL((k_finishForces<Real, double>), grid, block, 0, s, fx, fy, fz, fpx, fpy, fpz, userToSorted, nAtoms, (double*)out, accumulate);
+    else hipLaunchKernelGGL((k_finishForces<Real, float>), grid, block, 0, s, fx, fy, fz, fpx, fpy, fpz, userToSorted, nAtoms, (float*)out, accumulate);
+}
+
+template void launchGatherPositions<float>(const void*, int, int, const int*, const float*, Vec<float>::T4*, int, hipStream_t);
+template void launchGatherPositions<double>(const void*, int, int, const int*, const double*, Vec<double>::T4*, int, hipStream_t);
+template void launchFinishForces<float>(const float*, const float*, const float*, const float*, const float*, const float*, const int*, int, void*, int, int, hipStream_t);
+template void launchFinishForces<double>(const double*, const double*, const double*, const double*, const double*, const double*, const int*, int, void*, int, int, hipStream_t);
+
+}  // namespace snb

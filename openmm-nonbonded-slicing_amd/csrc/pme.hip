@@ -1,0 +1,572 @@
+// pme.hip -- sliced PME reciprocal pipeline for gfx950 (MI355X): B-spline charge spreading onto one grid per
+// subset, hand-written batched 3D real FFT (mixed radix 2/3/4/5/7 Stockham in LDS), fused
+// [x-FFT -> per-slice energy -> lambda-mixed convolution -> inverse x-FFT], and force interpolation from ONE
+// pre-mixed potential grid per atom.
+//
+// Replaces platforms/common/src/kernels/pme.cc (findAtomGridIndex :1-22, gridSpreadCharge :24-122,
+// reciprocalConvolution :138-189, gridEvaluateEnergy :191-274, gridInterpolateForce :276-391) and the cuFFT/VkFFT
+// back-ends (platforms/cuda/src/CudaCuFFT3D.cpp, CudaVkFFT3D.cpp).  Arithmetic parity is with
+// platforms/reference/src/ReferencePME.cpp:196-256 (index/fraction), :264-317 (B-splines), :320-396 (spread),
+// :400-595 (convolution + sliced energy), :598-702 (interpolation).
+//
+// Differences from the reference GPU design, chosen for MI355X:
+//  * the lambda mix  phi_I = sum_J lambda_IJ * eterm * S_J  is done in k-space inside the convolution kernel, so the
+//    interpolation gathers 125 values per atom instead of 125*n (pme.cc:360-371);
+//  * the last forward axis and the first inverse axis are the same axis, so both FFTs of that axis, the energy
+//    evaluation and the convolution run in one kernel without leaving LDS: 5 grid passes instead of 8;
+//  * the real axis (z) is transformed with the imaginary half implied, writing nz/2+1 complex outputs.
+#include "snb_internal.h"
+
+namespace snb {
+
+template <typename Real> struct Cx { Real x, y; };
+template <typename Real> __device__ inline Cx<Real> cmul(Cx<Real> a, Cx<Real> b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+// ---------------------------------------------------------------------------------------------------
+// B-splines of order 5 and their derivatives (ReferencePME.cpp:264-317), in registers.
+// ---------------------------------------------------------------------------------------------------
+template <typename Real> __device__ inline void bspline5(Real dr, Real* d, Real* dd) {
+    d[4] = 0; d[1] = dr; d[0] = 1 - dr; d[2] = 0; d[3] = 0;
+    // k = 3
+    {
+        const Real div = Real(0.5);
+        d[2] = div * dr * d[1];
+        d[1] = div * ((dr + 1) * d[0] + (2 - dr) * d[1]);
+        d[0] = div * (1 - dr) * d[0];
+    }
+    // k = 4
+    {
+        const Real div = Real(1.0 / 3.0);
+        d[3] = div * dr * d[2];
+        d[2] = div * ((dr + 1) * d[1] + (3 - dr) * d[2]);
+        d[1] = div * ((dr + 2) * d[0] + (2 - dr) * d[1]);
+        d[0] = div * (1 - dr) * d[0];
+    }
+    dd[0] = -d[0];
+    dd[1] = d[0] - d[1]; dd[2] = d[1] - d[2]; dd[3] = d[2] - d[3]; dd[4] = d[3] - d[4];
+    {
+        const Real div = Real(0.25);
+        d[4] = div * dr * d[3];
+        d[3] = div * ((dr + 1) * d[2] + (4 - dr) * d[3]);
+        d[2] = div * ((dr + 2) * d[1] + (3 - dr) * d[2]);
+        d[1] = div * ((dr + 3) * d[0] + (2 - dr) * d[1]);
+        d[0] = div * (1 - dr) * d[0];
+    }
+}
+
+// grid index + fraction (ReferencePME.cpp:245-254)
+template <typename Real> __device__ inline void gridCoord(const Real* recip, Real x, Real y, Real z, int nx, int ny, int nz, int* idx, Real* frac) {
+    const int n[3] = {nx, ny, nz};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        Real t = x * recip[d] + y * recip[3 + d] + z * recip[6 + d];
+        t = (t - floor(t)) * n[d];
+        int ti = (int)t;
+        frac[d] = t - ti;
+        idx[d] = ti >= n[d] ? ti - n[d] : ti;
+    }
+}
+
+template <typename Real> __device__ inline Real pmeCharge(const PmeParams<Real>& p, int atom) {
+    if (p.dispersion) { const auto se = p.sigeps[atom]; return Real(8) * se.x * se.x * se.x * se.y; }   // c6_i (ReferenceSlicedLJCoulombIxn.cpp:247)
+    return p.posq[atom].w;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Spreading: 32 lanes per atom, lane = one (x,y) stencil row, 5 float atomics along z.
+// (ReferencePME.cpp:320-396).  The grids were cleared by a memset on the same stream.
+// ---------------------------------------------------------------------------------------------------
+template <typename Real> __global__ __launch_bounds__(256) void k_spread(const PmeParams<Real> p) {
+    const int gid = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int r = threadIdx.x & 31;
+    if (gid >= p.natoms || r >= 25) return;
+    const int slot = p.atomGrid[gid];
+    if (slot < 0) return;
+    const Real q = pmeCharge(p, gid);
+    if (q == Real(0)) return;
+    const auto pos = p.posq[gid];
+    int idx[3]; Real fr[3];
+    gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, p.d.nz, idx, fr);
+    Real tx[5], ty[5], tz[5], dtmp[5];
+    bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
+    const int ix = r / 5, iy = r - ix * 5;
+    int xi = idx[0] + ix; if (xi >= p.d.nx) xi -= p.d.nx;
+    int yi = idx[1] + iy; if (yi >= p.d.ny) yi -= p.d.ny;
+    Real wxy = q;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { if (k == ix) wxy *= tx[k]; }
+#pragma unroll
+    for (int k = 0; k < 5; k++) { if (k == iy) wxy *= ty[k]; }
+    Real* row = p.gridReal + (((size_t)slot * p.d.nx + xi) * p.d.ny + yi) * p.d.nz;
+#pragma unroll
+    for (int iz = 0; iz < 5; iz++) {
+        int zi = idx[2] + iz; if (zi >= p.d.nz) zi -= p.d.nz;
+        __hip_atomic_fetch_add(&row[zi], wxy * tz[iz], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <typename Real> void launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
+    hipMemsetAsync(p.gridReal, 0, sizeof(Real) * (size_t)p.nsub * p.d.nx * p.d.ny * p.d.nz, s);
+    if (p.natoms <= 0) return;
+    hipLaunchKernelGGL((k_spread<Real>), dim3((p.natoms + 7) / 8), dim3(256), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stockham FFT stages in LDS.  Data layout in LDS: a[k * BS + b]  (k = position on the line, b = line in the batch).
+// One stage of radix P:  b[t + s(Pq + k)] = (sum_j a[t + s(q + m j)] W_P^{jk}) * W_n^{q k s}.
+// ---------------------------------------------------------------------------------------------------
+template <typename Real> __device__ inline void bf2(Cx<Real>& a, Cx<Real>& b) { Cx<Real> t = {a.x - b.x, a.y - b.y}; a = {a.x + b.x, a.y + b.y}; b = t; }
+
+template <typename Real, int P> __device__ inline void butterflyGeneric(Cx<Real>* v, int sign) {
+    // O(P^2) DFT with compile-time twiddles (P = 3, 5, 7); after unrolling every cos/sin below is a constant.
+    Cx<Real> out[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) {
+        Cx<Real> acc = v[0];
+#pragma unroll
+        for (int j = 1; j < P; j++) {
+            const int e = (j * k) % P;
+            const double ang = -2.0 * SNB_PI * e / P;
+            const Real c = (Real)__builtin_cos(ang);
+            const Real sf = (Real)__builtin_sin(ang);       // forward: w = exp(-2 pi i e/P) = c + i*sf
+            const Real wy = (sign < 0) ? sf : -sf;
+            acc.x += v[j].x * c - v[j].y * wy;
+            acc.y += v[j].x * wy + v[j].y * c;
+        }
+        out[k] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < P; k++) v[k] = out[k];
+}
+
+template <typename Real, int P> __device__ inline void butterflyP(Cx<Real>* v, int sign) {
+    if (P == 2) {
+        bf2(v[0], v[1]);
+    } else if (P == 4) {
+        bf2(v[0], v[2]); bf2(v[1], v[3]);
+        // v[3] *= -i (forward) or +i (inverse)
+        Cx<Real> t = v[3];
+        if (sign < 0) v[3] = {t.y, -t.x}; else v[3] = {-t.y, t.x};
+        bf2(v[0], v[1]); bf2(v[2], v[3]);
+        // outputs in order 0,2,1,3 -> reorder
+        Cx<Real> o1 = v[2], o2 = v[1];
+        v[1] = o1; v[2] = o2;
+    } else {
+        butterflyGeneric<Real, P>(v, sign);
+    }
+}
+
+template <typename Real, int P>
+__device__ inline void fftStage(const Cx<Real>* a, Cx<Real>* b, int n, int len, int s, int sign, const Cx<Real>* tw, int nb, int BS, int tid, int nthreads) {
+    const int m = len / P;
+    const int perLine = n / P;
+    const int items = perLine * nb;
+    const float invNb = 1.0f / nb, invS = 1.0f / s;
+    for (int it = tid; it < items; it += nthreads) {
+        const int r = (int)((it + 0.5f) * invNb);
+        const int bi = it - r * nb;
+        const int q = (int)((r + 0.5f) * invS);
+        const int t = r - q * s;
+        Cx<Real> v[P];
+#pragma unroll
+        for (int j = 0; j < P; j++) v[j] = a[(t + s * (q + m * j)) * BS + bi];
+        butterflyP<Real, P>(v, sign);
+        const int base = t + s * P * q;
+#pragma unroll
+        for (int k = 0; k < P; k++) {
+            Cx<Real> o = v[k];
+            if (k > 0 && q > 0) {
+                Cx<Real> w = tw[q * k * s];
+                if (sign > 0) w.y = -w.y;
+                o = cmul(o, w);
+            }
+            b[(base + s * k) * BS + bi] = o;
+        }
+    }
+}
+
+// Runs all stages; returns the buffer holding the result.  Caller must __syncthreads() before reading it.
+template <typename Real>
+__device__ inline Cx<Real>* fftLines(Cx<Real>* a, Cx<Real>* b, int n, const int* factors, int nf, int sign, const Cx<Real>* tw, int nb, int BS, int tid, int nthreads) {
+    int len = n, s = 1;
+    for (int f = 0; f < nf; f++) {
+        const int P = factors[f];
+        __syncthreads();
+        switch (P) {
+            case 2: fftStage<Real, 2>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
+            case 3: fftStage<Real, 3>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
+            case 4: fftStage<Real, 4>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
+            case 5: fftStage<Real, 5>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
+            default: fftStage<Real, 7>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
+        }
+        Cx<Real>* tmp = a; a = b; b = tmp;
+        len /= P; s *= P;
+    }
+    return a;
+}
+
+extern __shared__ __align__(16) unsigned char s_dyn[];
+
+// ---- z axis: real <-> half-complex.  One work-group transforms NL contiguous lines. ----------------
+template <typename Real, bool FORWARD> __global__ __launch_bounds__(256) void k_fftZ(const PmeParams<Real> p, int NL) {
+    const int nz = p.d.nz, nzc = p.d.nzc;
+    const int BS = NL + 1;   // padded batch stride (bank spread for the transposing LDS accesses)
+    Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
+    Cx<Real>* B = A + (size_t)nz * BS;
+    const size_t nlines = (size_t)p.nsub * p.d.nx * p.d.ny;
+    const size_t line0 = (size_t)blockIdx.x * NL;
+    const int nb = (int)((nlines - line0) < (size_t)NL ? (nlines - line0) : (size_t)NL);
+    const int tid = threadIdx.x;
+    const Cx<Real>* tw = reinterpret_cast<const Cx<Real>*>(p.twz);
+    if (FORWARD) {
+        for (int it = tid; it < nb * nz; it += 256) {
+            const int l = it / nz, k = it - l * nz;
+            A[k * BS + l] = {p.gridReal[(line0 + l) * nz + k], Real(0)};
+        }
+        Cx<Real>* R = fftLines<Real>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, 256);
+        __syncthreads();
+        Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.gridCplx);
+        for (int it = tid; it < nb * nzc; it += 256) {
+            const int l = it / nzc, k = it - l * nzc;
+            out[(line0 + l) * nzc + k] = R[k * BS + l];
+        }
+    } else {
+        const Cx<Real>* in = reinterpret_cast<const Cx<Real>*>(p.gridCplx);
+        for (int it = tid; it < nb * nzc; it += 256) {
+            const int l = it / nzc, k = it - l * nzc;
+            const Cx<Real> v = in[(line0 + l) * nzc + k];
+            A[k * BS + l] = v;
+            if (k > 0 && nz - k >= nzc) A[(nz - k) * BS + l] = {v.x, -v.y};   // Hermitian half
+        }
+        Cx<Real>* R = fftLines<Real>(A, B, nz, p.d.fz, p.d.nfz, +1, tw, nb, BS, tid, 256);
+        __syncthreads();
+        for (int it = tid; it < nb * nz; it += 256) {
+            const int l = it / nz, k = it - l * nz;
+            p.gridReal[(line0 + l) * nz + k] = R[k * BS + l].x;
+        }
+    }
+}
+
+// ---- strided axis (y): tiles of NB adjacent lines (adjacent = consecutive complex elements in memory) ----
+// address(a, b, k) = a*strideA + b + k*strideK, b in [0, nbTotal)
+template <typename Real> __global__ __launch_bounds__(256) void k_fftStrided(const PmeParams<Real> p, int n, size_t strideA, int nbTotal, size_t strideK,
+                                                                          int NB, int tilesPerA, int sign, int axis) {
+    const int a = blockIdx.x / tilesPerA, tile = blockIdx.x - a * tilesPerA;
+    const int b0 = tile * NB;
+    const int nb = (nbTotal - b0) < NB ? (nbTotal - b0) : NB;
+    Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
+    Cx<Real>* B = A + (size_t)n * NB;
+    Cx<Real>* g = reinterpret_cast<Cx<Real>*>(p.gridCplx) + (size_t)a * strideA + b0;
+    const int tid = threadIdx.x;
+    for (int it = tid; it < n * nb; it += 256) {
+        const int k = it / nb, b = it - k * nb;
+        A[k * NB + b] = g[(size_t)k * strideK + b];
+    }
+    const Cx<Real>* tw = reinterpret_cast<const Cx<Real>*>(axis == 1 ? p.twy : p.twx);
+    Cx<Real>* R = fftLines<Real>(A, B, n, axis == 1 ? p.d.fy : p.d.fx, axis == 1 ? p.d.nfy : p.d.nfx, sign, tw, nb, NB, tid, 256);
+    __syncthreads();
+    for (int it = tid; it < n * nb; it += 256) {
+        const int k = it / nb, b = it - k * nb;
+        g[(size_t)k * strideK + b] = R[k * NB + b];
+    }
+}
+
+// ---- reciprocal-space kernel value (ReferencePME.cpp:425-471 Coulomb, :522-570 dispersion) -------------
+template <typename Real> __device__ inline Real recipTerm(const PmeParams<Real>& p, int kx, int ky, int kz) {
+    const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz;
+    const Real mx = (Real)((kx < (nx + 1) / 2) ? kx : kx - nx);
+    const Real my = (Real)((ky < (ny + 1) / 2) ? ky : ky - ny);
+    const Real mz = (Real)((kz < (nz + 1) / 2) ? kz : kz - nz);
+    const Real mhx = mx * p.recip[0];
+    const Real mhy = mx * p.recip[3] + my * p.recip[4];
+    const Real mhz = mx * p.recip[6] + my * p.recip[7] + mz * p.recip[8];
+    const Real m2 = mhx * mhx + mhy * mhy + mhz * mhz;
+    const Real bprod = p.modx[kx] * p.mody[ky] * p.modz[kz];
+    if (!p.dispersion) {
+        if (kx == 0 && ky == 0 && kz == 0) return Real(0);
+        const Real factor = Real(SNB_PI * SNB_PI) / (p.alpha * p.alpha);
+        const Real denom = m2 * Real(SNB_PI) * p.volume * bprod;
+        return Real(SNB_ONE_4PI_EPS0) * exp(-factor * m2) / denom;
+    } else {
+        const Real boxfactor = Real(-2 * SNB_PI * 1.7724538509055159) / (Real(6) * p.volume);
+        const Real denom = boxfactor / bprod;
+        const Real bfac = Real(SNB_PI) / p.alpha;
+        const Real fac1 = Real(2 * SNB_PI * SNB_PI * SNB_PI * 1.7724538509055159);
+        const Real fac2 = p.alpha * p.alpha * p.alpha;
+        const Real fac3 = Real(-2) * p.alpha * Real(SNB_PI * SNB_PI);
+        const Real m = sqrt(m2), m3 = m * m2, b = bfac * m;
+        return (fac1 * (Real)erfc((double)b) * m3 + exp(-b * b) * (fac2 + fac3 * m2)) * denom;
+    }
+}
+
+// ---- fused x-axis kernel: forward FFT_x, sliced energy, lambda-mixed convolution, inverse FFT_x ---------
+// One work-group owns NB adjacent (ky,kz) columns for ALL held subsets: batch index = sub*NB + col.
+template <typename Real> __global__ __launch_bounds__(256) void k_convolveX(const PmeParams<Real> p, int NB, int nCols) {
+    const int nx = p.d.nx, nsub = p.nsub;
+    const int BS = nsub * NB;
+    const int c0 = blockIdx.x * NB;
+    const int nbc = (nCols - c0) < NB ? (nCols - c0) : NB;
+    Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
+    Cx<Real>* B = A + (size_t)nx * BS;
+    Real* et = reinterpret_cast<Real*>(B + (size_t)nx * BS);          // [nx][NB]
+    __shared__ double s_red[4];
+    const size_t strideK = (size_t)nCols;                              // ny*nzc
+    const size_t strideSub = (size_t)nx * nCols;
+    Cx<Real>* g = reinterpret_cast<Cx<Real>*>(p.gridCplx);
+    const int tid = threadIdx.x;
+    // load: when nbc < NB the unused batch slots are zero-filled so the FFT can run on the full batch shape
+    for (int it = tid; it < nx * BS; it += 256) {
+        const int k = it / BS, bb = it - k * BS;
+        const int sub = bb / NB, col = bb - sub * NB;
+        Cx<Real> v = {Real(0), Real(0)};
+        if (col < nbc) v = g[sub * strideSub + (size_t)k * strideK + c0 + col];
+        A[k * BS + bb] = v;
+    }
+    const Cx<Real>* tw = reinterpret_cast<const Cx<Real>*>(p.twx);
+    Cx<Real>* S = fftLines<Real>(A, B, nx, p.d.fx, p.d.nfx, -1, tw, BS, BS, tid, 256);
+    Cx<Real>* O = (S == A) ? B : A;
+    __syncthreads();
+    // eterm per (kx, col)
+    for (int it = tid; it < nx * NB; it += 256) {
+        const int kx = it / NB, col = it - kx * NB;
+        Real e = 0;
+        if (col < nbc) {
+            const int c = c0 + col;
+            const int ky = c / p.d.nzc, kz = c - ky * p.d.nzc;
+            e = recipTerm<Real>(p, kx, ky, kz);
+        }
+        et[it] = e;
+    }
+    __syncthreads();
+    // per-slice energies: E_II = 1/2 sum_k eterm |S_I|^2 ; E_IJ = sum_k eterm Re(S_I conj S_J) (ReferencePME.cpp:487-491),
+    // over the full grid => Hermitian weight 2 for interior kz planes.
+    if (p.wantEnergy) {
+        const int term = p.dispersion ? 1 : 0;
+        for (int I = 0; I < nsub; I++)
+            for (int J = 0; J <= I; J++) {
+                double acc = 0;
+                for (int it = tid; it < nx * NB; it += 256) {
+                    const int kx = it / NB, col = it - kx * NB;
+                    if (col >= nbc) continue;
+                    const int kz = (c0 + col) % p.d.nzc;
+                    const Real w = (kz == 0 || (2 * kz == p.d.nz)) ? Real(1) : Real(2);
+                    const Cx<Real> a = S[kx * BS + I * NB + col], b = S[kx * BS + J * NB + col];
+                    acc += (double)(w * et[it] * (a.x * b.x + a.y * b.y));
+                }
+                if (I == J) acc *= 0.5;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                __syncthreads();
+                if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+                __syncthreads();
+                if (tid == 0) {
+                    const int gi = p.gridSubset[I], gj = p.gridSubset[J];
+                    const int slice = gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi;
+                    atomicAdd(&p.sliceE[2 * slice + term], s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+                }
+            }
+    }
+    // convolution with the lambda mix:  O_I = eterm * sum_J lambda[slice(I,J)][term] * S_J   (mix=0: O_I = eterm * S_I)
+    {
+        const int term = p.dispersion ? 1 : 0;
+        for (int it = tid; it < nx * BS; it += 256) {
+            const int k = it / BS, bb = it - k * BS;
+            const int I = bb / NB, col = bb - I * NB;
+            Cx<Real> acc = {Real(0), Real(0)};
+            if (p.mix) {
+                const int gi = p.gridSubset[I];
+                for (int J = 0; J < nsub; J++) {
+                    const int gj = p.gridSubset[J];
+                    const int slice = gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi;
+                    const Real lam = p.lambdas[2 * slice + term];
+                    const Cx<Real> v = S[k * BS + J * NB + col];
+                    acc.x += lam * v.x; acc.y += lam * v.y;
+                }
+            } else
+                acc = S[it];
+            const Real e = et[k * NB + col];
+            O[it] = {acc.x * e, acc.y * e};
+        }
+    }
+    Cx<Real>* R = fftLines<Real>(O, S, nx, p.d.fx, p.d.nfx, +1, tw, BS, BS, tid, 256);
+    __syncthreads();
+    for (int it = tid; it < nx * BS; it += 256) {
+        const int k = it / BS, bb = it - k * BS;
+        const int sub = bb / NB, col = bb - sub * NB;
+        if (col < nbc) g[sub * strideSub + (size_t)k * strideK + c0 + col] = R[it];
+    }
+}
+
+static size_t ldsBudget() { return 96 * 1024; }
+
+template <typename Real> static int pickBatch(size_t bytesPerBatchElem, int maxB, int minB = 1) {
+    int b = (int)(ldsBudget() / bytesPerBatchElem);
+    if (b > maxB) b = maxB;
+    if (b < minB) b = minB;
+    return b;
+}
+
+template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s) {
+    const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc;
+    // z: real -> half complex
+    {
+        int NL = pickBatch<Real>((size_t)2 * nz * sizeof(Cx<Real>), 17) - 1;   // padded stride NL+1 must be odd
+        NL &= ~1;
+        if (NL < 2) NL = 2;
+        const size_t lds = (size_t)2 * nz * (NL + 1) * sizeof(Cx<Real>);
+        const size_t nlines = (size_t)p.nsub * nx * ny;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_fftZ<Real, true>), dim3((unsigned)((nlines + NL - 1) / NL)), dim3(256), lds, s, p, NL);
+    }
+    // y
+    {
+        const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), 16);
+        const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>);
+        const int tilesPerA = (nzc + NB - 1) / NB;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_fftStrided<Real>), dim3((unsigned)(p.nsub * nx * tilesPerA)), dim3(256), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB,
+                           tilesPerA, -1, 1);
+    }
+}
+
+template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hipStream_t s) {
+    const int nx = p.d.nx;
+    const int nCols = p.d.ny * p.d.nzc;
+    const size_t perCol = (size_t)2 * nx * p.nsub * sizeof(Cx<Real>) + (size_t)nx * sizeof(Real);
+    const int NB = pickBatch<Real>(perCol, 16);
+    const size_t lds = perCol * NB;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_convolveX<Real>), dim3((unsigned)((nCols + NB - 1) / NB)), dim3(256), lds, s, p, NB, nCols);
+}
+
+template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipStream_t s) {
+    const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc;
+    {
+        const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), 16);
+        const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>);
+        const int tilesPerA = (nzc + NB - 1) / NB;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_fftStrided<Real>), dim3((unsigned)(p.nsub * nx * tilesPerA)), dim3(256), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB,
+                           tilesPerA, +1, 1);
+    }
+    {
+        int NL = pickBatch<Real>((size_t)2 * nz * sizeof(Cx<Real>), 17) - 1;   // padded stride NL+1 must be odd
+        NL &= ~1;
+        if (NL < 2) NL = 2;
+        const size_t lds = (size_t)2 * nz * (NL + 1) * sizeof(Cx<Real>);
+        const size_t nlines = (size_t)p.nsub * nx * ny;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_fftZ<Real, false>), dim3((unsigned)((nlines + NL - 1) / NL)), dim3(256), lds, s, p, NL);
+    }
+}
+
+// x axis alone (used by the FFT unit-test hook; the pipeline itself uses the fused k_convolveX)
+template <typename Real> void launchPmeFFTX(const PmeParams<Real>& p, int sign, hipStream_t s) {
+    const int nx = p.d.nx, nCols = p.d.ny * p.d.nzc;
+    const int NB = pickBatch<Real>((size_t)2 * nx * sizeof(Cx<Real>), 16);
+    const size_t lds = (size_t)2 * nx * NB * sizeof(Cx<Real>);
+    const int tilesPerA = (nCols + NB - 1) / NB;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_fftStrided<Real>), dim3((unsigned)(p.nsub * tilesPerA)), dim3(256), lds, s, p, nx, (size_t)nx * nCols, nCols, (size_t)nCols, NB,
+                       tilesPerA, sign, 0);
+}
+template void launchPmeFFTX<float>(const PmeParams<float>&, int, hipStream_t);
+template void launchPmeFFTX<double>(const PmeParams<double>&, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------
+// Force interpolation (ReferencePME.cpp:598-702): 32 lanes per atom, lane = (x,y) stencil row.
+// Unsharded: the atom reads the one pre-mixed grid of its own subset.  Sharded (mix=0): it loops over the
+// grids this engine holds, scaling by lambda[slice(s_i, J)], and also accumulates E = 1/2 q psi_J(r_i).
+// ---------------------------------------------------------------------------------------------------
+template <typename Real> __global__ __launch_bounds__(256) void k_interpolate(const PmeParams<Real> p) {
+    const int gid = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int r = threadIdx.x & 31;
+    if (gid >= p.natoms) return;
+    const int si = p.atomSubset[gid];
+    const Real q = si >= 0 ? pmeCharge(p, gid) : Real(0);
+    const auto pos = p.posq[gid];
+    int idx[3]; Real fr[3];
+    gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, p.d.nz, idx, fr);
+    Real tx[5], ty[5], tz[5], dx[5], dy[5], dz[5];
+    bspline5<Real>(fr[0], tx, dx); bspline5<Real>(fr[1], ty, dy); bspline5<Real>(fr[2], tz, dz);
+    Real fx = 0, fy = 0, fz = 0;
+    const int term = p.dispersion ? 1 : 0;
+    if (r < 25 && si >= 0 && q != Real(0)) {
+        const int ix = r / 5, iy = r - ix * 5;
+        int xi = idx[0] + ix; if (xi >= p.d.nx) xi -= p.d.nx;
+        int yi = idx[1] + iy; if (yi >= p.d.ny) yi -= p.d.ny;
+        Real txv = 0, dxv = 0, tyv = 0, dyv = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { if (k == ix) { txv = tx[k]; dxv = dx[k]; } if (k == iy) { tyv = ty[k]; dyv = dy[k]; } }
+        const int nG = p.mix ? 1 : p.nsub;
+        for (int gI = 0; gI < nG; gI++) {
+            int slot; Real lam = 1;
+            if (p.mix) slot = p.atomGrid[gid];   // own subset's mixed grid
+            else {
+                slot = gI;
+                const int gj = p.gridSubset[gI];
+                const int slice = si > gj ? si * (si + 1) / 2 + gj : gj * (gj + 1) / 2 + si;
+                lam = p.lambdas[2 * slice + term];
+            }
+            if (slot < 0) continue;
+            const Real* row = p.gridReal + (((size_t)slot * p.d.nx + xi) * p.d.ny + yi) * p.d.nz;
+            Real sz = 0, sdz = 0;
+#pragma unroll
+            for (int iz = 0; iz < 5; iz++) {
+                int zi = idx[2] + iz; if (zi >= p.d.nz) zi -= p.d.nz;
+                const Real gv = row[zi];
+                sz += tz[iz] * gv; sdz += dz[iz] * gv;
+            }
+            fx += lam * dxv * tyv * sz; fy += lam * txv * dyv * sz; fz += lam * txv * tyv * sdz;
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { fx += __shfl_xor(fx, o, 64); fy += __shfl_xor(fy, o, 64); fz += __shfl_xor(fz, o, 64); }
+    if (r == 0) {
+        const Real nx = p.d.nx, ny = p.d.ny, nz = p.d.nz;
+        const Real gx = -q * (fx * nx * p.recip[0]);
+        const Real gy = -q * (fx * nx * p.recip[3] + fy * ny * p.recip[4]);
+        const Real gz = -q * (fx * nx * p.recip[6] + fy * ny * p.recip[7] + fz * nz * p.recip[8]);
+        if (p.dispersion) { p.fpx[gid] += gx; p.fpy[gid] += gy; p.fpz[gid] += gz; }   // second pipeline of LJPME adds
+        else { p.fpx[gid] = gx; p.fpy[gid] = gy; p.fpz[gid] = gz; }
+    }
+}
+
+template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s) {
+    if (p.natoms <= 0) return;
+    hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), 0, s, p);
+}
+
+template void launchPmeSpread<float>(const PmeParams<float>&, hipStream_t);
+template void launchPmeSpread<double>(const PmeParams<double>&, hipStream_t);
+template void launchPmeForwardFFT<float>(const PmeParams<float>&, hipStream_t);
+template void launchPmeForwardFFT<double>(const PmeParams<double>&, hipStream_t);
+template void launchPmeConvolution<float>(const PmeParams<float>&, hipStream_t);
+template void launchPmeConvolution<double>(const PmeParams<double>&, hipStream_t);
+template void launchPmeInverseFFT<float>(const PmeParams<float>&, hipStream_t);
+template void launchPmeInverseFFT<double>(const PmeParams<double>&, hipStream_t);
+template void launchPmeInterpolate<float>(const PmeParams<float>&, hipStream_t);
+template void launchPmeInterpolate<double>(const PmeParams<double>&, hipStream_t);
+
+// ---- host helpers ---------------------------------------------------------------------------------
+bool factorize(int n, int* factors, int* nf) {
+    int k = 0;
+    while (n % 4 == 0) { factors[k++] = 4; n /= 4; }
+    while (n % 2 == 0) { factors[k++] = 2; n /= 2; }
+    while (n % 3 == 0) { factors[k++] = 3; n /= 3; }
+    while (n % 5 == 0) { factors[k++] = 5; n /= 5; }
+    while (n % 7 == 0) { factors[k++] = 7; n /= 7; }
+    *nf = k;
+    return n == 1 && k <= 16;
+}
+
+int legalGridSize(int n) {
+    if (n < 6) n = 6;
+    for (;; n++) {
+        int f[32], nf, m = n;
+        for (int p : {2, 3, 5, 7}) while (m % p == 0) m /= p;
+        if (m == 1 && factorize(n, f, &nf)) return n;
+    }
+}
+
+}  // namespace snb

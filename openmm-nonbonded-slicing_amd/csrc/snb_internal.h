@@ -1,0 +1,119 @@
+// snb_internal.h -- shared declarations of the MI355X SlicedNonbondedForce engine (not part of the C ABI).
+//
+// Data layout in HBM (see DESIGN.md "Data layout"):
+//   atoms are kept in a SORTED order: by subset, then along a serpentine path of xy-columns, by z inside a
+//   column; each subset is padded to a multiple of 32 so that every 32-atom BLOCK has one subset.  All hot
+//   arrays are struct-of-arrays over the sorted index:
+//     posq   : Real4[Npad]   x,y,z (box-wrapped at build time, continuous afterwards), q
+//     sigeps : Real2[Npad]   sigma/2, 2*sqrt(epsilon)      (reference convention, ReferenceNonbondedSlicingKernels.cpp:364-368)
+//     fx,fy,fz : Real[Npad]  direct-space force accumulators (atomics)
+//   tiles (32 i-atoms of one block x 32 individually gathered j-atoms of ONE subset):
+//     tileJ    : int32[T][32]  sorted j index | (periodic-image code << 27)
+//     tileInfo : int4[T]       x = j subset, y = exclusion-mask index or -1
+//     masks    : uint32[M][32] bit j of word i set = pair (i,j) excluded
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#define SNB_ONE_4PI_EPS0 138.93545764438198
+#define SNB_PI 3.14159265358979323846
+#define SNB_EPSILON0 (1.0 / (4.0 * SNB_PI * SNB_ONE_4PI_EPS0))
+#define SNB_JIDX_MASK 0x07FFFFFF
+#define SNB_JSHIFT_BITS 27
+#define SNB_PME_ORDER 5
+
+namespace snb {
+
+template <typename Real> struct Vec;
+template <> struct Vec<float> { using T2 = float2; using T4 = float4; };
+template <> struct Vec<double> { using T2 = double2; using T4 = double4; };
+
+// Method classes the pair kernel is compiled for.
+enum { MC_NOCUTOFF = 0, MC_RF = 1, MC_EWALD = 2, MC_LJPME = 3 };
+
+template <typename Real> struct DirectParams {
+    const typename Vec<Real>::T4* posq;
+    const typename Vec<Real>::T2* sigeps;
+    const int* blockSubset;   // [numBlocks]
+    const int2* blockTiles;   // [numBlocks] (first tile, tile count)
+    const int* workOrder;     // [numWork] block ids, longest first
+    const int* tileJ;         // [T*32]
+    const int4* tileInfo;     // [T]
+    const unsigned* masks;    // [M*32]
+    Real* fx; Real* fy; Real* fz;
+    double* sliceE;           // [S*2] raw energies
+    const Real* lambdas;      // [S*2]
+    int numWork, workStart, workStride;   // sharding: items workStart, workStart+workStride, ...
+    int nsub;
+    Real cutoff2, krf, crf, alpha, alphaD, k4pe;          // k4pe = ONE_4PI_EPS0
+    Real invCut6, multShift6;                              // LJPME potential shifts
+    int useSwitch; Real switchDist, invSwitchWidth;
+    Real box[9]; Real invBoxDiag[3];                       // for the per-pair wrap variant
+    Real shifts[27 * 3];                                   // periodic image vectors, code = (sx+1)*9+(sy+1)*3+(sz+1)
+};
+
+template <typename Real> struct PairListParams {  // exceptions (1-4) and exclusion corrections: one thread per pair
+    const typename Vec<Real>::T4* posq;
+    const int2* pairs;        // sorted indices
+    const typename Vec<Real>::T4* params;   // 1-4: (sigma, 4 eps, k*qq, slice bits) ; exclusion: (k*qi*qj, c6i*c6j, -, slice bits)
+    int n;
+    Real* fx; Real* fy; Real* fz;
+    double* sliceE;
+    const Real* lambdas;
+    int periodic;
+    Real box[9];
+    Real alpha, alphaD;
+    int ljpme;
+};
+
+struct PmePlanDims {
+    int nx, ny, nz, nzc;      // nzc = nz/2+1
+    int nfx, nfy, nfz;        // number of radix factors per axis
+    int fx[16], fy[16], fz[16];
+};
+
+template <typename Real> struct PmeParams {
+    PmePlanDims d;
+    int nsub;                 // grids held (all subsets, or this shard's)
+    int natoms;               // padded sorted atoms
+    const typename Vec<Real>::T4* posq;
+    const typename Vec<Real>::T2* sigeps;
+    const int* atomSubset;    // [Npad] sorted
+    const int* atomGrid;      // [Npad] grid slot of the atom's subset, or -1 (not owned / padding)
+    Real* gridReal;           // [nsub][nx][ny][nz]
+    typename Vec<Real>::T2* gridCplx;   // [nsub][nx][ny][nzc]
+    const typename Vec<Real>::T2* twx; const typename Vec<Real>::T2* twy; const typename Vec<Real>::T2* twz;   // roots of unity exp(-2 pi i k/n)
+    const Real* modx; const Real* mody; const Real* modz;       // B-spline moduli
+    Real recip[9];            // reciprocal box (ReferencePME.cpp:186-194)
+    Real alpha, volume;
+    int dispersion;           // 0: Coulomb charges & kernel, 1: LJPME dispersion
+    const Real* lambdas;      // [S*2]
+    const int* gridSubset;    // [nsub] subset id of each held grid
+    int nsubTotal;
+    int mix;                  // 1: lambda-mix the potentials in k-space (unsharded); 0: plain convolution (sharded)
+    double* sliceE;
+    Real* fpx; Real* fpy; Real* fpz;   // reciprocal force accumulators (plain stores when unsharded)
+    int wantEnergy;
+};
+
+// ---- launchers implemented in the .hip translation units -------------------------------------
+template <typename Real> void launchDirect(const DirectParams<Real>& p, int methodClass, bool wrap, bool energy, hipStream_t s);
+template <typename Real> void launchExceptions(const PairListParams<Real>& p, bool energy, hipStream_t s);
+template <typename Real> void launchExclusionCorrection(const PairListParams<Real>& p, bool energy, hipStream_t s);
+template <typename Real> void launchPmeSpread(const PmeParams<Real>& p, hipStream_t s);
+template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s);
+template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hipStream_t s);   // fused x-FFT, energy, convolution, inverse x-FFT
+template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipStream_t s);
+template <typename Real> void launchPmeFFTX(const PmeParams<Real>& p, int sign, hipStream_t s);   // x axis alone (test hook)
+template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s);
+template <typename Real> void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
+                                                    typename Vec<Real>::T4* posq, int nPadded, hipStream_t s);
+template <typename Real> void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, const Real* fpx, const Real* fpy, const Real* fpz,
+                                                 const int* userToSorted, int nAtoms, void* out, int isDouble, int accumulate, hipStream_t s);
+
+int legalGridSize(int n);
+bool factorize(int n, int* factors, int* nfactors);
+
+}  // namespace snb

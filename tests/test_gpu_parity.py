@@ -1,0 +1,154 @@
+"""Parity tests proper (-m gpu): the HIP engine, driven through the C ABI (include/snb.h) by the host-side mirror
+of the reference interface, against (a) the reference's closed-form known answers and (b) the CPU oracle on
+identical seeded inputs.  Tolerances: 1e-3 single / 1e-5 double relative with the reference's max(|x|,1) scaling
+(BASELINE.json north_star; openmmapi/include/internal/AssertionUtilities.h:7-26)."""
+import functools
+
+import numpy as np
+import pytest
+
+import kat_cases as K
+import systems
+
+pytestmark = pytest.mark.gpu
+
+TOLS = {"single": 1e-3, "double": 1e-5}
+
+
+def make_ev(snb, precision, **opts):
+    def ev(force, positions, box=None, parameters=None, include_direct=True, include_reciprocal=True):
+        positions = np.asarray(positions, dtype=float).reshape(-1, 3)
+        system = snb.System()
+        for _ in range(force.getNumParticles()):
+            system.addParticle(1.0)
+        if box is not None:
+            system.setDefaultPeriodicBoxVectors(*np.asarray(box, dtype=float))
+        system.addForce(force)
+        force.setForceGroup(0); force.setReciprocalSpaceForceGroup(1)
+        ctx = snb.Context(system, precision=precision, **opts)
+        if parameters:
+            for k, v in parameters.items():
+                ctx.setParameter(k, v)
+        ctx.setPositions(positions)
+        groups = (1 if include_direct else 0) | (2 if include_reciprocal else 0)
+        st = ctx.getState(getEnergy=True, getForces=True, getParameterDerivatives=True, groups=groups)
+        kern = ctx._kernelFor(force)
+        return dict(energy=st.getPotentialEnergy(), forces=st.getForces(), derivatives=st.getEnergyParameterDerivatives(),
+                    slice_energies=kern.lastSliceEnergies.copy(), lambdas=kern._lastLambdas.copy(), stats=kern.getStats())
+    return ev
+
+
+@pytest.fixture(scope="module")
+def F(snb):
+    return snb.SlicedNonbondedForce
+
+
+@pytest.fixture(scope="module", params=["single", "double"])
+def prec(request):
+    return request.param
+
+
+def test_native_library_loaded(snb):
+    L = snb.capi.lib()
+    assert L.snb_abi_version() == 1
+
+
+@pytest.mark.parametrize("case", ["testCoulomb", "testLJ", "testExclusionsAnd14", "testCutoff", "testCutoff14", "testPeriodic",
+                                  "testPeriodicExceptions", "testTriclinic", "testDispersionCorrection", "testTwoForces",
+                                  "testParameterOffsets", "testEwaldExceptions", "testDirectAndReciprocal"])
+def test_reference_kat(case, snb, F, prec):
+    tol = 1e-3 if prec == "single" else K.TOL
+    kw = {}
+    if case == "testTriclinic":
+        kw = dict(tol=1e-3 if prec == "single" else 1e-4, iterations=12)
+    elif case in ("testEwaldExceptions", "testDirectAndReciprocal", "testParameterOffsets"):
+        kw = dict(tol=tol)
+    else:
+        kw = dict(tol=tol)
+    getattr(K, case)(make_ev(snb, prec), F, **kw)
+
+
+def test_switching_function(snb, F, prec):
+    tol = 1e-3 if prec == "single" else K.TOL
+    K.testSwitchingFunction(make_ev(snb, prec), F, 1, tol=tol, fd_tol=3e-3 if prec == "single" else 1e-3)
+    if prec == "double":
+        K.testSwitchingFunction(make_ev(snb, prec), F, 4, pme=(2.0, 30, 30, 30), tol=tol)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2, 4, 5])
+@pytest.mark.parametrize("exceptions", [False, True])
+@pytest.mark.parametrize("lj", [False, True])
+def test_nonbonded_slicing(method, exceptions, lj, snb, F, prec):
+    n = 28 if exceptions else 40
+    K.testNonbondedSlicing(make_ev(snb, prec), F, method, exceptions, lj, tol=2e-3 if prec == "single" else K.TOL,
+                           pme=(1.0, n, n, n) if method in (4, 5) else None, ljpme=(1.0, n, n, n) if method == 5 else None)
+
+
+def _compare(ev, oev, force, pos, box, tol, **okw):
+    r = ev(force, pos, box)
+    o = oev(force, pos, box, **okw)
+    K.assertEqualTo(o["energy"], r["energy"], tol)
+    S = o["slice_energies"].shape[0]
+    for s in range(S):
+        for t in range(2):
+            K.assertEqualTo(o["slice_energies"][s, t], r["slice_energies"][s, t], tol)
+    fo, fr = o["forces"], r["forces"]
+    scale = np.maximum(np.linalg.norm(fo, axis=1), 1.0)
+    err = np.linalg.norm(fo - fr, axis=1) / scale
+    assert err.max() <= tol, "max force error %g at atom %d" % (err.max(), int(err.argmax()))
+    for k, v in o["derivatives"].items():
+        K.assertEqualTo(v, r["derivatives"][k], tol)
+    return r, o
+
+
+@pytest.fixture(scope="module")
+def oev(oracle):
+    def _o(force, positions, box=None, parameters=None, include_direct=True, include_reciprocal=True, **kw):
+        return oracle.evaluate(force, np.asarray(positions, dtype=float), box, parameters, include_direct, include_reciprocal, **kw)
+    return _o
+
+
+CASES = [
+    # name, n, nsub, method, L, cutoff, pme, ljpme, switch
+    ("C1_nocutoff_1000_n2", 1000, 2, 0, 2.154, 1.0, None, None, False),
+    ("rf_periodic_3000_n3", 3000, 3, 2, 3.2, 1.0, None, None, True),
+    ("cutoff_nonperiodic_2000_n2", 2000, 2, 1, 2.8, 1.0, None, None, False),
+    ("pme_4096_n2", 4096, 2, 4, 3.5, 1.0, (2.6283, 32, 32, 32), None, False),
+    ("pme_6000_n4", 6000, 4, 4, 4.0, 1.0, (2.6283, 36, 36, 36), None, True),
+    ("ljpme_3000_n4", 3000, 4, 5, 3.2, 1.0, (2.6283, 28, 28, 28), (2.6283, 20, 20, 20), False),
+    ("pme_smallbox_wrap_600_n2", 600, 2, 4, 2.05, 1.0, (2.6283, 20, 20, 20), None, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_random_system_vs_oracle(case, snb, F, oev, prec):
+    name, n, nsub, method, L, cutoff, pme, ljpme, switch = case
+    force, pos, box = systems.random_box(F, n, nsub, method, L, cutoff, pme=pme, ljpme=ljpme, switch=switch)
+    r, o = _compare(make_ev(snb, prec), oev, force, pos, box, TOLS[prec])
+    assert r["stats"].n_tiles > 0
+
+
+def test_padding_and_rebuild_interval(snb, F, oev):
+    """Tiles built with a skin and reused across steps must give the same answer as a fresh list."""
+    force, pos, box = systems.random_box(F, 4096, 2, 4, 3.5, 1.0, pme=(2.6283, 32, 32, 32))
+    ev = make_ev(snb, "double", neighbor_padding=0.15, rebuild_interval=10)
+    _compare(ev, oev, force, pos, box, 1e-5)
+
+
+def test_fft_against_numpy(snb):
+    import ctypes
+    L = snb.capi.lib()
+    rng = np.random.default_rng(3)
+    dp = ctypes.POINTER(ctypes.c_double)
+    # sizes of the reference's FFT tests (platforms/cuda/tests/TestCudaCuFFT3D.cpp:36-141) plus the bench grids
+    for prec, tol in ((1, 1e-10), (0, 2e-4)):
+        for (nx, ny, nz), batch in [((28, 25, 25), 1), ((25, 28, 25), 2), ((25, 25, 28), 3), ((21, 25, 27), 2), ((28, 25, 30), 1), ((80, 80, 80), 2), ((120, 120, 120), 1)]:
+            a = rng.standard_normal((batch, nx, ny, nz))
+            spec = np.zeros((batch, nx, ny, nz // 2 + 1, 2)); rt = np.zeros_like(a)
+            st = L.snb_test_fft3d(prec, 0, batch, nx, ny, nz, a.ctypes.data_as(dp), spec.ctypes.data_as(dp), rt.ctypes.data_as(dp))
+            assert st == 0
+            ref = np.fft.rfftn(a, axes=(1, 2, 3))
+            got = spec[..., 0] + 1j * spec[..., 1]
+            scale = np.abs(ref).max()
+            assert np.abs(got - ref).max() / scale < tol, (prec, nx, ny, nz)
+            assert np.abs(rt / (nx * ny * nz) - a).max() < tol * 10, (prec, nx, ny, nz)

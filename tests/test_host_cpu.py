@@ -1,0 +1,94 @@
+"""CPU-only checks of the host side: the interface mirror's error behaviour, and that the C-ABI library loads and
+exports every symbol include/snb.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+def test_header_symbols_exported(snb):
+    capi = snb.capi
+    capi.build()
+    L = capi.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "snb.h")).read()
+    declared = set(re.findall(r"\b(snb_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name)
+    assert L.snb_abi_version() == capi.SNB_ABI_VERSION
+
+
+def test_struct_layout_matches_header(snb):
+    capi = snb.capi
+    # sizes follow from the field lists in include/snb.h (natural alignment)
+    assert ctypes.sizeof(capi.SnbConfig) == 8 * 4 + 4 * 8 + 6 * 4 + 8 + 3 * 4 + 4 + 8 + 3 * 4 + 4 + 8
+    assert ctypes.sizeof(capi.SnbStats) == 7 * 8 + 6 * 4 + 4 * 8
+
+
+def test_legal_grid_sizes(snb):
+    L = snb.capi.lib()
+    for n, want in [(80, 80), (116, 120), (173, 175), (87, 90), (121, 125), (5, 6), (97, 98), (1021, 1024)]:
+        assert L.snb_legal_grid_size(n) == want
+
+
+def test_create_without_gpu_fails_loudly(snb):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    capi = snb.capi
+    cfg = capi.SnbConfig(); cfg.abi_version = 1; cfg.n_atoms = 2; cfg.n_subsets = 1; cfg.method = 0; cfg.precision = 0
+    h = ctypes.c_void_p()
+    st = capi.lib().snb_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert st == capi.SNB_ERR_HIP and not h
+    assert b"no HIP device" in capi.lib().snb_last_error(None)
+    f = snb.SlicedNonbondedForce(1); f.addParticle(0, 1, 0); f.addParticle(0, 1, 0)
+    s = snb.System(); s.addParticle(1); s.addParticle(1); s.addForce(f)
+    with pytest.raises(snb.OpenMMException):
+        snb.Context(s)
+
+
+def test_dispersion_coefficients_host_helper_matches_oracle(snb, oracle):
+    rng = np.random.default_rng(0)
+    n, nsub = 500, 3
+    f = snb.SlicedNonbondedForce(nsub)
+    f.setNonbondedMethod(2); f.setCutoffDistance(1.1); f.setUseSwitchingFunction(True); f.setSwitchingDistance(0.9)
+    for i in range(n):
+        f.addParticle(0.0, rng.choice([0.3, 0.31, 0.25]), rng.choice([0.5, 0.7])); f.setParticleSubset(i, int(rng.integers(0, nsub)))
+    want = oracle.dispersion_coefficients(f)
+    sig = np.array([f.getParticleParameters(i)[1] for i in range(n)]); eps = np.array([f.getParticleParameters(i)[2] for i in range(n)])
+    sub = np.array([f.getParticleSubset(i) for i in range(n)], dtype=np.int32)
+    out = np.zeros(nsub * (nsub + 1) // 2)
+    dp = ctypes.POINTER(ctypes.c_double)
+    st = snb.capi.lib().snb_compute_dispersion_coefficients(n, nsub, sig.ctypes.data_as(dp), eps.ctypes.data_as(dp), sub.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                           1.1, 1, 0.9, out.ctypes.data_as(dp))
+    assert st == 0
+    np.testing.assert_allclose(out, want, rtol=1e-12)
+
+
+def test_scaling_parameter_clash_rules(snb):
+    # python/tests/TestSlicedNonbondedForce.py:51-67
+    f = snb.SlicedNonbondedForce(2)
+    f.addGlobalParameter("lambda", 1.0); f.addGlobalParameter("lambda2", 1.0)
+    f.addScalingParameter("lambda", 0, 1, True, True)
+    with pytest.raises(snb.OpenMMException):
+        f.addScalingParameter("lambda2", 0, 1, True, False)
+    with pytest.raises(snb.OpenMMException):
+        f.addScalingParameter("lambda2", 1, 0, False, True)
+    f.addScalingParameter("lambda2", 1, 1, True, False)
+    with pytest.raises(snb.OpenMMException):
+        f.addScalingParameter("lambda", 0, 0, False, False)
+    with pytest.raises(snb.OpenMMException):
+        f.addScalingParameter("nope", 0, 0, True, True)
+    with pytest.raises(snb.OpenMMException):
+        f.setParticleSubset(0, 0)   # no particles yet: index out of range
+    f.addParticle(0, 1, 0)
+    with pytest.raises(snb.OpenMMException):
+        f.setParticleSubset(0, 2)
+    assert f.getNumSlices() == 3 and snb.sliceIndex(1, 0) == 1 and snb.sliceIndex(1, 1) == 2
+    f.addEnergyParameterDerivative("lambda")
+    with pytest.raises(snb.OpenMMException):
+        f.addEnergyParameterDerivative("lambda")
+    assert f.getEnergyParameterDerivativeName(0) == "lambda"
