@@ -498,6 +498,19 @@ public:
                     hMasks[(size_t)tileMask[t] * 32 + k] |= 1u << bit;
                 }
             }
+            // padding slots (partially filled tiles, padded i rows) are masked out as well, so that parked padding
+            // coordinates can never contribute (in the per-pair-wrap variant they would be folded back into the box)
+            {
+                unsigned iPadRows = 0;
+                for (int k = 0; k < 32; k++) if (sortedToUser[I * 32 + k] < 0) iPadRows |= 1u << k;
+                for (int t = 0; t < (int)tileMask.size(); t++) {
+                    unsigned jPad = 0;
+                    for (int k = 0; k < 32; k++) if (hTileJ[(size_t)(firstTile + t) * 32 + k] < 0) jPad |= 1u << k;
+                    if (!jPad && !iPadRows) continue;
+                    if (tileMask[t] < 0) { tileMask[t] = (int)(hMasks.size() / 32); hMasks.resize(hMasks.size() + 32, 0u); hTileInfo[firstTile + t].y = tileMask[t]; }
+                    for (int k = 0; k < 32; k++) hMasks[(size_t)tileMask[t] * 32 + k] |= ((iPadRows >> k) & 1u) ? 0xFFFFFFFFu : jPad;
+                }
+            }
             for (int t = 0; t < (int)tileMask.size(); t++) if (tileMask[t] >= 0) numMaskTiles++;
             // reset the scratch map
             for (int k = 0; k < 32; k++) slotOf[I * 32 + k] = -1;
