@@ -87,6 +87,10 @@ typedef struct {
     double  last_recip_ms;      /* HIP-event time of the last reciprocal pipeline (all its kernels)     */
     double  last_total_ms;      /* HIP-event time of the last snb_execute (all kernels)                 */
     double  last_rebuild_ms;    /* wall time of the last neighbour rebuild                              */
+    double  sum_direct_ms;      /* cumulative HIP-event times since snb_reset_timers (harvested lazily,   */
+    double  sum_recip_ms;       /*   no per-step host synchronisation)                                  */
+    double  sum_total_ms;
+    int64_t n_timed;            /* executes included in the sums                                        */
 } snb_stats;
 
 /* -- lifetime ---------------------------------------------------------------------------------- */
@@ -134,6 +138,7 @@ snb_status snb_synchronize(snb_handle h);
 snb_status snb_get_pme_parameters(snb_handle h, double* alpha, int32_t grid[3]);
 snb_status snb_get_ljpme_parameters(snb_handle h, double* alpha, int32_t grid[3]);
 snb_status snb_get_stats(snb_handle h, snb_stats* out);
+snb_status snb_reset_timers(snb_handle h);
 /* Smallest FFT-legal mesh size >= n (radices 2,3,5,7). */
 int32_t    snb_legal_grid_size(int32_t n);
 int32_t    snb_abi_version(void);

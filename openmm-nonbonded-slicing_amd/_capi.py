@@ -18,7 +18,7 @@ SYMBOLS = [
     "snb_create", "snb_destroy", "snb_last_error", "snb_set_particles", "snb_set_exceptions", "snb_set_lambdas",
     "snb_set_dispersion_coefficients", "snb_compute_dispersion_coefficients", "snb_set_box", "snb_set_positions",
     "snb_rebuild_neighbors", "snb_execute", "snb_get_forces", "snb_get_slice_energies", "snb_synchronize",
-    "snb_get_pme_parameters", "snb_get_ljpme_parameters", "snb_get_stats", "snb_legal_grid_size", "snb_abi_version",
+    "snb_get_pme_parameters", "snb_get_ljpme_parameters", "snb_get_stats", "snb_reset_timers", "snb_legal_grid_size", "snb_abi_version",
     "snb_test_fft3d",
 ]
 
@@ -41,7 +41,8 @@ class SnbStats(ctypes.Structure):
         ("n_tiles", ctypes.c_int64), ("n_blocks", ctypes.c_int64), ("n_padded_atoms", ctypes.c_int64), ("n_exclusion_tiles", ctypes.c_int64),
         ("n_exclusions", ctypes.c_int64), ("n_14", ctypes.c_int64), ("n_rebuilds", ctypes.c_int64), ("grid", ctypes.c_int32 * 3),
         ("dgrid", ctypes.c_int32 * 3), ("last_direct_ms", ctypes.c_double), ("last_recip_ms", ctypes.c_double),
-        ("last_total_ms", ctypes.c_double), ("last_rebuild_ms", ctypes.c_double),
+        ("last_total_ms", ctypes.c_double), ("last_rebuild_ms", ctypes.c_double), ("sum_direct_ms", ctypes.c_double),
+        ("sum_recip_ms", ctypes.c_double), ("sum_total_ms", ctypes.c_double), ("n_timed", ctypes.c_int64),
     ]
 
 
@@ -85,6 +86,7 @@ def lib():
     L.snb_get_pme_parameters.argtypes = [vp, dp, ip]
     L.snb_get_ljpme_parameters.argtypes = [vp, dp, ip]
     L.snb_get_stats.argtypes = [vp, ctypes.POINTER(SnbStats)]
+    L.snb_reset_timers.argtypes = [vp]
     L.snb_legal_grid_size.argtypes = [i32]; L.snb_legal_grid_size.restype = i32
     L.snb_abi_version.restype = i32
     L.snb_test_fft3d.argtypes = [i32, i32, i32, i32, i32, i32, dp, dp, dp]

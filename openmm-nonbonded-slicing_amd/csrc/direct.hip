@@ -14,18 +14,19 @@
 // lambda scaling costs two multiplies per TILE and per-slice energies are two accumulators per tile -- there is no
 // per-pair slice arithmetic at all (the reference computes the slice index and loads LAMBDA[slice] per pair).
 #include "snb_internal.h"
+#include <cstdlib>
 
 namespace snb {
 
 // ---- math helpers -------------------------------------------------------------------------------
-__device__ inline float rsq(float x) { return __frsqrt_rn(x); }
+__device__ inline float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ inline double rsq(double x) { return 1.0 / sqrt(x); }
 __device__ inline float fexp(float x) { return __expf(x); }
 __device__ inline double fexp(double x) { return exp(x); }
 // erfc(ar) given e = exp(-ar^2).  Single precision: Abramowitz & Stegun 7.1.26 (max abs error 1.5e-7), the
 // same approximation the reference GPU path uses (coulombLennardJones.cc:18-23); double: libm.
 __device__ inline float erfcFromExp(float ar, float e) {
-    float t = __frcp_rn(1.0f + 0.3275911f * ar);
+    float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ar);
     return (0.254829592f + (-0.284496736f + (1.421413741f + (-1.453152027f + 1.061405429f * t) * t) * t) * t) * t * e;
 }
 __device__ inline double erfcFromExp(double ar, double) { return erfc(ar); }
@@ -50,21 +51,47 @@ template <typename Real> __device__ inline void wrapDelta(Real& dx, Real& dy, Re
     s = floor(dx * inv[0] + Real(0.5)); dx -= s * box[0];
 }
 
+// The sorted coordinates are box-wrapped per atom (imageOffset = wrapped - user).  Non-periodic exceptions
+// (periodicExceptions == false, ReferenceSlicedLJCoulombIxn.cpp:461-464) need the user's own coordinates back.
+template <typename Real> __device__ inline void unwrapDelta(Real& dx, Real& dy, Real& dz, const Real* off, int i, int j) {
+    dx -= off[3 * i] - off[3 * j]; dy -= off[3 * i + 1] - off[3 * j + 1]; dz -= off[3 * i + 2] - off[3 * j + 2];
+}
+
+// ---- cross-lane helpers -------------------------------------------------------------------------
+// DPP row_ror:1 -- every 16-lane row rotates by one lane (lane c receives the value of lane (c-1)&15).
+__device__ inline float rowRor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false)); }
+__device__ inline double rowRor1(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)b, hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
 // ---- the tile kernel ----------------------------------------------------------------------------
+// Work item = (i-block, run of <= 8 tiles).  Lane layout: 4 DPP rows of 16 lanes; row r works on the 16x16 sub-tile
+// (i-half r&1, j-half r>>1).  At step s lane c of a row meets j-slot (c-s)&15 of its j-half; the j-force accumulator
+// travels WITH the j-slot by a one-lane DPP row rotation per step (v_add_f32_dpp: one VALU op per component, no LDS),
+// so after 16 steps lane c holds the force on j-slot c.  j-atom data is read from LDS (staged once per tile, each
+// 16-atom half stored twice so the rotated index c+16-s needs no wrap).
 template <typename Real, int MC, bool WRAP, bool ENERGY>
 __global__ __launch_bounds__(256) void k_direct(const DirectParams<Real> p) {
     using T4 = typename Vec<Real>::T4;
     using T2 = typename Vec<Real>::T2;
     __shared__ T4 s_pos[4][64];
     __shared__ T2 s_se[4][64];
-    __shared__ Real s_f[4][3][64];
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int item = blockIdx.x * 4 + wid;
     if (item >= p.numWork) return;                       // whole wave leaves; no block-level barrier is used below
-    const int I = __builtin_amdgcn_readfirstlane(p.workOrder[p.workStart + item * p.workStride]);
-    const int il = lane & 31, h = lane >> 5;
+    const int4 wi = p.workItems[p.workStart + item * p.workStride];
+    const int I = __builtin_amdgcn_readfirstlane(wi.x);
+    const int tBegin = __builtin_amdgcn_readfirstlane(wi.y), tEnd = tBegin + __builtin_amdgcn_readfirstlane(wi.z);
+    const int c = lane & 15, row = lane >> 4;
+    const int il = 16 * (row & 1) + c;                   // my i-atom within the block
+    const int jh = row >> 1;                             // my j-half
+    const int stageJ = 16 * (lane >> 5) + c;             // j-atom this lane stages (entry `lane` of the doubled image)
 
     const T4 pi = p.posq[I * 32 + il];
     const T2 sei = p.sigeps[I * 32 + il];
@@ -76,31 +103,34 @@ __global__ __launch_bounds__(256) void k_direct(const DirectParams<Real> p) {
     Real ecl = 0, elj = 0;
     int curSlice = -1;
 
-    const int2 bt = p.blockTiles[I];
     T4* myPos = s_pos[wid];
     T2* mySe = s_se[wid];
-    Real* myFx = s_f[wid][0]; Real* myFy = s_f[wid][1]; Real* myFz = s_f[wid][2];
+    const T4* rdPos = myPos + 32 * jh + c + 16;          // entry for step s is rdPos[-s]
+    const T2* rdSe = mySe + 32 * jh + c + 16;
 
-    for (int t = bt.x; t < bt.x + bt.y; t++) {
-        // ---- stage the j-tile (both halves store: entries k and k+32 hold the same atom) ----
-        const int jcode = p.tileJ[t * 32 + il];
-        const int4 info = p.tileInfo[t];
-        const int jidx = jcode & SNB_JIDX_MASK;
-        const bool jvalid = jcode >= 0;
-        T4 pj; T2 sej;
-        if (jvalid) {
-            pj = p.posq[jidx]; sej = p.sigeps[jidx];
+    // software pipeline: the j-atoms of tile t+1 are fetched while tile t is computed
+    int jcode = p.tileJ[tBegin * 32 + stageJ];
+    T4 pj; T2 sej;
+    auto fetch = [&](int code, T4& x, T2& se) {
+        if (code != -1) {   // -1 = padding slot (image codes use bits 27..31, so the sign bit is NOT a validity flag)
+            const int idx = code & SNB_JIDX_MASK;
+            x = p.posq[idx]; se = p.sigeps[idx];
             if (!WRAP) {
-                const int sc = (jcode >> SNB_JSHIFT_BITS) & 31;
-                pj.x += p.shifts[sc * 3]; pj.y += p.shifts[sc * 3 + 1]; pj.z += p.shifts[sc * 3 + 2];
+                const int sc = (code >> SNB_JSHIFT_BITS) & 31;
+                x.x += p.shifts[sc * 3]; x.y += p.shifts[sc * 3 + 1]; x.z += p.shifts[sc * 3 + 2];
             }
-        } else {
-            pj.x = Real(3e9) + Real(1e6) * il; pj.y = Real(-5e9); pj.z = Real(7e9); pj.w = 0; sej.x = 0; sej.y = 0;
-        }
+        } else { x.x = Real(3e9) + Real(1e6) * c; x.y = Real(-5e9); x.z = Real(7e9); x.w = 0; se.x = 0; se.y = 0; }
+    };
+    fetch(jcode, pj, sej);
+
+    for (int t = tBegin; t < tEnd; t++) {
+        const int4 info = p.tileInfo[t];
+        __builtin_amdgcn_wave_barrier();
         myPos[lane] = pj; mySe[lane] = sej;
-        myFx[lane] = 0; myFy[lane] = 0; myFz[lane] = 0;
+        const int curCode = jcode;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (t + 1 < tEnd) { jcode = p.tileJ[(t + 1) * 32 + stageJ]; fetch(jcode, pj, sej); }
 
         const int sj = info.x;
         const int slice = sliceOf(si, sj);
@@ -112,22 +142,23 @@ __global__ __launch_bounds__(256) void k_direct(const DirectParams<Real> p) {
             ecl = 0; elj = 0; curSlice = slice;
         }
         const Real lamC = p.lambdas[2 * slice], lamL = p.lambdas[2 * slice + 1];
-        const unsigned maskWord = info.y >= 0 ? p.masks[info.y * 32 + il] : 0u;
+        unsigned maskWord = info.y >= 0 ? p.masks[info.y * 32 + il] : 0u;
+        maskWord >>= 16 * jh;                            // my j-half's 16 bits
         // lambda folded into the i-side parameters once per tile (forces only need the scaled values)
         const Real qiS = qi * lamC;
         const Real epsiS = sei.y * lamL;
+        Real fjx = 0, fjy = 0, fjz = 0;
 
 #pragma unroll 4
         for (int s = 0; s < 16; s++) {
-            const int js = il + h + 2 * s;               // 0..62, duplicate layout => no wrap
-            const T4 xj = myPos[js];
-            const T2 sj2 = mySe[js];
+            const T4 xj = rdPos[-s];
+            const T2 sj2 = rdSe[-s];
             Real dx = pi.x - xj.x, dy = pi.y - xj.y, dz = pi.z - xj.z;
             if (WRAP) wrapDelta<Real>(dx, dy, dz, p.box, p.invBoxDiag);
             const Real r2 = dx * dx + dy * dy + dz * dz;
             const Real invR = rsq(r2);
             const Real r = r2 * invR;
-            bool include = !((maskWord >> (js & 31)) & 1u);
+            bool include = !((maskWord >> ((c - s) & 15)) & 1u);
             if (MC != MC_NOCUTOFF) include = include && (r2 < p.cutoff2);
 
             // Lennard-Jones (ReferenceSlicedLJCoulombIxn.cpp:390-396, 600-616)
@@ -193,23 +224,21 @@ __global__ __launch_bounds__(256) void k_direct(const DirectParams<Real> p) {
             if (ENERGY) { ecl += include ? eC : Real(0); elj += include ? eLJ : Real(0); }
             const Real gx = f * dx, gy = f * dy, gz = f * dz;
             fix += gx; fiy += gy; fiz += gz;
-            ldsAdd(&myFx[js], -gx); ldsAdd(&myFy[js], -gy); ldsAdd(&myFz[js], -gz);
+            // the accumulator follows its j-slot along the row: rotate in (slot of lane c at step s = slot of lane c-1 at step s-1), then add
+            fjx = rowRor1(fjx) - gx; fjy = rowRor1(fjy) - gy; fjz = rowRor1(fjz) - gz;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- flush j-forces: one global atomic per j-atom and component ----
-        if (h == 0 && jvalid) {
-            gAdd(&p.fx[jidx], myFx[il] + myFx[il + 32]);
-            gAdd(&p.fy[jidx], myFy[il] + myFy[il + 32]);
-            gAdd(&p.fz[jidx], myFz[il] + myFz[il + 32]);
+        // rotate-then-add leaves lane c holding slot c+1: one more rotation brings every slot home; then add the two
+        // i-halves (rows r and r^1) and flush
+        fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
+        fjx += __shfl_xor(fjx, 16, 64); fjy += __shfl_xor(fjy, 16, 64); fjz += __shfl_xor(fjz, 16, 64);
+        if ((row & 1) == 0 && curCode != -1) {            // lanes 0-15 (j-half 0) and 32-47 (j-half 1): entry `lane` == j-slot
+            const int jidx = curCode & SNB_JIDX_MASK;
+            gAdd(&p.fx[jidx], fjx); gAdd(&p.fy[jidx], fjy); gAdd(&p.fz[jidx], fjz);
         }
-        __builtin_amdgcn_wave_barrier();
     }
-    // combine the two halves' i-forces and flush
+    // rows r and r^2 hold the same i-atoms (different j-halves)
     fix += __shfl_xor(fix, 32, 64); fiy += __shfl_xor(fiy, 32, 64); fiz += __shfl_xor(fiz, 32, 64);
-    if (h == 0) {
-        gAdd(&p.fx[I * 32 + il], fix); gAdd(&p.fy[I * 32 + il], fiy); gAdd(&p.fz[I * 32 + il], fiz);
-    }
+    if (row < 2) { gAdd(&p.fx[I * 32 + il], fix); gAdd(&p.fy[I * 32 + il], fiy); gAdd(&p.fz[I * 32 + il], fiz); }
     if (ENERGY && curSlice >= 0) {
         double a = waveSum((double)ecl), b = waveSum((double)elj);
         if (lane == 0) { atomicAdd(&p.sliceE[2 * curSlice], a); atomicAdd(&p.sliceE[2 * curSlice + 1], b); }
@@ -229,7 +258,8 @@ template <typename Real, int MC> static void launchDirectMC(const DirectParams<R
     }
 }
 
-template <typename Real> void launchDirect(const DirectParams<Real>& p, int mc, bool wrap, bool energy, hipStream_t s) {
+template <typename Real> void launchDirect(const DirectParams<Real>& p0, int mc, bool wrap, bool energy, hipStream_t s) {
+    const DirectParams<Real>& p = p0;
     switch (mc) {
         case MC_NOCUTOFF: launchDirectMC<Real, MC_NOCUTOFF>(p, wrap, energy, s); break;
         case MC_RF: launchDirectMC<Real, MC_RF>(p, wrap, energy, s); break;
@@ -250,6 +280,7 @@ template <typename Real, bool ENERGY> __global__ void k_exceptions(const PairLis
         const auto xi = p.posq[ij.x]; const auto xj = p.posq[ij.y];
         Real dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
         if (p.periodic) { Real inv[3] = {Real(1) / p.box[0], Real(1) / p.box[4], Real(1) / p.box[8]}; wrapDelta<Real>(dx, dy, dz, p.box, inv); }
+        else unwrapDelta<Real>(dx, dy, dz, p.imageOffset, ij.x, ij.y);
         const Real invR = rsq(dx * dx + dy * dy + dz * dz);
         Real s2 = invR * par.x; s2 *= s2;
         const Real s6 = s2 * s2 * s2;
@@ -273,6 +304,7 @@ template <typename Real, bool ENERGY> __global__ void k_exclusionCorrection(cons
     const auto xi = p.posq[ij.x]; const auto xj = p.posq[ij.y];
     Real dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
     if (p.periodic) { Real inv[3] = {Real(1) / p.box[0], Real(1) / p.box[4], Real(1) / p.box[8]}; wrapDelta<Real>(dx, dy, dz, p.box, inv); }
+    else unwrapDelta<Real>(dx, dy, dz, p.imageOffset, ij.x, ij.y);
     const Real r2 = dx * dx + dy * dy + dz * dz;
     const Real r = sqrt(r2);
     const Real invR = Real(1) / r;

@@ -59,6 +59,7 @@ struct EngineBase {
     virtual void getSliceEnergies(double*) = 0;
     virtual void sync() = 0;
     virtual void getStats(snb_stats*) = 0;
+    virtual void resetTimers() = 0;
     virtual void getPme(double*, int32_t*, bool dispersion) = 0;
 };
 
@@ -167,7 +168,10 @@ template <typename Real> class Engine : public EngineBase {
 public:
     int N, nsub, S;
     hipStream_t stream = nullptr; bool ownStream = false;
-    hipEvent_t evStart, evDirect0, evDirect1, evRecip0, evRecip1, evEnd;
+    // ring of per-execute event sets, harvested lazily into cumulative kernel times (no per-step host sync)
+    static constexpr int RING = 128;
+    struct EvSet { hipEvent_t e[5]; bool pending = false; };   // start, direct0, direct1(=recip0 after pair lists), recip1, end
+    std::vector<EvSet> ring; int ringPos = 0;
     // host-side definition
     std::vector<double> charge, sigma, epsilon; std::vector<int32_t> subset;
     std::vector<int32_t> excPairs; std::vector<double> excQQ, excSigma, excEps; std::vector<int32_t> excForce14;
@@ -177,11 +181,11 @@ public:
     const void* devUserPos = nullptr; int posIsDouble = 1, posStride4 = 0; bool havePositions = false;
     DevBuf<unsigned char> ownedPos;
     // sorted state
-    int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0; bool wrapMode = false;
+    int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0, shardTiles = 0; bool wrapMode = false;
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> fx, fy, fz, fpx, fpy, fpz, imageOffset, dLambdas;
-    DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, workOrder, tileJ, atomSubset, atomGrid, gridSubset;
-    DevBuf<int2> blockTiles, pairs14, pairsExcl; DevBuf<int4> tileInfo; DevBuf<unsigned> masks;
+    DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset;
+    DevBuf<int2> pairs14, pairsExcl; DevBuf<int4> tileInfo, workItems; int numWorkItems = 0; DevBuf<unsigned> masks;
     DevBuf<T4> params14, paramsExcl; int n14 = 0, nExcl = 0;
     DevBuf<double> sliceE;
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
@@ -195,7 +199,8 @@ public:
         std::memset(&stats, 0, sizeof(stats));
         HIPCHECK(hipSetDevice(c.device));
         if (c.stream) stream = (hipStream_t)c.stream; else { HIPCHECK(hipStreamCreate(&stream)); ownStream = true; }
-        for (hipEvent_t* e : {&evStart, &evDirect0, &evDirect1, &evRecip0, &evRecip1, &evEnd}) HIPCHECK(hipEventCreate(e));
+        ring.resize(RING);
+        for (auto& r : ring) for (int k = 0; k < 5; k++) HIPCHECK(hipEventCreate(&r.e[k]));
         charge.assign(N, 0.0); sigma.assign(N, 1.0); epsilon.assign(N, 0.0); subset.assign(N, 0);
         lambdas.assign((size_t)S * 2, 1.0); dispCoef.assign(S, 0.0); hostSliceE.assign((size_t)S * 2, 0.0);
         sliceE.resize((size_t)S * 2);
@@ -218,7 +223,7 @@ public:
     }
     ~Engine() override {
         (void)hipStreamSynchronize(stream);
-        for (hipEvent_t e : {evStart, evDirect0, evDirect1, evRecip0, evRecip1, evEnd}) (void)hipEventDestroy(e);
+        for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
         if (ownStream) (void)hipStreamDestroy(stream);
     }
     bool isPme() const { return cfg.method == SNB_PME || cfg.method == SNB_LJPME; }
@@ -505,7 +510,7 @@ public:
                 for (int k = 0; k < 32; k++) if (sortedToUser[I * 32 + k] < 0) iPadRows |= 1u << k;
                 for (int t = 0; t < (int)tileMask.size(); t++) {
                     unsigned jPad = 0;
-                    for (int k = 0; k < 32; k++) if (hTileJ[(size_t)(firstTile + t) * 32 + k] < 0) jPad |= 1u << k;
+                    for (int k = 0; k < 32; k++) if (hTileJ[(size_t)(firstTile + t) * 32 + k] == -1) jPad |= 1u << k;
                     if (!jPad && !iPadRows) continue;
                     if (tileMask[t] < 0) { tileMask[t] = (int)(hMasks.size() / 32); hMasks.resize(hMasks.size() + 32, 0u); hTileInfo[firstTile + t].y = tileMask[t]; }
                     for (int k = 0; k < 32; k++) hMasks[(size_t)tileMask[t] * 32 + k] |= ((iPadRows >> k) & 1u) ? 0xFFFFFFFFu : jPad;
@@ -519,13 +524,19 @@ public:
             if (emptyBlock) { hBlockTiles[I].y = 0; }
         }
         numTiles = (int64_t)hTileInfo.size();
-        std::vector<int> hWork(numBlocks);
-        std::iota(hWork.begin(), hWork.end(), 0);
-        std::stable_sort(hWork.begin(), hWork.end(), [&](int a, int b) { return hBlockTiles[a].y > hBlockTiles[b].y; });
+        // work items: runs of <= 8 tiles of one i-block (fine grain => several rounds of waves per CU, small tail)
+        std::vector<int4> hWork;
+        const int CH = 8;
+        for (int b = 0; b < numBlocks; b++)
+            for (int o = 0; o < hBlockTiles[b].y; o += CH) hWork.push_back(make_int4(b, hBlockTiles[b].x + o, std::min(CH, hBlockTiles[b].y - o), 0));
+        std::stable_sort(hWork.begin(), hWork.end(), [&](const int4& a, const int4& b) { return a.z > b.z; });
+        numWorkItems = (int)hWork.size();
+        shardTiles = 0;
+        for (int w = cfg.shard_rank; w < numWorkItems; w += cfg.shard_count) shardTiles += hWork[w].z;
         // 7. upload
         posq.upload(hPosq, stream); sigeps.upload(hSigeps, stream); imageOffset.upload(hOff, stream);
         dSortedToUser.upload(sortedToUser, stream); dUserToSorted.upload(userToSorted, stream);
-        blockSubset.upload(blkSubset, stream); blockTiles.upload(hBlockTiles, stream); workOrder.upload(hWork, stream);
+        blockSubset.upload(blkSubset, stream); workItems.upload(hWork, stream);
         tileJ.upload(hTileJ, stream); tileInfo.upload(hTileInfo, stream); masks.upload(hMasks, stream);
         atomSubset.upload(hAtomSubset, stream); atomGrid.upload(hAtomGrid, stream);
         fx.resize(Npad); fy.resize(Npad); fz.resize(Npad); fpx.resize(Npad); fpy.resize(Npad); fpz.resize(Npad);
@@ -606,21 +617,23 @@ public:
         else if (paramsDirty) refreshParameters();
         stepsSinceRebuild++;
         const bool energy = includeEnergy != 0;
-        HIPCHECK(hipEventRecord(evStart, stream));
+        EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
+        if (ev.pending) harvest(ev);
+        HIPCHECK(hipEventRecord(ev.e[0], stream));
         launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, stream);
         HIPCHECK(hipMemsetAsync(fx.p, 0, sizeof(Real) * Npad, stream));
         HIPCHECK(hipMemsetAsync(fy.p, 0, sizeof(Real) * Npad, stream));
         HIPCHECK(hipMemsetAsync(fz.p, 0, sizeof(Real) * Npad, stream));
         if (energy) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2, stream));
         const bool ew = cfg.method >= SNB_Ewald;
-        HIPCHECK(hipEventRecord(evDirect0, stream));
+        HIPCHECK(hipEventRecord(ev.e[1], stream));
         if (includeDirect) {
             DirectParams<Real> p;
             std::memset(&p, 0, sizeof(p));
-            p.posq = posq.p; p.sigeps = sigeps.p; p.blockSubset = blockSubset.p; p.blockTiles = blockTiles.p; p.workOrder = workOrder.p;
+            p.posq = posq.p; p.sigeps = sigeps.p; p.blockSubset = blockSubset.p; p.workItems = workItems.p;
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.sliceE = sliceE.p; p.lambdas = dLambdas.p;
             const int r = cfg.shard_rank, c = cfg.shard_count;
-            p.workStart = r; p.workStride = c; p.numWork = numBlocks > r ? (numBlocks - r + c - 1) / c : 0;
+            p.workStart = r; p.workStride = c; p.numWork = numWorkItems > r ? (numWorkItems - r + c - 1) / c : 0;
             p.nsub = nsub;
             p.cutoff2 = (Real)(cfg.cutoff * cfg.cutoff);
             p.krf = (Real)(std::pow(cfg.cutoff, -3.0) * (cfg.rf_dielectric - 1.0) / (2.0 * cfg.rf_dielectric + 1.0));
@@ -644,20 +657,20 @@ public:
             else if (cfg.method == SNB_LJPME) mc = MC_LJPME;
             launchDirect<Real>(p, mc, wrapMode, energy, stream);
         }
-        HIPCHECK(hipEventRecord(evDirect1, stream));
+        HIPCHECK(hipEventRecord(ev.e[2], stream));
         if (includeDirect && cfg.shard_rank == 0) {   // O(N) pair lists: rank 0 only when sharded
             PairListParams<Real> q;
             std::memset(&q, 0, sizeof(q));
             q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.sliceE = sliceE.p; q.lambdas = dLambdas.p;
             const bool exPeriodic = (cfg.method == SNB_NoCutoff || cfg.method == SNB_CutoffNonPeriodic) ? false : cfg.exceptions_periodic != 0;
-            q.periodic = exPeriodic ? 1 : 0;
+            q.periodic = exPeriodic ? 1 : 0; q.imageOffset = imageOffset.p;
             for (int i = 0; i < 9; i++) q.box[i] = (Real)box[i];
             q.alpha = (Real)cfg.alpha; q.alphaD = (Real)cfg.alpha_d; q.ljpme = cfg.method == SNB_LJPME;
             q.pairs = pairs14.p; q.params = params14.p; q.n = n14;
             launchExceptions<Real>(q, energy, stream);
             if (ew) { q.pairs = pairsExcl.p; q.params = paramsExcl.p; q.n = nExcl; launchExclusionCorrection<Real>(q, energy, stream); }
         }
-        HIPCHECK(hipEventRecord(evRecip0, stream));
+        HIPCHECK(hipEventRecord(ev.e[3], stream));
         lastRecip = false;
         if (includeRecip && isPme()) {
             lastRecip = true;
@@ -671,8 +684,8 @@ public:
                 HIPCHECK(hipMemsetAsync(fpx.p, 0, sizeof(Real) * Npad, stream)); HIPCHECK(hipMemsetAsync(fpy.p, 0, sizeof(Real) * Npad, stream)); HIPCHECK(hipMemsetAsync(fpz.p, 0, sizeof(Real) * Npad, stream));
             }
         }
-        HIPCHECK(hipEventRecord(evRecip1, stream));
-        HIPCHECK(hipEventRecord(evEnd, stream));
+        HIPCHECK(hipEventRecord(ev.e[4], stream));
+        ev.pending = true;
         if (energy) {
             std::vector<double> dev((size_t)S * 2);
             HIPCHECK(hipMemcpyAsync(dev.data(), sliceE.p, sizeof(double) * S * 2, hipMemcpyDeviceToHost, stream));
@@ -682,6 +695,18 @@ public:
             if (energyOut) { double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }
         } else if (energyOut) *energyOut = 0.0;
     }
+
+    void harvest(EvSet& ev) {
+        HIPCHECK(hipEventSynchronize(ev.e[4]));
+        float a = 0, b = 0, c = 0;
+        HIPCHECK(hipEventElapsedTime(&a, ev.e[1], ev.e[2]));
+        HIPCHECK(hipEventElapsedTime(&b, ev.e[3], ev.e[4]));
+        HIPCHECK(hipEventElapsedTime(&c, ev.e[0], ev.e[4]));
+        stats.last_direct_ms = a; stats.last_recip_ms = b; stats.last_total_ms = c;
+        stats.sum_direct_ms += a; stats.sum_recip_ms += b; stats.sum_total_ms += c; stats.n_timed++;
+        ev.pending = false;
+    }
+    void resetTimers() override { for (auto& r : ring) if (r.pending) harvest(r); stats.sum_direct_ms = stats.sum_recip_ms = stats.sum_total_ms = 0; stats.n_timed = 0; }
 
     void runPme(PmeParams<Real>& pp) {
         launchPmeSpread<Real>(pp, stream);
@@ -727,12 +752,9 @@ public:
         HIPCHECK(hipStreamSynchronize(stream));
         stats.n_tiles = 0;
         // tiles processed by this shard
-        stats.n_tiles = numTiles; stats.n_blocks = numBlocks; stats.n_padded_atoms = Npad; stats.n_exclusion_tiles = numMaskTiles;
+        stats.n_tiles = shardTiles; stats.n_blocks = numBlocks; stats.n_padded_atoms = Npad; stats.n_exclusion_tiles = numMaskTiles;
         for (int d = 0; d < 3; d++) { stats.grid[d] = isPme() ? pme.d.nx * (d == 0) + pme.d.ny * (d == 1) + pme.d.nz * (d == 2) : 0; stats.dgrid[d] = cfg.method == SNB_LJPME ? dpme.d.nx * (d == 0) + dpme.d.ny * (d == 1) + dpme.d.nz * (d == 2) : 0; }
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, evDirect0, evDirect1) == hipSuccess) stats.last_direct_ms = ms;
-        if (hipEventElapsedTime(&ms, evRecip0, evRecip1) == hipSuccess) stats.last_recip_ms = ms;
-        if (hipEventElapsedTime(&ms, evStart, evEnd) == hipSuccess) stats.last_total_ms = ms;
+        for (int k = 0; k < RING; k++) { EvSet& r = ring[(ringPos + k) % RING]; if (r.pending) harvest(r); }
         *o = stats;
     }
     void getPme(double* alpha, int32_t* g, bool dispersion) override {
@@ -855,6 +877,7 @@ snb_status snb_get_ljpme_parameters(snb_handle h, double* alpha, int32_t grid[3]
     if (h->impl->cfg.method != SNB_LJPME) { h->impl->err = "getPMEParametersInContext: This Context is not using LJPME"; return SNB_ERR_NOT_PME; }
     return guard(h, [&] { h->impl->getPme(alpha, grid, true); });
 }
+snb_status snb_reset_timers(snb_handle h) { return guard(h, [&] { h->impl->resetTimers(); }); }
 snb_status snb_get_stats(snb_handle h, snb_stats* out) { if (!out) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->getStats(out); }); }
 
 snb_status snb_test_fft3d(int32_t precision, int32_t device, int32_t batch, int32_t nx, int32_t ny, int32_t nz, const double* in, double* spectrum, double* roundtrip) {

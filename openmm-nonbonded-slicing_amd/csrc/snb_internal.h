@@ -37,8 +37,7 @@ template <typename Real> struct DirectParams {
     const typename Vec<Real>::T4* posq;
     const typename Vec<Real>::T2* sigeps;
     const int* blockSubset;   // [numBlocks]
-    const int2* blockTiles;   // [numBlocks] (first tile, tile count)
-    const int* workOrder;     // [numWork] block ids, longest first
+    const int4* workItems;    // [numItems] (block, first tile, tile count <= 8, -), longest first
     const int* tileJ;         // [T*32]
     const int4* tileInfo;     // [T]
     const unsigned* masks;    // [M*32]
@@ -63,6 +62,7 @@ template <typename Real> struct PairListParams {  // exceptions (1-4) and exclus
     double* sliceE;
     const Real* lambdas;
     int periodic;
+    const Real* imageOffset;  // [Npad*3] wrapped - user coordinates (to undo the wrap for non-periodic exceptions)
     Real box[9];
     Real alpha, alphaD;
     int ljpme;

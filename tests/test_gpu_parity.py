@@ -152,3 +152,24 @@ def test_fft_against_numpy(snb):
             scale = np.abs(ref).max()
             assert np.abs(got - ref).max() / scale < tol, (prec, nx, ny, nz)
             assert np.abs(rt / (nx * ny * nz) - a).max() < tol * 10, (prec, nx, ny, nz)
+
+
+def test_bench_workload_24k_vs_oracle(snb):
+    """The bench generator's water + solute-blob box at 24k atoms (all 27 periodic image codes occur; molecules straddle the
+    box faces, exceptions are non-periodic) against the oracle, with the neighbour skin the bench uses."""
+    import ctypes
+    import torch
+    import bench
+    w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+    fo, so, _, _ = bench.oracle_eval(w, 4, 54, 0)
+    n = len(w["q"])
+    for prec, tol in (("double", 1e-5), ("single", 1e-3)):
+        eng = bench.Engine(snb, w, 4, 54, 0, prec, 0, 0, 1, 0.1, 1 << 30)
+        dt = torch.float64 if prec == "double" else torch.float32
+        pos = torch.tensor(w["pos"], dtype=dt, device="cuda"); forces = torch.zeros((n, 3), dtype=dt, device="cuda")
+        eng.set_positions_device(pos.data_ptr(), prec == "double")
+        eng.execute(True); eng.forces_to(forces.data_ptr(), prec == "double"); eng.sync()
+        f = forces.double().cpu().numpy(); se = eng.slice_energies(so.shape[0])
+        ferr = np.max(np.linalg.norm(f - fo, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0))
+        eerr = np.max(np.abs(se - so) / np.maximum(np.abs(so), 1.0))
+        assert ferr < tol and eerr < tol, (prec, ferr, eerr)
