@@ -217,6 +217,16 @@ class Engine:
         box = np.diag([w["L"]] * 3).astype(np.float64).reshape(9)
         self.ok(self.L.snb_set_box(self.h, dp(box)))
 
+    def close(self):
+        if self.h:
+            self.L.snb_destroy(self.h); self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def ok(self, st, create=False):
         if st != 0:
             raise RuntimeError("snb error %d: %s" % (st, (self.L.snb_last_error(None if create else self.h) or b"").decode()))

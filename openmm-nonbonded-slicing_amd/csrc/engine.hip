@@ -169,7 +169,7 @@ public:
     int N, nsub, S;
     hipStream_t stream = nullptr; bool ownStream = false;
     // ring of per-execute event sets, harvested lazily into cumulative kernel times (no per-step host sync)
-    static constexpr int RING = 128;
+    static constexpr int RING = 32;
     struct EvSet { hipEvent_t e[5]; bool pending = false; };   // start, direct0, direct1(=recip0 after pair lists), recip1, end
     std::vector<EvSet> ring; int ringPos = 0;
     // host-side definition
@@ -185,7 +185,7 @@ public:
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> fx, fy, fz, fpx, fpy, fpz, imageOffset, dLambdas;
     DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset;
-    DevBuf<int2> pairs14, pairsExcl; DevBuf<int4> tileInfo, workItems; int numWorkItems = 0; DevBuf<unsigned> masks;
+    DevBuf<int2> pairs14, pairsExcl, colRange; DevBuf<int4> tileInfo, workItems; int numWorkItems = 0; int colCells[2] = {0, 0}; DevBuf<unsigned> masks;
     DevBuf<T4> params14, paramsExcl; int n14 = 0, nExcl = 0;
     DevBuf<double> sliceE;
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
@@ -324,11 +324,26 @@ public:
         const double aTarget = std::cbrt(32.0 * volume / std::max(N, 1));
         int ncx = std::max(1, std::min(2048, (int)std::lround(ext[0] / aTarget)));
         int ncy = std::max(1, std::min(2048, (int)std::lround(ext[1] / aTarget)));
+        // With PME on a rectangular box the sort columns are made commensurate with the mesh (whole grid cells, >= 5 wide),
+        // so the same sorted order feeds the brick-spreading kernel (pme.hip k_spreadBrick).
+        colCells[0] = colCells[1] = 0;
+        if (isPme() && rect && nGrids > 0) {
+            auto pick = [&](int n, double L) {
+                int best = 0; double bestErr = 1e300;
+                for (int d = 5; d <= 16 && d <= n; d++) if (n % d == 0) { double e = std::fabs(d * L / n - aTarget); if (e < bestErr) { bestErr = e; best = d; } }
+                return best;
+            };
+            const int px = pick(pme.d.nx, box[0]), py = pick(pme.d.ny, box[4]);
+            const size_t brickBytes = sizeof(double) * (size_t)px * py * pme.d.nz;
+            if (px > 0 && py > 0 && brickBytes <= 60 * 1024) { colCells[0] = px; colCells[1] = py; ncx = pme.d.nx / px; ncy = pme.d.ny / py; }
+        }
         std::vector<uint64_t> key(N);
+        std::vector<int> colOfAtom(N);
         for (int i = 0; i < N; i++) {
             const double* x = &wp[3 * (size_t)i];
             int cx = std::min(ncx - 1, std::max(0, (int)((x[0] - lo[0]) / ext[0] * ncx)));
             int cy = std::min(ncy - 1, std::max(0, (int)((x[1] - lo[1]) / ext[1] * ncy)));
+            colOfAtom[i] = cx * ncy + cy;
             int col = cx * ncy + ((cx & 1) ? (ncy - 1 - cy) : cy);
             double zf = std::min(1.0, std::max(0.0, (x[2] - lo[2]) / ext[2]));
             if (col & 1) zf = 1.0 - zf;
@@ -350,6 +365,17 @@ public:
             }
         }
         Npad = (int)sortedToUser.size(); numBlocks = Npad / 32;
+        if (colCells[0] > 0) {   // sorted range of every (subset, column): atoms of one column are contiguous in the sorted order
+            const int ncol = ncx * ncy;
+            std::vector<int2> hRange((size_t)nsub * ncol, make_int2(0, 0));
+            for (int s = 0; s < Npad; s++) {
+                const int u = sortedToUser[s]; if (u < 0) continue;
+                int2& rg = hRange[(size_t)subset[u] * ncol + colOfAtom[u]];
+                if (rg.y == 0) rg.x = s;
+                rg.y = s + 1;
+            }
+            colRange.upload(hRange, stream);
+        }
         if (Npad >= (1 << SNB_JSHIFT_BITS) - 1) throw HipError{"too many atoms for the 27-bit tile index"};
         // 4. sorted parameter arrays
         std::vector<T4> hPosq(Npad); std::vector<T2> hSigeps(Npad); std::vector<Real> hOff((size_t)Npad * 3, Real(0));
@@ -600,6 +626,9 @@ public:
         p.alpha = (Real)plan.alpha; p.volume = (Real)det; p.dispersion = plan.dispersion ? 1 : 0;
         p.lambdas = dLambdas.p; p.gridSubset = gridSubset.p; p.nsubTotal = nsub; p.mix = cfg.shard_count == 1 ? 1 : 0;
         p.sliceE = sliceE.p; p.fpx = fpx.p; p.fpy = fpy.p; p.fpz = fpz.p; p.wantEnergy = wantEnergy ? 1 : 0;
+        // brick spreading needs the plan's mesh to be the one the sort columns were cut for (the LJPME dispersion mesh falls back)
+        const bool brick = colCells[0] > 0 && plan.d.nx == pme.d.nx && plan.d.ny == pme.d.ny && plan.d.nz == pme.d.nz;
+        p.colCellsX = brick ? colCells[0] : 0; p.colCellsY = brick ? colCells[1] : 0; p.colRange = brick ? colRange.p : nullptr;
     }
 
     void execute(int includeForces, int includeEnergy, int includeDirect, int includeRecip, double* energyOut) override {

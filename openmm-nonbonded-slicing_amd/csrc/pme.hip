@@ -105,7 +105,80 @@ template <typename Real> __global__ __launch_bounds__(256) void k_spread(const P
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Brick spreading (the production path for rectangular boxes): no global atomics, no grid memset.
+// One work-group owns a (cx x cy x nz) column of one subset grid in LDS (as doubles: ds_add_f64 runs at ~9 cycles
+// per wave-instruction on gfx950, ds_add_f32 at ~190 -- measured, tools/ubench_atomics.hip).  Atoms are already sorted
+// by (subset, xy-column of exactly this size, z) for the pair kernel, so the candidates of a brick are the contiguous
+// sorted ranges of its 3x3 column neighbourhood (one column of margin on each side covers the drift since the last
+// re-sort: < skin/2 < one grid cell).  Every grid point is written exactly once, coalesced along z.
+// ---------------------------------------------------------------------------------------------------
+template <typename Real> __global__ __launch_bounds__(256) void k_spreadBrick(const PmeParams<Real> p) {
+    extern __shared__ __align__(16) unsigned char s_brick_raw[];
+    double* brick = reinterpret_cast<double*>(s_brick_raw);
+    const int cx = p.colCellsX, cy = p.colCellsY, ncx = p.d.nx / cx, ncy = p.d.ny / cy, nz = p.d.nz;
+    const int ncol = ncx * ncy;
+    const int slot = blockIdx.x / ncol, col = blockIdx.x - slot * ncol;
+    const int Cx = col / ncy, Cy = col - Cx * ncy;
+    const int x0 = Cx * cx, y0 = Cy * cy;
+    const int npts = cx * cy * nz;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < npts; i += 256) brick[i] = 0.0;
+    __syncthreads();
+    const int group = tid >> 5, r = tid & 31;
+    const int rix = r / 5, riy = r - rix * 5;
+    const int2* ranges = p.colRange + (size_t)p.gridSubset[slot] * ncol;
+    for (int dcx = -1; dcx <= 1; dcx++) {
+        int ccx = Cx + dcx; if (ccx < 0) ccx += ncx; if (ccx >= ncx) ccx -= ncx;
+        if (!(dcx == 0 || ncx >= 3 || (ncx == 2 && dcx == -1))) continue;   // fewer than 3 columns: never visit a column twice
+        for (int dcy = -1; dcy <= 1; dcy++) {
+            int ccy = Cy + dcy; if (ccy < 0) ccy += ncy; if (ccy >= ncy) ccy -= ncy;
+            if (!(dcy == 0 || ncy >= 3 || (ncy == 2 && dcy == -1))) continue;
+            const int2 rg = ranges[ccx * ncy + ccy];
+            for (int a = rg.x + group; a < rg.y; a += 8) {
+                const Real q = pmeCharge(p, a);
+                const auto pos = p.posq[a];
+                int idx[3]; Real fr[3];
+                gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
+                // stencil start relative to the brick, folded to (-n/2, n/2]
+                int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
+                int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
+                if (rx + 4 < 0 || rx >= cx || ry + 4 < 0 || ry >= cy || q == Real(0)) continue;   // uniform per 32-lane group
+                Real tx[5], ty[5], tz[5], dtmp[5];
+                bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
+                const int lx = rx + rix, ly = ry + riy;
+                if (r < 25 && lx >= 0 && lx < cx && ly >= 0 && ly < cy) {
+                    Real wxy = q;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { if (k == rix) wxy *= tx[k]; if (k == riy) wxy *= ty[k]; }
+                    double* line = brick + (size_t)(lx * cy + ly) * nz;
+#pragma unroll
+                    for (int iz = 0; iz < 5; iz++) {
+                        int zi = idx[2] + iz; if (zi >= nz) zi -= nz;
+                        __hip_atomic_fetch_add(&line[zi], (double)(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
+    for (int i = tid; i < npts; i += 256) {
+        const int l = i / nz, z = i - l * nz;
+        const int lx = l / cy, ly = l - lx * cy;
+        g[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z] = (Real)brick[i];
+    }
+}
+
 template <typename Real> void launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
+    if (p.colCellsX > 0 && p.colRange != nullptr) {
+        const size_t lds = sizeof(double) * (size_t)p.colCellsX * p.colCellsY * p.d.nz;
+        const int nblocks = p.nsub * (p.d.nx / p.colCellsX) * (p.d.ny / p.colCellsY);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_spreadBrick<Real>), dim3(nblocks), dim3(256), lds, s, p);
+        return;
+    }
+    // fallback (triclinic boxes, meshes without a usable column divisor): global float atomics
     hipMemsetAsync(p.gridReal, 0, sizeof(Real) * (size_t)p.nsub * p.d.nx * p.d.ny * p.d.nz, s);
     if (p.natoms <= 0) return;
     hipLaunchKernelGGL((k_spread<Real>), dim3((p.natoms + 7) / 8), dim3(256), 0, s, p);

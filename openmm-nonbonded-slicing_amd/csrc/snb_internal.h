@@ -96,6 +96,8 @@ template <typename Real> struct PmeParams {
     double* sliceE;
     Real* fpx; Real* fpy; Real* fpz;   // reciprocal force accumulators (plain stores when unsharded)
     int wantEnergy;
+    int colCellsX, colCellsY;  // brick spreading: sort-column size in grid cells (0 = use the atomic fallback)
+    const int2* colRange;      // [nsubTotal][ncx*ncy] sorted-atom range of every (subset, xy column)
 };
 
 // ---- launchers implemented in the .hip translation units -------------------------------------

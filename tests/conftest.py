@@ -16,6 +16,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def snb():
     """The product package (directory name has hyphens, so it is imported through importlib)."""
+    try:   # let torch create its HIP context first: tests that use torch for device buffers run after many engine contexts
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     return importlib.import_module("openmm-nonbonded-slicing_amd")
 
 
