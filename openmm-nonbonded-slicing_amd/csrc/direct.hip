@@ -30,6 +30,8 @@ __device__ inline float erfcFromExp(float ar, float e) {
     return (0.254829592f + (-0.284496736f + (1.421413741f + (-1.453152027f + 1.061405429f * t) * t) * t) * t) * t * e;
 }
 __device__ inline double erfcFromExp(double ar, double) { return erfc(ar); }
+__device__ inline double erfOf(float ar, float e) { return (double)(1.0f - erfcFromExp(ar, e)); }
+__device__ inline double erfOf(double ar, double) { return erf(ar); }
 
 __device__ inline void ldsAdd(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void ldsAdd(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -271,7 +273,10 @@ template void launchDirect<float>(const DirectParams<float>&, int, bool, bool, h
 template void launchDirect<double>(const DirectParams<double>&, int, bool, bool, hipStream_t);
 
 // ---- 1-4 exceptions: ReferenceSlicedLJCoulomb14.cpp:61-95 ----------------------------------------
-template <typename Real, bool ENERGY> __global__ void k_exceptions(const PairListParams<Real> p) {
+template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_exceptions(const PairListParams<Real> p) {
+    extern __shared__ double s_sliceE[];   // [2*S]
+    const int nS2 = 2 * p.nSlices;
+    if (ENERGY) { for (int i = threadIdx.x; i < nS2; i += 256) s_sliceE[i] = 0.0; __syncthreads(); }
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     double e0 = 0, e1 = 0; int slice = 0;
     if (k < p.n) {
@@ -292,62 +297,93 @@ template <typename Real, bool ENERGY> __global__ void k_exceptions(const PairLis
         gAdd(&p.fx[ij.y], -dEdR * dx); gAdd(&p.fy[ij.y], -dEdR * dy); gAdd(&p.fz[ij.y], -dEdR * dz);
         if (ENERGY) { e0 = par.z * invR; e1 = par.y * (s6 - Real(1)) * s6; }
     }
-    if (ENERGY && k < p.n) { atomicAdd(&p.sliceE[2 * slice], e0); atomicAdd(&p.sliceE[2 * slice + 1], e1); }
+    if (ENERGY) {
+        if (k < p.n) {
+            __hip_atomic_fetch_add(&s_sliceE[2 * slice], e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_sliceE[2 * slice + 1], e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nS2; i += 256) { const double v = s_sliceE[i]; if (v != 0.0) atomicAdd(&p.sliceE[i], v); }
+    }
 }
 
 // ---- Ewald exclusion corrections: ReferenceSlicedLJCoulombIxn.cpp:449-506 -------------------------
-template <typename Real, bool ENERGY> __global__ void k_exclusionCorrection(const PairListParams<Real> p) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= p.n) return;
-    const int2 ij = p.pairs[k];
-    const auto par = p.params[k];   // x = k*qi*qj, y = c6i*c6j, w = slice
-    const auto xi = p.posq[ij.x]; const auto xj = p.posq[ij.y];
-    Real dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-    if (p.periodic) { Real inv[3] = {Real(1) / p.box[0], Real(1) / p.box[4], Real(1) / p.box[8]}; wrapDelta<Real>(dx, dy, dz, p.box, inv); }
-    else unwrapDelta<Real>(dx, dy, dz, p.imageOffset, ij.x, ij.y);
-    const Real r2 = dx * dx + dy * dy + dz * dz;
-    const Real r = sqrt(r2);
-    const Real invR = Real(1) / r;
-    const Real ar = p.alpha * r;
-    const int slice = (int)par.w;
-    const Real lamC = p.lambdas[2 * slice], lamL = p.lambdas[2 * slice + 1];
-    Real f = 0; double e0 = 0, e1 = 0;
-    // the erf evaluation itself is done in double even in the single-precision engine: excluded pairs are few
-    // (O(N)) and erf(x) for small x is cancellation-prone in float.
-    const double erfv = erf((double)ar);
-    if (erfv > 1e-6) {
-        const Real ex = fexp(-ar * ar);
-        f = -lamC * par.x * invR * invR * invR * (Real(erfv) - ar * ex * Real(1.1283791670955126));
-        if (ENERGY) e0 = -(double)par.x * (double)invR * erfv;
-    } else if (ENERGY)
-        e0 = -(double)p.alpha * 1.1283791670955126 * (double)par.x;
-    if (p.ljpme) {
-        const Real dar2 = p.alphaD * p.alphaD * r2, dar4 = dar2 * dar2, dar6 = dar4 * dar2;
-        const Real invR2 = invR * invR;
-        const Real expd = fexp(-dar2);
-        const Real coef = par.y * invR2 * invR2 * invR2;
-        if (ENERGY) e1 = coef * (Real(1) - expd * (Real(1) + dar2 + Real(0.5) * dar4));
-        // reference: dEdR = -6 c6 r^-8 (...), forces[ii] -= lam*dEdR*delta  => f (applied as +f*delta on ii) = +6...
-        f += lamL * Real(6) * coef * invR2 * (Real(1) - expd * (Real(1) + dar2 + Real(0.5) * dar4 + dar6 * Real(1.0 / 6.0)));
+// One thread per ATOM walking its own exclusion list (CSR over sorted indices): every excluded pair is evaluated
+// from both ends, so the force update is a plain read-modify-write of the atom's own accumulator -- no atomics
+// (2 M scattered float atomics cost 70 us on MI355X; this costs a few us).  Energies: half a pair from each end,
+// reduced per slice in LDS (ds_add_f64) and flushed with one global atomic per slice and work-group.
+template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_exclusionAtoms(const PairListParams<Real> p) {
+    extern __shared__ double s_sliceE[];   // [2*S]
+    const int nS2 = 2 * p.nSlices;
+    if (ENERGY) { for (int i = threadIdx.x; i < nS2; i += 256) s_sliceE[i] = 0.0; __syncthreads(); }
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < p.n) {
+        const int e0 = p.exclStart[a], e1 = p.exclStart[a + 1];
+        if (e1 > e0) {
+            const auto xi = p.posq[a];
+            const auto sei = p.sigeps[a];
+            const int si = p.blockSubset[a >> 5];
+            const Real qi = xi.w * Real(SNB_ONE_4PI_EPS0);
+            const Real c6i = Real(8) * sei.x * sei.x * sei.x * sei.y;
+            Real inv[3] = {Real(1) / p.box[0], Real(1) / p.box[4], Real(1) / p.box[8]};
+            Real fx = 0, fy = 0, fz = 0;
+            for (int e = e0; e < e1; e++) {
+                const int b = p.exclList[e];
+                const auto xj = p.posq[b];
+                Real dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                if (p.periodic) wrapDelta<Real>(dx, dy, dz, p.box, inv); else unwrapDelta<Real>(dx, dy, dz, p.imageOffset, a, b);
+                const Real r2 = dx * dx + dy * dy + dz * dz;
+                const Real r = sqrt(r2);
+                const Real invR = Real(1) / r;
+                const Real ar = p.alpha * r;
+                const int slice = sliceOf(si, p.blockSubset[b >> 5]);
+                const Real lamC = p.lambdas[2 * slice], lamL = p.lambdas[2 * slice + 1];
+                const Real qq = qi * xj.w;
+                const Real ex = fexp(-ar * ar);
+                // energy evaluations use libm erf in double even in the single-precision engine: the raw slice energy is a
+                // small difference of large direct/reciprocal/exclusion sums and a 1e-7 bias in erf would show up in it.
+                const double erfv = ENERGY ? erf((double)ar) : erfOf(ar, ex);
+                Real f = 0;
+                if (erfv > 1e-6) {
+                    f = -lamC * qq * invR * invR * invR * (Real(erfv) - ar * ex * Real(1.1283791670955126));
+                    if (ENERGY) __hip_atomic_fetch_add(&s_sliceE[2 * slice], -0.5 * (double)qq * (double)invR * erfv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (ENERGY)
+                    __hip_atomic_fetch_add(&s_sliceE[2 * slice], -0.5 * (double)p.alpha * 1.1283791670955126 * (double)qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (p.ljpme) {
+                    const auto sej = p.sigeps[b];
+                    const Real c6 = c6i * (Real(8) * sej.x * sej.x * sej.x * sej.y);
+                    const Real dar2 = p.alphaD * p.alphaD * r2, dar4 = dar2 * dar2, dar6 = dar4 * dar2;
+                    const Real invR2 = invR * invR;
+                    const Real expd = fexp(-dar2);
+                    const Real coef = c6 * invR2 * invR2 * invR2;
+                    if (ENERGY) __hip_atomic_fetch_add(&s_sliceE[2 * slice + 1], 0.5 * (double)(coef * (Real(1) - expd * (Real(1) + dar2 + Real(0.5) * dar4))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // reference: dEdR = -6 c6 r^-8 (...), forces[ii] -= lam*dEdR*delta  =>  +6 lam c6 r^-8 (...) * delta on ii
+                    f += lamL * Real(6) * coef * invR2 * (Real(1) - expd * (Real(1) + dar2 + Real(0.5) * dar4 + dar6 * Real(1.0 / 6.0)));
+                }
+                fx += f * dx; fy += f * dy; fz += f * dz;
+            }
+            p.fx[a] += fx; p.fy[a] += fy; p.fz[a] += fz;
+        }
     }
-    if (f != Real(0)) {
-        gAdd(&p.fx[ij.x], f * dx); gAdd(&p.fy[ij.x], f * dy); gAdd(&p.fz[ij.x], f * dz);
-        gAdd(&p.fx[ij.y], -f * dx); gAdd(&p.fy[ij.y], -f * dy); gAdd(&p.fz[ij.y], -f * dz);
+    if (ENERGY) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nS2; i += 256) { const double v = s_sliceE[i]; if (v != 0.0) atomicAdd(&p.sliceE[i], v); }
     }
-    if (ENERGY) { atomicAdd(&p.sliceE[2 * slice], e0); if (p.ljpme) atomicAdd(&p.sliceE[2 * slice + 1], e1); }
 }
 
 template <typename Real> void launchExceptions(const PairListParams<Real>& p, bool energy, hipStream_t s) {
     if (p.n <= 0) return;
     dim3 grid((p.n + 255) / 256), block(256);
-    if (energy) hipLaunchKernelGGL((k_exceptions<Real, true>), grid, block, 0, s, p);
+    const size_t lds = sizeof(double) * 2 * p.nSlices;
+    if (energy) hipLaunchKernelGGL((k_exceptions<Real, true>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((k_exceptions<Real, false>), grid, block, 0, s, p);
 }
 template <typename Real> void launchExclusionCorrection(const PairListParams<Real>& p, bool energy, hipStream_t s) {
     if (p.n <= 0) return;
     dim3 grid((p.n + 255) / 256), block(256);
-    if (energy) hipLaunchKernelGGL((k_exclusionCorrection<Real, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((k_exclusionCorrection<Real, false>), grid, block, 0, s, p);
+    const size_t lds = sizeof(double) * 2 * p.nSlices;
+    if (energy) hipLaunchKernelGGL((k_exclusionAtoms<Real, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_exclusionAtoms<Real, false>), grid, block, 0, s, p);
 }
 template void launchExceptions<float>(const PairListParams<float>&, bool, hipStream_t);
 template void launchExceptions<double>(const PairListParams<double>&, bool, hipStream_t);

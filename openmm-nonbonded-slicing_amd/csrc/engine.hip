@@ -184,7 +184,7 @@ public:
     int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0, shardTiles = 0; bool wrapMode = false;
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> fx, fy, fz, fpx, fpy, fpz, imageOffset, dLambdas;
-    DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset;
+    DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset, exclStart, exclList;
     DevBuf<int2> pairs14, pairsExcl, colRange; DevBuf<int4> tileInfo, workItems; int numWorkItems = 0; int colCells[2] = {0, 0}; DevBuf<unsigned> masks;
     DevBuf<T4> params14, paramsExcl; int n14 = 0, nExcl = 0;
     DevBuf<double> sliceE;
@@ -594,7 +594,13 @@ public:
             qex.push_back(v);
         }
         n14 = (int)p14.size(); nExcl = (int)pex.size();
-        pairs14.upload(p14, stream); params14.upload(q14, stream); pairsExcl.upload(pex, stream); paramsExcl.upload(qex, stream);
+        pairs14.upload(p14, stream); params14.upload(q14, stream);
+        // exclusion CSR over sorted atoms (each pair listed from both ends)
+        std::vector<int> hStart((size_t)Npad + 1, 0), hList(2 * pex.size());
+        for (auto& pr : pex) { hStart[pr.x + 1]++; hStart[pr.y + 1]++; }
+        for (int i = 0; i < Npad; i++) hStart[i + 1] += hStart[i];
+        { std::vector<int> fill(Npad, 0); for (auto& pr : pex) { hList[hStart[pr.x] + fill[pr.x]++] = pr.y; hList[hStart[pr.y] + fill[pr.y]++] = pr.x; } }
+        exclStart.upload(hStart, stream); exclList.upload(hList, stream);
         stats.n_14 = n14; stats.n_exclusions = nExcl;
     }
 
@@ -693,11 +699,12 @@ public:
             q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.sliceE = sliceE.p; q.lambdas = dLambdas.p;
             const bool exPeriodic = (cfg.method == SNB_NoCutoff || cfg.method == SNB_CutoffNonPeriodic) ? false : cfg.exceptions_periodic != 0;
             q.periodic = exPeriodic ? 1 : 0; q.imageOffset = imageOffset.p;
+            q.sigeps = sigeps.p; q.blockSubset = blockSubset.p; q.exclStart = exclStart.p; q.exclList = exclList.p; q.nSlices = S;
             for (int i = 0; i < 9; i++) q.box[i] = (Real)box[i];
             q.alpha = (Real)cfg.alpha; q.alphaD = (Real)cfg.alpha_d; q.ljpme = cfg.method == SNB_LJPME;
             q.pairs = pairs14.p; q.params = params14.p; q.n = n14;
             launchExceptions<Real>(q, energy, stream);
-            if (ew) { q.pairs = pairsExcl.p; q.params = paramsExcl.p; q.n = nExcl; launchExclusionCorrection<Real>(q, energy, stream); }
+            if (ew && nExcl > 0) { q.n = Npad; launchExclusionCorrection<Real>(q, energy, stream); }
         }
         HIPCHECK(hipEventRecord(ev.e[3], stream));
         lastRecip = false;

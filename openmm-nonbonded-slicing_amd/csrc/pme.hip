@@ -113,20 +113,22 @@ template <typename Real> __global__ __launch_bounds__(256) void k_spread(const P
 // sorted ranges of its 3x3 column neighbourhood (one column of margin on each side covers the drift since the last
 // re-sort: < skin/2 < one grid cell).  Every grid point is written exactly once, coalesced along z.
 // ---------------------------------------------------------------------------------------------------
-template <typename Real> __global__ __launch_bounds__(256) void k_spreadBrick(const PmeParams<Real> p) {
+template <typename Real> __global__ __launch_bounds__(1024) void k_spreadBrick(const PmeParams<Real> p) {
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
-    double* brick = reinterpret_cast<double*>(s_brick_raw);
+    constexpr int NT = 1024, LISTCAP = 2048;
     const int cx = p.colCellsX, cy = p.colCellsY, ncx = p.d.nx / cx, ncy = p.d.ny / cy, nz = p.d.nz;
     const int ncol = ncx * ncy;
     const int slot = blockIdx.x / ncol, col = blockIdx.x - slot * ncol;
     const int Cx = col / ncy, Cy = col - Cx * ncy;
     const int x0 = Cx * cx, y0 = Cy * cy;
     const int npts = cx * cy * nz;
+    double* brick = reinterpret_cast<double*>(s_brick_raw);
+    int* list = reinterpret_cast<int*>(brick + npts);       // [LISTCAP] atoms of the current column whose stencil overlaps the brick
+    __shared__ int s_count;
     const int tid = threadIdx.x;
-    for (int i = tid; i < npts; i += 256) brick[i] = 0.0;
+    for (int i = tid; i < npts; i += NT) brick[i] = 0.0;
+    if (tid == 0) s_count = 0;
     __syncthreads();
-    const int group = tid >> 5, r = tid & 31;
-    const int rix = r / 5, riy = r - rix * 5;
     const int2* ranges = p.colRange + (size_t)p.gridSubset[slot] * ncol;
     for (int dcx = -1; dcx <= 1; dcx++) {
         int ccx = Cx + dcx; if (ccx < 0) ccx += ncx; if (ccx >= ncx) ccx -= ncx;
@@ -135,35 +137,57 @@ template <typename Real> __global__ __launch_bounds__(256) void k_spreadBrick(co
             int ccy = Cy + dcy; if (ccy < 0) ccy += ncy; if (ccy >= ncy) ccy -= ncy;
             if (!(dcy == 0 || ncy >= 3 || (ncy == 2 && dcy == -1))) continue;
             const int2 rg = ranges[ccx * ncy + ccy];
-            for (int a = rg.x + group; a < rg.y; a += 8) {
-                const Real q = pmeCharge(p, a);
-                const auto pos = p.posq[a];
-                int idx[3]; Real fr[3];
-                gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
-                // stencil start relative to the brick, folded to (-n/2, n/2]
-                int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
-                int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
-                if (rx + 4 < 0 || rx >= cx || ry + 4 < 0 || ry >= cy || q == Real(0)) continue;   // uniform per 32-lane group
-                Real tx[5], ty[5], tz[5], dtmp[5];
-                bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
-                const int lx = rx + rix, ly = ry + riy;
-                if (r < 25 && lx >= 0 && lx < cx && ly >= 0 && ly < cy) {
-                    Real wxy = q;
+            for (int chunk = rg.x; chunk < rg.y; chunk += LISTCAP) {
+                const int chunkEnd = (chunk + LISTCAP < rg.y) ? chunk + LISTCAP : rg.y;
+                // phase 1: one thread per candidate atom, coalesced loads, keep the atoms whose 5x5 footprint touches the brick
+                for (int a = chunk + tid; a < chunkEnd; a += NT) {
+                    const auto pos = p.posq[a];
+                    int idx[3]; Real fr[3];
+                    gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
+                    int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
+                    int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
+                    if (rx + 4 >= 0 && rx < cx && ry + 4 >= 0 && ry < cy && pmeCharge(p, a) != Real(0)) list[atomicAdd(&s_count, 1)] = a;
+                }
+                __syncthreads();
+                const int count = s_count;
+                // phase 2: one thread per kept atom; weights once, then the 125 stencil points (those inside the brick) into LDS
+                for (int k = tid; k < count; k += NT) {
+                    const int a = list[k];
+                    const Real q = pmeCharge(p, a);
+                    const auto pos = p.posq[a];
+                    int idx[3]; Real fr[3];
+                    gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
+                    int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
+                    int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
+                    Real tx[5], ty[5], tz[5], dtmp[5];
+                    bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
+                    int zi[5];
 #pragma unroll
-                    for (int k = 0; k < 5; k++) { if (k == rix) wxy *= tx[k]; if (k == riy) wxy *= ty[k]; }
-                    double* line = brick + (size_t)(lx * cy + ly) * nz;
+                    for (int iz = 0; iz < 5; iz++) { int z = idx[2] + iz; zi[iz] = z >= nz ? z - nz : z; }
 #pragma unroll
-                    for (int iz = 0; iz < 5; iz++) {
-                        int zi = idx[2] + iz; if (zi >= nz) zi -= nz;
-                        __hip_atomic_fetch_add(&line[zi], (double)(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int ix = 0; ix < 5; ix++) {
+                        const int lx = rx + ix;
+                        if (lx < 0 || lx >= cx) continue;
+#pragma unroll
+                        for (int iy = 0; iy < 5; iy++) {
+                            const int ly = ry + iy;
+                            if (ly < 0 || ly >= cy) continue;
+                            const Real wxy = q * tx[ix] * ty[iy];
+                            double* line = brick + (size_t)(lx * cy + ly) * nz;
+#pragma unroll
+                            for (int iz = 0; iz < 5; iz++)
+                                __hip_atomic_fetch_add(&line[zi[iz]], (double)(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
                 }
+                __syncthreads();
+                if (tid == 0) s_count = 0;
+                __syncthreads();
             }
         }
     }
-    __syncthreads();
     Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
-    for (int i = tid; i < npts; i += 256) {
+    for (int i = tid; i < npts; i += NT) {
         const int l = i / nz, z = i - l * nz;
         const int lx = l / cy, ly = l - lx * cy;
         g[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z] = (Real)brick[i];
@@ -172,10 +196,10 @@ template <typename Real> __global__ __launch_bounds__(256) void k_spreadBrick(co
 
 template <typename Real> void launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
     if (p.colCellsX > 0 && p.colRange != nullptr) {
-        const size_t lds = sizeof(double) * (size_t)p.colCellsX * p.colCellsY * p.d.nz;
+        const size_t lds = sizeof(double) * (size_t)p.colCellsX * p.colCellsY * p.d.nz + sizeof(int) * 2048;
         const int nblocks = p.nsub * (p.d.nx / p.colCellsX) * (p.d.ny / p.colCellsY);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_spreadBrick<Real>), dim3(nblocks), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((k_spreadBrick<Real>), dim3(nblocks), dim3(1024), lds, s, p);
         return;
     }
     // fallback (triclinic boxes, meshes without a usable column divisor): global float atomics
@@ -374,7 +398,8 @@ template <typename Real> __device__ inline Real recipTerm(const PmeParams<Real>&
 
 // ---- fused x-axis kernel: forward FFT_x, sliced energy, lambda-mixed convolution, inverse FFT_x ---------
 // One work-group owns NB adjacent (ky,kz) columns for ALL held subsets: batch index = sub*NB + col.
-template <typename Real> __global__ __launch_bounds__(256) void k_convolveX(const PmeParams<Real> p, int NB, int nCols) {
+template <typename Real> __global__ __launch_bounds__(512) void k_convolveX(const PmeParams<Real> p, int NB, int nCols) {
+    constexpr int NT = 512;
     const int nx = p.d.nx, nsub = p.nsub;
     const int BS = nsub * NB;
     const int c0 = blockIdx.x * NB;
@@ -382,13 +407,13 @@ template <typename Real> __global__ __launch_bounds__(256) void k_convolveX(cons
     Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
     Cx<Real>* B = A + (size_t)nx * BS;
     Real* et = reinterpret_cast<Real*>(B + (size_t)nx * BS);          // [nx][NB]
-    __shared__ double s_red[4];
+    __shared__ double s_red[NT / 64];
     const size_t strideK = (size_t)nCols;                              // ny*nzc
     const size_t strideSub = (size_t)nx * nCols;
     Cx<Real>* g = reinterpret_cast<Cx<Real>*>(p.gridCplx);
     const int tid = threadIdx.x;
     // load: when nbc < NB the unused batch slots are zero-filled so the FFT can run on the full batch shape
-    for (int it = tid; it < nx * BS; it += 256) {
+    for (int it = tid; it < nx * BS; it += NT) {
         const int k = it / BS, bb = it - k * BS;
         const int sub = bb / NB, col = bb - sub * NB;
         Cx<Real> v = {Real(0), Real(0)};
@@ -396,11 +421,11 @@ template <typename Real> __global__ __launch_bounds__(256) void k_convolveX(cons
         A[k * BS + bb] = v;
     }
     const Cx<Real>* tw = reinterpret_cast<const Cx<Real>*>(p.twx);
-    Cx<Real>* S = fftLines<Real>(A, B, nx, p.d.fx, p.d.nfx, -1, tw, BS, BS, tid, 256);
+    Cx<Real>* S = fftLines<Real>(A, B, nx, p.d.fx, p.d.nfx, -1, tw, BS, BS, tid, NT);
     Cx<Real>* O = (S == A) ? B : A;
     __syncthreads();
     // eterm per (kx, col)
-    for (int it = tid; it < nx * NB; it += 256) {
+    for (int it = tid; it < nx * NB; it += NT) {
         const int kx = it / NB, col = it - kx * NB;
         Real e = 0;
         if (col < nbc) {
@@ -418,7 +443,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_convolveX(cons
         for (int I = 0; I < nsub; I++)
             for (int J = 0; J <= I; J++) {
                 double acc = 0;
-                for (int it = tid; it < nx * NB; it += 256) {
+                for (int it = tid; it < nx * NB; it += NT) {
                     const int kx = it / NB, col = it - kx * NB;
                     if (col >= nbc) continue;
                     const int kz = (c0 + col) % p.d.nzc;
@@ -435,14 +460,15 @@ template <typename Real> __global__ __launch_bounds__(256) void k_convolveX(cons
                 if (tid == 0) {
                     const int gi = p.gridSubset[I], gj = p.gridSubset[J];
                     const int slice = gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi;
-                    atomicAdd(&p.sliceE[2 * slice + term], s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+                    double tot = 0; for (int w = 0; w < NT / 64; w++) tot += s_red[w];
+                    atomicAdd(&p.sliceE[2 * slice + term], tot);
                 }
             }
     }
     // convolution with the lambda mix:  O_I = eterm * sum_J lambda[slice(I,J)][term] * S_J   (mix=0: O_I = eterm * S_I)
     {
         const int term = p.dispersion ? 1 : 0;
-        for (int it = tid; it < nx * BS; it += 256) {
+        for (int it = tid; it < nx * BS; it += NT) {
             const int k = it / BS, bb = it - k * BS;
             const int I = bb / NB, col = bb - I * NB;
             Cx<Real> acc = {Real(0), Real(0)};
@@ -461,9 +487,9 @@ template <typename Real> __global__ __launch_bounds__(256) void k_convolveX(cons
             O[it] = {acc.x * e, acc.y * e};
         }
     }
-    Cx<Real>* R = fftLines<Real>(O, S, nx, p.d.fx, p.d.nfx, +1, tw, BS, BS, tid, 256);
+    Cx<Real>* R = fftLines<Real>(O, S, nx, p.d.fx, p.d.nfx, +1, tw, BS, BS, tid, NT);
     __syncthreads();
-    for (int it = tid; it < nx * BS; it += 256) {
+    for (int it = tid; it < nx * BS; it += NT) {
         const int k = it / BS, bb = it - k * BS;
         const int sub = bb / NB, col = bb - sub * NB;
         if (col < nbc) g[sub * strideSub + (size_t)k * strideK + c0 + col] = R[it];
@@ -506,10 +532,12 @@ template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hip
     const int nx = p.d.nx;
     const int nCols = p.d.ny * p.d.nzc;
     const size_t perCol = (size_t)2 * nx * p.nsub * sizeof(Cx<Real>) + (size_t)nx * sizeof(Real);
-    const int NB = pickBatch<Real>(perCol, 16);
+    int NB = (int)((40 * 1024) / perCol);     // ~40 KB per work-group: 3-4 work-groups of 512 threads per CU
+    if (NB > 16) NB = 16;
+    if (NB < 1) NB = 1;
     const size_t lds = perCol * NB;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_convolveX<Real>), dim3((unsigned)((nCols + NB - 1) / NB)), dim3(256), lds, s, p, NB, nCols);
+    hipLaunchKernelGGL((k_convolveX<Real>), dim3((unsigned)((nCols + NB - 1) / NB)), dim3(512), lds, s, p, NB, nCols);
 }
 
 template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipStream_t s) {

@@ -53,8 +53,13 @@ template <typename Real> struct DirectParams {
     Real shifts[27 * 3];                                   // periodic image vectors, code = (sx+1)*9+(sy+1)*3+(sz+1)
 };
 
-template <typename Real> struct PairListParams {  // exceptions (1-4) and exclusion corrections: one thread per pair
+template <typename Real> struct PairListParams {  // 1-4 exceptions: one thread per pair; exclusion corrections: one thread per atom
     const typename Vec<Real>::T4* posq;
+    const typename Vec<Real>::T2* sigeps;
+    const int* blockSubset;
+    const int* exclStart;     // [Npad+1] CSR over sorted atoms (exclusion corrections: n = Npad)
+    const int* exclList;      // sorted partner indices
+    int nSlices;
     const int2* pairs;        // sorted indices
     const typename Vec<Real>::T4* params;   // 1-4: (sigma, 4 eps, k*qq, slice bits) ; exclusion: (k*qi*qj, c6i*c6j, -, slice bits)
     int n;
