@@ -30,6 +30,9 @@ __device__ inline float erfcFromExp(float ar, float e) {
     return (0.254829592f + (-0.284496736f + (1.421413741f + (-1.453152027f + 1.061405429f * t) * t) * t) * t) * t * e;
 }
 __device__ inline double erfcFromExp(double ar, double) { return erfc(ar); }
+// exp(-alpha^2 r^2): single precision folds log2(e) into the constant and issues one v_exp_f32
+__device__ inline float expNegAlpha2R2(float a2l2e, float, float r2) { return __builtin_amdgcn_exp2f(-a2l2e * r2); }
+__device__ inline double expNegAlpha2R2(double, double alpha, double r2) { return exp(-alpha * alpha * r2); }
 __device__ inline double erfOf(float ar, float e) { return (double)(1.0f - erfcFromExp(ar, e)); }
 __device__ inline double erfOf(double ar, double) { return erf(ar); }
 
@@ -61,13 +64,103 @@ template <typename Real> __device__ inline void unwrapDelta(Real& dx, Real& dy, 
 
 // ---- cross-lane helpers -------------------------------------------------------------------------
 // DPP row_ror:1 -- every 16-lane row rotates by one lane (lane c receives the value of lane (c-1)&15).
-__device__ inline float rowRor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false)); }
+__device__ inline float rowRor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true)); }
 __device__ inline double rowRor1(double v) {
     long long b = __builtin_bit_cast(long long, v);
     int lo = (int)b, hi = (int)(b >> 32);
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xF, 0xF, false);
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xF, 0xF, false);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+// The 16 pair steps of one tile for this lane's row.  MASKED: the tile carries an exclusion/padding mask;
+// SWITCH: LJ switching function active.  Both are wave-uniform and resolved at compile time so that the common
+// case (no mask, no switch) carries no test for them in the loop.
+template <typename Real, int MC, bool WRAP, bool ENERGY, bool MASKED, bool SWITCH>
+__device__ __forceinline__ void tileSteps(const DirectParams<Real>& p, const typename Vec<Real>::T4* rdPos, const typename Vec<Real>::T2* rdSe,
+                                          const typename Vec<Real>::T4 pi, const typename Vec<Real>::T2 sei, const Real qi, const Real qiS, const Real epsiS,
+                                          const Real c6i, const Real lamC, const Real lamL, const unsigned maskWord, const int c,
+                                          Real& fix, Real& fiy, Real& fiz, Real& fjx, Real& fjy, Real& fjz, Real& ecl, Real& elj) {
+    using T4 = typename Vec<Real>::T4;
+    using T2 = typename Vec<Real>::T2;
+#pragma unroll 4
+        for (int s = 0; s < 16; s++) {
+            const T4 xj = rdPos[-s];
+            const T2 sj2 = rdSe[-s];
+            Real dx = pi.x - xj.x, dy = pi.y - xj.y, dz = pi.z - xj.z;
+            if (WRAP) wrapDelta<Real>(dx, dy, dz, p.box, p.invBoxDiag);
+            const Real r2 = dx * dx + dy * dy + dz * dz;
+            const Real invR = rsq(r2);
+            const Real r = r2 * invR;
+            bool include = MC == MC_NOCUTOFF ? true : (r2 < p.cutoff2);
+            if (MASKED) include = include && !((maskWord >> ((c - s) & 15)) & 1u);
+
+            // Lennard-Jones (ReferenceSlicedLJCoulombIxn.cpp:390-396, 600-616)
+            const Real sig = sei.x + sj2.x;
+            Real s2 = sig * invR; s2 *= s2;
+            const Real s6 = s2 * s2 * s2;
+            Real fLJ, eLJ = 0, fC, eC = 0;
+            if (ENERGY) {
+                const Real es6 = sei.y * sj2.y * s6;
+                fLJ = es6 * (Real(12) * s6 - Real(6));
+                eLJ = es6 * (s6 - Real(1));
+            } else {
+                const Real es6 = epsiS * sj2.y * s6;
+                fLJ = es6 * (Real(12) * s6 - Real(6));
+            }
+            if (MC == MC_LJPME) {
+                // multiplicative grid term + potential shifts (:398-426)
+                const Real dar2 = p.alphaD * p.alphaD * r2;
+                const Real dar4 = dar2 * dar2, dar6 = dar4 * dar2;
+                const Real invR2 = invR * invR;
+                const Real c6 = c6i * (Real(8) * sj2.x * sj2.x * sj2.x * sj2.y);
+                const Real coef = invR2 * invR2 * invR2 * c6;
+                const Real expd = fexp(-dar2);
+                const Real epre = Real(1) + dar2 + Real(0.5) * dar4;
+                const Real dpre = epre + dar6 * Real(1.0 / 6.0);
+                const Real fmul = Real(6) * coef * (Real(1) - expd * dpre);
+                if (ENERGY) {
+                    Real sg2 = sig * sig; const Real sg6 = sg2 * sg2 * sg2 * p.invCut6;
+                    eLJ += coef * (Real(1) - expd * epre) + sei.y * sj2.y * (Real(1) - sg6) * sg6 - c6 * p.multShift6;
+                    fLJ += fmul;
+                } else
+                    fLJ += fmul * lamL;
+            } else if (MC != MC_NOCUTOFF) {
+                if (SWITCH && r > p.switchDist) {        // (:380-384, 428-431)
+                    const Real tt = (r - p.switchDist) * p.invSwitchWidth;
+                    const Real sw = Real(1) + tt * tt * tt * (Real(-10) + tt * (Real(15) - tt * Real(6)));
+                    const Real dsw = tt * tt * (Real(-30) + tt * (Real(60) - tt * Real(30))) * p.invSwitchWidth;
+                    Real e0 = eLJ;
+                    if (!ENERGY) { const Real es6 = epsiS * sj2.y * s6; e0 = es6 * (s6 - Real(1)); }
+                    fLJ = fLJ * sw - e0 * dsw * r;
+                    eLJ *= sw;
+                }
+            }
+            // Coulomb
+            const Real qq = (ENERGY ? qi : qiS) * xj.w;
+            if (MC == MC_EWALD || MC == MC_LJPME) {
+                const Real ar = p.alpha * r;
+                const Real ex = expNegAlpha2R2(p.alpha2l2e, p.alpha, r2);
+                const Real erfcv = erfcFromExp(ar, ex);
+                const Real pref = qq * invR;
+                fC = pref * (erfcv + ar * ex * Real(1.1283791670955126));   // 2/sqrt(pi) (:387-388)
+                if (ENERGY) eC = pref * erfcv;                                // (:444)
+            } else if (MC == MC_RF) {
+                fC = qq * (invR - Real(2) * p.krf * r2);                      // (:609)
+                if (ENERGY) eC = qq * (invR + p.krf * r2 - p.crf);            // (:619)
+            } else {
+                fC = qq * invR;                                               // (:611)
+                if (ENERGY) eC = fC;
+            }
+            Real f = ENERGY ? (lamL * fLJ + lamC * fC) : (fLJ + fC);
+            f *= invR * invR;
+            f = include ? f : Real(0);
+            if (ENERGY) { ecl += include ? eC : Real(0); elj += include ? eLJ : Real(0); }
+            const Real gx = f * dx, gy = f * dy, gz = f * dz;
+            fix += gx; fiy += gy; fiz += gz;
+            // the accumulator follows its j-slot along the row: rotate in (slot of lane c at step s = slot of lane c-1 at step s-1), then add
+            fjx = rowRor1(fjx) - gx; fjy = rowRor1(fjy) - gy; fjz = rowRor1(fjz) - gz;
+        }
 }
 
 // ---- the tile kernel ----------------------------------------------------------------------------
@@ -77,7 +170,7 @@ __device__ inline double rowRor1(double v) {
 // so after 16 steps lane c holds the force on j-slot c.  j-atom data is read from LDS (staged once per tile, each
 // 16-atom half stored twice so the rotated index c+16-s needs no wrap).
 template <typename Real, int MC, bool WRAP, bool ENERGY>
-__global__ __launch_bounds__(256) void k_direct(const DirectParams<Real> p) {
+__global__ __launch_bounds__(256, 6) void k_direct(const DirectParams<Real> p) {
     using T4 = typename Vec<Real>::T4;
     using T2 = typename Vec<Real>::T2;
     __shared__ T4 s_pos[4][64];
@@ -144,90 +237,20 @@ __global__ __launch_bounds__(256) void k_direct(const DirectParams<Real> p) {
             ecl = 0; elj = 0; curSlice = slice;
         }
         const Real lamC = p.lambdas[2 * slice], lamL = p.lambdas[2 * slice + 1];
-        unsigned maskWord = info.y >= 0 ? p.masks[info.y * 32 + il] : 0u;
+        const bool hasMask = info.y >= 0;
+        unsigned maskWord = hasMask ? p.masks[info.y * 32 + il] : 0u;
         maskWord >>= 16 * jh;                            // my j-half's 16 bits
         // lambda folded into the i-side parameters once per tile (forces only need the scaled values)
         const Real qiS = qi * lamC;
         const Real epsiS = sei.y * lamL;
         Real fjx = 0, fjy = 0, fjz = 0;
 
-#pragma unroll 4
-        for (int s = 0; s < 16; s++) {
-            const T4 xj = rdPos[-s];
-            const T2 sj2 = rdSe[-s];
-            Real dx = pi.x - xj.x, dy = pi.y - xj.y, dz = pi.z - xj.z;
-            if (WRAP) wrapDelta<Real>(dx, dy, dz, p.box, p.invBoxDiag);
-            const Real r2 = dx * dx + dy * dy + dz * dz;
-            const Real invR = rsq(r2);
-            const Real r = r2 * invR;
-            bool include = !((maskWord >> ((c - s) & 15)) & 1u);
-            if (MC != MC_NOCUTOFF) include = include && (r2 < p.cutoff2);
-
-            // Lennard-Jones (ReferenceSlicedLJCoulombIxn.cpp:390-396, 600-616)
-            const Real sig = sei.x + sj2.x;
-            Real s2 = sig * invR; s2 *= s2;
-            const Real s6 = s2 * s2 * s2;
-            Real fLJ, eLJ = 0, fC, eC = 0;
-            if (ENERGY) {
-                const Real es6 = sei.y * sj2.y * s6;
-                fLJ = es6 * (Real(12) * s6 - Real(6));
-                eLJ = es6 * (s6 - Real(1));
-            } else {
-                const Real es6 = epsiS * sj2.y * s6;
-                fLJ = es6 * (Real(12) * s6 - Real(6));
-            }
-            if (MC == MC_LJPME) {
-                // multiplicative grid term + potential shifts (:398-426)
-                const Real dar2 = p.alphaD * p.alphaD * r2;
-                const Real dar4 = dar2 * dar2, dar6 = dar4 * dar2;
-                const Real invR2 = invR * invR;
-                const Real c6 = c6i * (Real(8) * sj2.x * sj2.x * sj2.x * sj2.y);
-                const Real coef = invR2 * invR2 * invR2 * c6;
-                const Real expd = fexp(-dar2);
-                const Real epre = Real(1) + dar2 + Real(0.5) * dar4;
-                const Real dpre = epre + dar6 * Real(1.0 / 6.0);
-                const Real fmul = Real(6) * coef * (Real(1) - expd * dpre);
-                if (ENERGY) {
-                    Real sg2 = sig * sig; const Real sg6 = sg2 * sg2 * sg2 * p.invCut6;
-                    eLJ += coef * (Real(1) - expd * epre) + sei.y * sj2.y * (Real(1) - sg6) * sg6 - c6 * p.multShift6;
-                    fLJ += fmul;
-                } else
-                    fLJ += fmul * lamL;
-            } else if (MC != MC_NOCUTOFF) {
-                if (p.useSwitch && r > p.switchDist) {   // (:380-384, 428-431); wave-uniform flag, per-lane distance
-                    const Real tt = (r - p.switchDist) * p.invSwitchWidth;
-                    const Real sw = Real(1) + tt * tt * tt * (Real(-10) + tt * (Real(15) - tt * Real(6)));
-                    const Real dsw = tt * tt * (Real(-30) + tt * (Real(60) - tt * Real(30))) * p.invSwitchWidth;
-                    Real e0 = eLJ;
-                    if (!ENERGY) { const Real es6 = epsiS * sj2.y * s6; e0 = es6 * (s6 - Real(1)); }
-                    fLJ = fLJ * sw - e0 * dsw * r;
-                    eLJ *= sw;
-                }
-            }
-            // Coulomb
-            const Real qq = (ENERGY ? qi : qiS) * xj.w;
-            if (MC == MC_EWALD || MC == MC_LJPME) {
-                const Real ar = p.alpha * r;
-                const Real ex = fexp(-ar * ar);
-                const Real erfcv = erfcFromExp(ar, ex);
-                const Real pref = qq * invR;
-                fC = pref * (erfcv + ar * ex * Real(1.1283791670955126));   // 2/sqrt(pi) (:387-388)
-                if (ENERGY) eC = pref * erfcv;                                // (:444)
-            } else if (MC == MC_RF) {
-                fC = qq * (invR - Real(2) * p.krf * r2);                      // (:609)
-                if (ENERGY) eC = qq * (invR + p.krf * r2 - p.crf);            // (:619)
-            } else {
-                fC = qq * invR;                                               // (:611)
-                if (ENERGY) eC = fC;
-            }
-            Real f = ENERGY ? (lamL * fLJ + lamC * fC) : (fLJ + fC);
-            f *= invR * invR;
-            f = include ? f : Real(0);
-            if (ENERGY) { ecl += include ? eC : Real(0); elj += include ? eLJ : Real(0); }
-            const Real gx = f * dx, gy = f * dy, gz = f * dz;
-            fix += gx; fiy += gy; fiz += gz;
-            // the accumulator follows its j-slot along the row: rotate in (slot of lane c at step s = slot of lane c-1 at step s-1), then add
-            fjx = rowRor1(fjx) - gx; fjy = rowRor1(fjy) - gy; fjz = rowRor1(fjz) - gz;
+        if (p.useSwitch && MC != MC_LJPME && MC != MC_NOCUTOFF) {
+            if (hasMask) tileSteps<Real, MC, WRAP, ENERGY, true, true>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+            else tileSteps<Real, MC, WRAP, ENERGY, false, true>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+        } else {
+            if (hasMask) tileSteps<Real, MC, WRAP, ENERGY, true, false>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+            else tileSteps<Real, MC, WRAP, ENERGY, false, false>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
         }
         // rotate-then-add leaves lane c holding slot c+1: one more rotation brings every slot home; then add the two
         // i-halves (rows r and r^1) and flush

@@ -674,6 +674,7 @@ public:
             p.krf = (Real)(std::pow(cfg.cutoff, -3.0) * (cfg.rf_dielectric - 1.0) / (2.0 * cfg.rf_dielectric + 1.0));
             p.crf = (Real)((1.0 / cfg.cutoff) * (3.0 * cfg.rf_dielectric) / (2.0 * cfg.rf_dielectric + 1.0));
             p.alpha = (Real)cfg.alpha; p.alphaD = (Real)cfg.alpha_d; p.k4pe = (Real)SNB_ONE_4PI_EPS0;
+            p.alpha2l2e = (Real)(cfg.alpha * cfg.alpha * 1.4426950408889634);
             const double ic2 = 1.0 / (cfg.cutoff * cfg.cutoff), ic6 = ic2 * ic2 * ic2;
             const double dar2 = cfg.alpha_d * cfg.alpha_d * cfg.cutoff * cfg.cutoff;
             p.invCut6 = (Real)ic6; p.multShift6 = (Real)(ic6 * (1.0 - std::exp(-dar2) * (1.0 + dar2 + 0.5 * dar2 * dar2)));

@@ -438,7 +438,7 @@ template <typename Real> __global__ __launch_bounds__(512) void k_convolveX(cons
     __syncthreads();
     // per-slice energies: E_II = 1/2 sum_k eterm |S_I|^2 ; E_IJ = sum_k eterm Re(S_I conj S_J) (ReferencePME.cpp:487-491),
     // over the full grid => Hermitian weight 2 for interior kz planes.
-    if (p.wantEnergy) {
+    if (p.wantEnergy && p.mix) {   // sharded engines get the energies by interpolation instead (k_interpolate)
         const int term = p.dispersion ? 1 : 0;
         for (int I = 0; I < nsub; I++)
             for (int J = 0; J <= I; J++) {
@@ -580,9 +580,13 @@ template void launchPmeFFTX<double>(const PmeParams<double>&, int, hipStream_t);
 // grids this engine holds, scaling by lambda[slice(s_i, J)], and also accumulates E = 1/2 q psi_J(r_i).
 // ---------------------------------------------------------------------------------------------------
 template <typename Real> __global__ __launch_bounds__(256) void k_interpolate(const PmeParams<Real> p) {
+    extern __shared__ double s_sliceE[];   // [2*S], sharded energy evaluation only
+    const bool shardE = !p.mix && p.wantEnergy;
+    const int nS2 = p.nsubTotal * (p.nsubTotal + 1);
+    if (shardE) { for (int i = threadIdx.x; i < nS2; i += 256) s_sliceE[i] = 0.0; __syncthreads(); }
     const int gid = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int r = threadIdx.x & 31;
-    if (gid >= p.natoms) return;
+    if (gid < p.natoms) {
     const int si = p.atomSubset[gid];
     const Real q = si >= 0 ? pmeCharge(p, gid) : Real(0);
     const auto pos = p.posq[gid];
@@ -619,6 +623,13 @@ template <typename Real> __global__ __launch_bounds__(256) void k_interpolate(co
                 sz += tz[iz] * gv; sdz += dz[iz] * gv;
             }
             fx += lam * dxv * tyv * sz; fy += lam * txv * dyv * sz; fz += lam * txv * tyv * sdz;
+            if (shardE) {
+                // E[slice(s_i, J)] += 1/2 q_i psi_J(r_i): equal to the k-space Gram sum because spreading and interpolation
+                // use the same B-splines; the off-diagonal slice receives its two halves from the two owner ranks
+                const int gj = p.gridSubset[gI];
+                const int slice = si > gj ? si * (si + 1) / 2 + gj : gj * (gj + 1) / 2 + si;
+                __hip_atomic_fetch_add(&s_sliceE[2 * slice + term], 0.5 * (double)q * (double)(txv * tyv * sz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
 #pragma unroll
@@ -631,11 +642,17 @@ template <typename Real> __global__ __launch_bounds__(256) void k_interpolate(co
         if (p.dispersion) { p.fpx[gid] += gx; p.fpy[gid] += gy; p.fpz[gid] += gz; }   // second pipeline of LJPME adds
         else { p.fpx[gid] = gx; p.fpy[gid] = gy; p.fpz[gid] = gz; }
     }
+    }
+    if (shardE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nS2; i += 256) { const double v = s_sliceE[i]; if (v != 0.0) atomicAdd(&p.sliceE[i], v); }
+    }
 }
 
 template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s) {
     if (p.natoms <= 0) return;
-    hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), 0, s, p);
+    const size_t lds = (!p.mix && p.wantEnergy) ? sizeof(double) * p.nsubTotal * (p.nsubTotal + 1) : 0;
+    hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
 }
 
 template void launchPmeSpread<float>(const PmeParams<float>&, hipStream_t);
