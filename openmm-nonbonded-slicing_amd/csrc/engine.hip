@@ -183,7 +183,8 @@ public:
     // sorted state
     int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0, shardTiles = 0; bool wrapMode = false;
     std::vector<int> sortedToUser, userToSorted;
-    DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> fx, fy, fz, fpx, fpy, fpz, imageOffset, dLambdas;
+    DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
+    struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
     DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset, exclStart, exclList;
     DevBuf<int2> pairs14, pairsExcl, colRange; DevBuf<int4> tileInfo, workItems; int numWorkItems = 0; int colCells[2] = {0, 0}; DevBuf<unsigned> masks;
     DevBuf<T4> params14, paramsExcl; int n14 = 0, nExcl = 0;
@@ -191,6 +192,9 @@ public:
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
+    struct GraphKey { const void* pos; int isDouble, stride4; bool direct, recip; bool operator==(const GraphKey& o) const { return pos == o.pos && isDouble == o.isDouble && stride4 == o.stride4 && direct == o.direct && recip == o.recip; } };
+    hipGraphExec_t graphExec = nullptr; GraphKey graphKey{}; long long execCount = 0;
+    void dropGraph() { if (graphExec) { (void)hipGraphExecDestroy(graphExec); graphExec = nullptr; } }
     bool lastRecip = false;
     snb_stats stats;
 
@@ -223,6 +227,7 @@ public:
     }
     ~Engine() override {
         (void)hipStreamSynchronize(stream);
+        dropGraph();
         for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
         if (ownStream) (void)hipStreamDestroy(stream);
     }
@@ -282,6 +287,7 @@ public:
 
     void rebuild() {
         auto t0 = std::chrono::steady_clock::now();
+        dropGraph();   // buffers may move and every kernel argument block changes
         // 1. host copy of the user positions
         std::vector<double> hp((size_t)N * 3);
         {
@@ -565,7 +571,8 @@ public:
         blockSubset.upload(blkSubset, stream); workItems.upload(hWork, stream);
         tileJ.upload(hTileJ, stream); tileInfo.upload(hTileInfo, stream); masks.upload(hMasks, stream);
         atomSubset.upload(hAtomSubset, stream); atomGrid.upload(hAtomGrid, stream);
-        fx.resize(Npad); fy.resize(Npad); fz.resize(Npad); fpx.resize(Npad); fpy.resize(Npad); fpz.resize(Npad);
+        forceBuf.resize((size_t)6 * Npad);
+        fx.p = forceBuf.p; fy.p = fx.p + Npad; fz.p = fy.p + Npad; fpx.p = fz.p + Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
         buildPairLists();
         HIPCHECK(hipStreamSynchronize(stream));
         needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;
@@ -606,6 +613,7 @@ public:
 
     // parameters changed but the sort is still valid: refresh the sorted parameter arrays in place
     void refreshParameters() {
+        dropGraph();
         std::vector<T2> hSigeps(Npad); std::vector<Real> hq(Npad, Real(0));
         for (int s = 0; s < Npad; s++) {
             int u = sortedToUser[s];
@@ -652,16 +660,48 @@ public:
         else if (paramsDirty) refreshParameters();
         stepsSinceRebuild++;
         const bool energy = includeEnergy != 0;
-        EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
-        if (ev.pending) harvest(ev);
-        HIPCHECK(hipEventRecord(ev.e[0], stream));
+        lastRecip = includeRecip && isPme();
+        // Forces-only steps replay a captured hipGraph (the ~14 small launches of a step are host-launch-bound otherwise:
+        // 7-8 us of idle GPU between kernels).  Every 8th step -- and every energy step -- is enqueued eagerly with HIP events
+        // around the pair kernel and the reciprocal pipeline; those samples feed snb_stats' kernel timers.
+        const bool eager = energy || cfg.disable_graph || (execCount++ % 8 == 0);
+        if (eager) {
+            EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
+            if (ev.pending) harvest(ev);
+            enqueueStep(energy, includeDirect != 0, includeRecip != 0, &ev);
+            ev.pending = true;
+        } else {
+            GraphKey key{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0};
+            if (!graphExec || !(key == graphKey)) {
+                dropGraph();
+                hipGraph_t graph = nullptr;
+                HIPCHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                try { enqueueStep(false, includeDirect != 0, includeRecip != 0, nullptr); }
+                catch (...) { (void)hipStreamEndCapture(stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+                HIPCHECK(hipStreamEndCapture(stream, &graph));
+                HIPCHECK(hipGraphInstantiate(&graphExec, graph, nullptr, nullptr, 0));
+                HIPCHECK(hipGraphDestroy(graph));
+                graphKey = key;
+            }
+            HIPCHECK(hipGraphLaunch(graphExec, stream));
+        }
+        if (energy) {
+            std::vector<double> dev((size_t)S * 2);
+            HIPCHECK(hipMemcpyAsync(dev.data(), sliceE.p, sizeof(double) * S * 2, hipMemcpyDeviceToHost, stream));
+            HIPCHECK(hipStreamSynchronize(stream));
+            hostSliceE = dev;
+            addHostTerms(includeDirect != 0, includeRecip != 0);
+            if (energyOut) { double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }
+        } else if (energyOut) *energyOut = 0.0;
+    }
+
+    void enqueueStep(bool energy, bool includeDirect, bool includeRecip, EvSet* ev) {
+        if (ev) HIPCHECK(hipEventRecord(ev->e[0], stream));
         launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, stream);
-        HIPCHECK(hipMemsetAsync(fx.p, 0, sizeof(Real) * Npad, stream));
-        HIPCHECK(hipMemsetAsync(fy.p, 0, sizeof(Real) * Npad, stream));
-        HIPCHECK(hipMemsetAsync(fz.p, 0, sizeof(Real) * Npad, stream));
+        HIPCHECK(hipMemsetAsync(forceBuf.p, 0, sizeof(Real) * 6 * Npad, stream));
         if (energy) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2, stream));
         const bool ew = cfg.method >= SNB_Ewald;
-        HIPCHECK(hipEventRecord(ev.e[1], stream));
+        if (ev) HIPCHECK(hipEventRecord(ev->e[1], stream));
         if (includeDirect) {
             DirectParams<Real> p;
             std::memset(&p, 0, sizeof(p));
@@ -693,7 +733,7 @@ public:
             else if (cfg.method == SNB_LJPME) mc = MC_LJPME;
             launchDirect<Real>(p, mc, wrapMode, energy, stream);
         }
-        HIPCHECK(hipEventRecord(ev.e[2], stream));
+        if (ev) HIPCHECK(hipEventRecord(ev->e[2], stream));
         if (includeDirect && cfg.shard_rank == 0) {   // O(N) pair lists: rank 0 only when sharded
             PairListParams<Real> q;
             std::memset(&q, 0, sizeof(q));
@@ -707,30 +747,17 @@ public:
             launchExceptions<Real>(q, energy, stream);
             if (ew && nExcl > 0) { q.n = Npad; launchExclusionCorrection<Real>(q, energy, stream); }
         }
-        HIPCHECK(hipEventRecord(ev.e[3], stream));
-        lastRecip = false;
+        if (ev) HIPCHECK(hipEventRecord(ev->e[3], stream));
         if (includeRecip && isPme()) {
-            lastRecip = true;
             if (nGrids > 0) {
                 PmeParams<Real> pp;
                 std::memset(&pp, 0, sizeof(pp));
                 fillPme(pp, pme, energy);
                 runPme(pp);
                 if (cfg.method == SNB_LJPME) { fillPme(pp, dpme, energy); runPme(pp); }
-            } else {
-                HIPCHECK(hipMemsetAsync(fpx.p, 0, sizeof(Real) * Npad, stream)); HIPCHECK(hipMemsetAsync(fpy.p, 0, sizeof(Real) * Npad, stream)); HIPCHECK(hipMemsetAsync(fpz.p, 0, sizeof(Real) * Npad, stream));
             }
         }
-        HIPCHECK(hipEventRecord(ev.e[4], stream));
-        ev.pending = true;
-        if (energy) {
-            std::vector<double> dev((size_t)S * 2);
-            HIPCHECK(hipMemcpyAsync(dev.data(), sliceE.p, sizeof(double) * S * 2, hipMemcpyDeviceToHost, stream));
-            HIPCHECK(hipStreamSynchronize(stream));
-            hostSliceE = dev;
-            addHostTerms(includeDirect != 0, includeRecip != 0);
-            if (energyOut) { double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }
-        } else if (energyOut) *energyOut = 0.0;
+        if (ev) HIPCHECK(hipEventRecord(ev->e[4], stream));
     }
 
     void harvest(EvSet& ev) {

@@ -310,11 +310,12 @@ template <typename Real, bool FORWARD> __global__ __launch_bounds__(256) void k_
     const int BS = NL + 1;   // padded batch stride (bank spread for the transposing LDS accesses)
     Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
     Cx<Real>* B = A + (size_t)nz * BS;
+    Cx<Real>* tw = B + (size_t)nz * BS;                 // roots of unity staged in LDS (the butterflies index them per item)
     const size_t nlines = (size_t)p.nsub * p.d.nx * p.d.ny;
     const size_t line0 = (size_t)blockIdx.x * NL;
     const int nb = (int)((nlines - line0) < (size_t)NL ? (nlines - line0) : (size_t)NL);
     const int tid = threadIdx.x;
-    const Cx<Real>* tw = reinterpret_cast<const Cx<Real>*>(p.twz);
+    for (int k = tid; k < nz; k += 256) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
     if (FORWARD) {
         for (int it = tid; it < nb * nz; it += 256) {
             const int l = it / nz, k = it - l * nz;
@@ -353,13 +354,14 @@ template <typename Real> __global__ __launch_bounds__(256) void k_fftStrided(con
     const int nb = (nbTotal - b0) < NB ? (nbTotal - b0) : NB;
     Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
     Cx<Real>* B = A + (size_t)n * NB;
+    Cx<Real>* tw = B + (size_t)n * NB;
     Cx<Real>* g = reinterpret_cast<Cx<Real>*>(p.gridCplx) + (size_t)a * strideA + b0;
     const int tid = threadIdx.x;
+    for (int k = tid; k < n; k += 256) tw[k] = reinterpret_cast<const Cx<Real>*>(axis == 1 ? p.twy : p.twx)[k];
     for (int it = tid; it < n * nb; it += 256) {
         const int k = it / nb, b = it - k * nb;
         A[k * NB + b] = g[(size_t)k * strideK + b];
     }
-    const Cx<Real>* tw = reinterpret_cast<const Cx<Real>*>(axis == 1 ? p.twy : p.twx);
     Cx<Real>* R = fftLines<Real>(A, B, n, axis == 1 ? p.d.fy : p.d.fx, axis == 1 ? p.d.nfy : p.d.nfx, sign, tw, nb, NB, tid, 256);
     __syncthreads();
     for (int it = tid; it < n * nb; it += 256) {
@@ -406,7 +408,8 @@ template <typename Real> __global__ __launch_bounds__(512) void k_convolveX(cons
     const int nbc = (nCols - c0) < NB ? (nCols - c0) : NB;
     Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
     Cx<Real>* B = A + (size_t)nx * BS;
-    Real* et = reinterpret_cast<Real*>(B + (size_t)nx * BS);          // [nx][NB]
+    Cx<Real>* tw = B + (size_t)nx * BS;                                // [nx] roots of unity
+    Real* et = reinterpret_cast<Real*>(tw + nx);                       // [nx][NB]
     __shared__ double s_red[NT / 64];
     const size_t strideK = (size_t)nCols;                              // ny*nzc
     const size_t strideSub = (size_t)nx * nCols;
@@ -420,7 +423,7 @@ template <typename Real> __global__ __launch_bounds__(512) void k_convolveX(cons
         if (col < nbc) v = g[sub * strideSub + (size_t)k * strideK + c0 + col];
         A[k * BS + bb] = v;
     }
-    const Cx<Real>* tw = reinterpret_cast<const Cx<Real>*>(p.twx);
+    for (int k = tid; k < nx; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twx)[k];
     Cx<Real>* S = fftLines<Real>(A, B, nx, p.d.fx, p.d.nfx, -1, tw, BS, BS, tid, NT);
     Cx<Real>* O = (S == A) ? B : A;
     __syncthreads();
@@ -512,7 +515,7 @@ template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipS
         int NL = pickBatch<Real>((size_t)2 * nz * sizeof(Cx<Real>), 17) - 1;   // padded stride NL+1 must be odd
         NL &= ~1;
         if (NL < 2) NL = 2;
-        const size_t lds = (size_t)2 * nz * (NL + 1) * sizeof(Cx<Real>);
+        const size_t lds = (size_t)2 * nz * (NL + 1) * sizeof(Cx<Real>) + (size_t)nz * sizeof(Cx<Real>);
         const size_t nlines = (size_t)p.nsub * nx * ny;
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_fftZ<Real, true>), dim3((unsigned)((nlines + NL - 1) / NL)), dim3(256), lds, s, p, NL);
@@ -520,7 +523,7 @@ template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipS
     // y
     {
         const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), 16);
-        const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>);
+        const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>) + (size_t)ny * sizeof(Cx<Real>);
         const int tilesPerA = (nzc + NB - 1) / NB;
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_fftStrided<Real>), dim3((unsigned)(p.nsub * nx * tilesPerA)), dim3(256), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB,
@@ -532,10 +535,11 @@ template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hip
     const int nx = p.d.nx;
     const int nCols = p.d.ny * p.d.nzc;
     const size_t perCol = (size_t)2 * nx * p.nsub * sizeof(Cx<Real>) + (size_t)nx * sizeof(Real);
+    const size_t twBytes = (size_t)nx * sizeof(Cx<Real>);
     int NB = (int)((40 * 1024) / perCol);     // ~40 KB per work-group: 3-4 work-groups of 512 threads per CU
     if (NB > 16) NB = 16;
     if (NB < 1) NB = 1;
-    const size_t lds = perCol * NB;
+    const size_t lds = perCol * NB + twBytes;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_convolveX<Real>), dim3((unsigned)((nCols + NB - 1) / NB)), dim3(512), lds, s, p, NB, nCols);
 }
@@ -544,7 +548,7 @@ template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipS
     const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc;
     {
         const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), 16);
-        const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>);
+        const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>) + (size_t)ny * sizeof(Cx<Real>);
         const int tilesPerA = (nzc + NB - 1) / NB;
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_fftStrided<Real>), dim3((unsigned)(p.nsub * nx * tilesPerA)), dim3(256), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB,
@@ -554,7 +558,7 @@ template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipS
         int NL = pickBatch<Real>((size_t)2 * nz * sizeof(Cx<Real>), 17) - 1;   // padded stride NL+1 must be odd
         NL &= ~1;
         if (NL < 2) NL = 2;
-        const size_t lds = (size_t)2 * nz * (NL + 1) * sizeof(Cx<Real>);
+        const size_t lds = (size_t)2 * nz * (NL + 1) * sizeof(Cx<Real>) + (size_t)nz * sizeof(Cx<Real>);
         const size_t nlines = (size_t)p.nsub * nx * ny;
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_fftZ<Real, false>), dim3((unsigned)((nlines + NL - 1) / NL)), dim3(256), lds, s, p, NL);
@@ -565,7 +569,7 @@ template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipS
 template <typename Real> void launchPmeFFTX(const PmeParams<Real>& p, int sign, hipStream_t s) {
     const int nx = p.d.nx, nCols = p.d.ny * p.d.nzc;
     const int NB = pickBatch<Real>((size_t)2 * nx * sizeof(Cx<Real>), 16);
-    const size_t lds = (size_t)2 * nx * NB * sizeof(Cx<Real>);
+    const size_t lds = (size_t)2 * nx * NB * sizeof(Cx<Real>) + (size_t)nx * sizeof(Cx<Real>);
     const int tilesPerA = (nCols + NB - 1) / NB;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_fftStrided<Real>), dim3((unsigned)(p.nsub * tilesPerA)), dim3(256), lds, s, p, nx, (size_t)nx * nCols, nCols, (size_t)nCols, NB,
@@ -649,8 +653,90 @@ template <typename Real> __global__ __launch_bounds__(256) void k_interpolate(co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Brick interpolation (unsharded production path on rectangular boxes): the mirror image of k_spreadBrick.
+// One work-group stages the (c_x+6) x (c_y+6) x nz neighbourhood of one column of ONE pre-mixed potential grid in LDS
+// with coalesced loads (halo: 4 stencil cells + 1 cell of drift on either side), then ONE THREAD PER ATOM of that
+// (subset, column) range evaluates its 125-point stencil out of LDS.  ~14 wave-instructions per atom instead of ~180
+// for the 32-lanes-per-atom gather kernel (which recomputes the B-splines 32 times and reduces by shuffles).
+// ---------------------------------------------------------------------------------------------------
+template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBrick(const PmeParams<Real> p) {
+    extern __shared__ __align__(16) unsigned char s_brick_raw[];
+    constexpr int NT = 1024, HALO_LO = 1, EXTRA = 6;
+    Real* brick = reinterpret_cast<Real*>(s_brick_raw);
+    const int cx = p.colCellsX, cy = p.colCellsY, ncx = p.d.nx / cx, ncy = p.d.ny / cy, nz = p.d.nz;
+    const int ncol = ncx * ncy;
+    const int slot = blockIdx.x / ncol, col = blockIdx.x - slot * ncol;
+    const int2 rg = p.colRange[(size_t)p.gridSubset[slot] * ncol + col];
+    if (rg.y <= rg.x) return;                                 // empty column of this subset: nothing to interpolate
+    const int Cx = col / ncy, Cy = col - Cx * ncy;
+    const int x0 = Cx * cx, y0 = Cy * cy;
+    const int bx = cx + EXTRA, by = cy + EXTRA;
+    const int tid = threadIdx.x;
+    const Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
+    for (int i = tid; i < bx * by * nz; i += NT) {
+        const int l = i / nz, z = i - l * nz;
+        const int lx = l / by, ly = l - lx * by;
+        int x = x0 + lx - HALO_LO; if (x < 0) x += p.d.nx; else if (x >= p.d.nx) x -= p.d.nx;
+        int y = y0 + ly - HALO_LO; if (y < 0) y += p.d.ny; else if (y >= p.d.ny) y -= p.d.ny;
+        brick[i] = g[((size_t)x * p.d.ny + y) * nz + z];
+    }
+    __syncthreads();
+    const int term = p.dispersion ? 1 : 0; (void)term;
+    for (int a = rg.x + tid; a < rg.y; a += NT) {
+        const Real q = pmeCharge(p, a);
+        const auto pos = p.posq[a];
+        int idx[3]; Real fr[3];
+        gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
+        int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
+        int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
+        Real tx[5], ty[5], tz[5], dx[5], dy[5], dz[5];
+        bspline5<Real>(fr[0], tx, dx); bspline5<Real>(fr[1], ty, dy); bspline5<Real>(fr[2], tz, dz);
+        int zi[5];
+#pragma unroll
+        for (int iz = 0; iz < 5; iz++) { int z = idx[2] + iz; zi[iz] = z >= nz ? z - nz : z; }
+        Real fx = 0, fy = 0, fz = 0;
+        const bool inBrick = rx >= -HALO_LO && rx + 4 < bx - HALO_LO && ry >= -HALO_LO && ry + 4 < by - HALO_LO;
+        if (q != Real(0)) {
+#pragma unroll
+            for (int ix = 0; ix < 5; ix++) {
+#pragma unroll
+                for (int iy = 0; iy < 5; iy++) {
+                    Real sz = 0, sdz = 0;
+                    if (inBrick) {
+                        const Real* line = brick + (size_t)((rx + HALO_LO + ix) * by + (ry + HALO_LO + iy)) * nz;
+#pragma unroll
+                        for (int iz = 0; iz < 5; iz++) { const Real gv = line[zi[iz]]; sz += tz[iz] * gv; sdz += dz[iz] * gv; }
+                    } else {   // drifted further than the halo since the last re-sort: correct but slow path through global memory
+                        int x = idx[0] + ix; if (x >= p.d.nx) x -= p.d.nx;
+                        int y = idx[1] + iy; if (y >= p.d.ny) y -= p.d.ny;
+                        const Real* line = g + ((size_t)x * p.d.ny + y) * nz;
+#pragma unroll
+                        for (int iz = 0; iz < 5; iz++) { const Real gv = line[zi[iz]]; sz += tz[iz] * gv; sdz += dz[iz] * gv; }
+                    }
+                    fx += dx[ix] * ty[iy] * sz; fy += tx[ix] * dy[iy] * sz; fz += tx[ix] * ty[iy] * sdz;
+                }
+            }
+        }
+        const Real nx = p.d.nx, ny = p.d.ny, nzr = p.d.nz;
+        p.fpx[a] = -q * (fx * nx * p.recip[0]);
+        p.fpy[a] = -q * (fx * nx * p.recip[3] + fy * ny * p.recip[4]);
+        p.fpz[a] = -q * (fx * nx * p.recip[6] + fy * ny * p.recip[7] + fz * nzr * p.recip[8]);
+    }
+}
+
 template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s) {
     if (p.natoms <= 0) return;
+    if (p.mix && !p.dispersion && p.colCellsX > 0 && p.colRange != nullptr) {
+        const size_t lds = sizeof(Real) * (size_t)(p.colCellsX + 6) * (p.colCellsY + 6) * p.d.nz;
+        if (lds <= 150 * 1024) {
+            // padding atoms and atoms of empty columns are never visited: the engine clears all force views once per step
+            const int nblocks = p.nsub * (p.d.nx / p.colCellsX) * (p.d.ny / p.colCellsY);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBrick<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_interpolateBrick<Real>), dim3(nblocks), dim3(1024), lds, s, p);
+            return;
+        }
+    }
     const size_t lds = (!p.mix && p.wantEnergy) ? sizeof(double) * p.nsubTotal * (p.nsubTotal + 1) : 0;
     hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
 }

@@ -24,8 +24,24 @@ def test_header_symbols_exported(snb):
 def test_struct_layout_matches_header(snb):
     capi = snb.capi
     # sizes follow from the field lists in include/snb.h (natural alignment)
-    assert ctypes.sizeof(capi.SnbConfig) == 8 * 4 + 4 * 8 + 6 * 4 + 8 + 3 * 4 + 4 + 8 + 3 * 4 + 4 + 8
+    assert ctypes.sizeof(capi.SnbConfig) == 8 * 4 + 4 * 8 + 6 * 4 + 8 + 3 * 4 + 4 + 8 + 3 * 4 + 2 * 4 + 4 + 8
     assert ctypes.sizeof(capi.SnbStats) == 7 * 8 + 6 * 4 + 4 * 8 + 3 * 8 + 8
+
+
+def test_struct_layout_matches_c_compiler(snb, tmp_path):
+    """sizeof/offsetof as gcc sees include/snb.h must equal the ctypes mirror used by the Python binding."""
+    import subprocess
+    capi = snb.capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "snb.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(snb_config), offsetof(snb_config, cutoff), '
+                   'offsetof(snb_config, dgrid), offsetof(snb_config, neighbor_padding), offsetof(snb_config, stream), sizeof(snb_stats), offsetof(snb_stats, sum_direct_ms));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    C, S = capi.SnbConfig, capi.SnbStats
+    want = [ctypes.sizeof(C), C.cutoff.offset, C.dgrid.offset, C.neighbor_padding.offset, C.stream.offset, ctypes.sizeof(S), S.sum_direct_ms.offset]
+    assert got == want, (got, want)
 
 
 def test_legal_grid_sizes(snb):
