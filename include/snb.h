@@ -70,7 +70,7 @@ typedef struct {
     int32_t shard_rank;         /* multi-GPU: this engine owns PME subsets J with J % shard_count == shard_rank */
     int32_t shard_count;        /*            and direct-space work items w with w % shard_count == shard_rank; 1 = unsharded */
     int32_t disable_graph;      /* 1 = enqueue every step eagerly (default 0: forces-only steps replay a captured hipGraph)  */
-    int32_t reserved0;
+    int32_t host_neighbor_build; /* 1 = always build the tile lists on the host (default 0: on the GPU when the box allows it)            */
     void*   stream;             /* hipStream_t to enqueue on, or NULL for an engine-owned stream        */
 } snb_config;
 

@@ -32,7 +32,7 @@ class SnbConfig(ctypes.Structure):
         ("cutoff", ctypes.c_double), ("switch_distance", ctypes.c_double), ("rf_dielectric", ctypes.c_double), ("alpha", ctypes.c_double),
         ("grid", ctypes.c_int32 * 3), ("kmax", ctypes.c_int32 * 3), ("alpha_d", ctypes.c_double), ("dgrid", ctypes.c_int32 * 3),
         ("neighbor_padding", ctypes.c_double), ("rebuild_interval", ctypes.c_int32), ("shard_rank", ctypes.c_int32),
-        ("shard_count", ctypes.c_int32), ("disable_graph", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("stream", ctypes.c_void_p),
+        ("shard_count", ctypes.c_int32), ("disable_graph", ctypes.c_int32), ("host_neighbor_build", ctypes.c_int32), ("stream", ctypes.c_void_p),
     ]
 
 

@@ -303,7 +303,8 @@ template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_e
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     double e0 = 0, e1 = 0; int slice = 0;
     if (k < p.n) {
-        const int2 ij = p.pairs[k];
+        int2 ij = p.pairs[k];
+        ij.x = p.userToSorted[ij.x]; ij.y = p.userToSorted[ij.y];
         const auto par = p.params[k];
         const auto xi = p.posq[ij.x]; const auto xj = p.posq[ij.y];
         Real dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
@@ -340,8 +341,9 @@ template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_e
     const int nS2 = 2 * p.nSlices;
     if (ENERGY) { for (int i = threadIdx.x; i < nS2; i += 256) s_sliceE[i] = 0.0; __syncthreads(); }
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a < p.n) {
-        const int e0 = p.exclStart[a], e1 = p.exclStart[a + 1];
+    const int ua = a < p.n ? p.sortedToUser[a] : -1;
+    if (ua >= 0) {
+        const int e0 = p.exclStart[ua], e1 = p.exclStart[ua + 1];
         if (e1 > e0) {
             const auto xi = p.posq[a];
             const auto sei = p.sigeps[a];
@@ -351,7 +353,7 @@ template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_e
             Real inv[3] = {Real(1) / p.box[0], Real(1) / p.box[4], Real(1) / p.box[8]};
             Real fx = 0, fy = 0, fz = 0;
             for (int e = e0; e < e1; e++) {
-                const int b = p.exclList[e];
+                const int b = p.userToSorted[p.exclList[e]];
                 const auto xj = p.posq[b];
                 Real dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
                 if (p.periodic) wrapDelta<Real>(dx, dy, dz, p.box, inv); else unwrapDelta<Real>(dx, dy, dz, p.imageOffset, a, b);

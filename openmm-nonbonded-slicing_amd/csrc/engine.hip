@@ -9,6 +9,8 @@
 #include "snb_internal.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -186,7 +188,11 @@ public:
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
     DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset, exclStart, exclList;
-    DevBuf<int2> pairs14, pairsExcl, colRange; DevBuf<int4> tileInfo, workItems; int numWorkItems = 0; int colCells[2] = {0, 0}; DevBuf<unsigned> masks;
+    // GPU neighbour build: static user-order data and scratch
+    DevBuf<int> dUSubset, dSubsetStart, dSubsetPaddedStart, dSlotOfSubset, dValsIn, dValsOut, dCounters; DevBuf<Real> dUCharge, dWrapped, dOffsetU; DevBuf<T2> dUSigEps;
+    DevBuf<unsigned char> dPadFlag, dSortTemp; DevBuf<unsigned long long> dKeysIn, dKeysOut; DevBuf<float> dBlockCenter, dBlockHalf;
+    std::vector<int> hSubsetStart, hSubsetPaddedStart, staticBlkSubset; int staticNpad = 0; size_t tileCap = 0; bool staticDirty = true, gpuBuilt = false;
+    DevBuf<int2> pairs14, pairsExcl, colRange; DevBuf<int4> tileInfo, workItems, workItemsPartial; int numWorkItems = 0; int colCells[2] = {0, 0}; DevBuf<unsigned> masks;
     DevBuf<T4> params14, paramsExcl; int n14 = 0, nExcl = 0;
     DevBuf<double> sliceE;
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
@@ -240,7 +246,7 @@ public:
             if (subset[i] != sub[i] || sigma[i] != sg[i] || epsilon[i] != ep[i]) needRebuild = true;   // subsets change the sort; sigma/eps ride along
         }
         charge.assign(q, q + N); sigma.assign(sg, sg + N); epsilon.assign(ep, ep + N); subset.assign(sub, sub + N);
-        haveParticles = true; paramsDirty = true;
+        haveParticles = true; paramsDirty = true; staticDirty = true;
     }
     void setExceptions(int32_t m, const int32_t* pairs, const double* qq, const double* sg, const double* ep, const int32_t* f14) override {
         for (int k = 0; k < m; k++)
@@ -249,7 +255,7 @@ public:
         if (np != excPairs) needRebuild = true;   // the exclusion masks live in the tiles
         excPairs.swap(np); excQQ.assign(qq, qq + m); excSigma.assign(sg, sg + m); excEps.assign(ep, ep + m);
         if (f14) excForce14.assign(f14, f14 + m); else excForce14.assign(m, 0);
-        paramsDirty = true;
+        paramsDirty = true; staticDirty = true;
     }
     void setLambdas(const double* l) override {
         lambdas.assign(l, l + (size_t)S * 2);
@@ -286,8 +292,15 @@ public:
     static inline bool owns(int I, int J) { return ((I + J) & 1) ? (I > J) : (I < J); }
 
     void rebuild() {
-        auto t0 = std::chrono::steady_clock::now();
         dropGraph();   // buffers may move and every kernel argument block changes
+        if (staticDirty) uploadStatic();
+        gpuBuilt = false;
+        if (!cfg.host_neighbor_build && gpuRebuild()) return;
+        hostRebuild();
+    }
+
+    void hostRebuild() {
+        auto t0 = std::chrono::steady_clock::now();
         // 1. host copy of the user positions
         std::vector<double> hp((size_t)N * 3);
         {
@@ -573,59 +586,129 @@ public:
         atomSubset.upload(hAtomSubset, stream); atomGrid.upload(hAtomGrid, stream);
         forceBuf.resize((size_t)6 * Npad);
         fx.p = forceBuf.p; fy.p = fx.p + Npad; fz.p = fy.p + Npad; fpx.p = fz.p + Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
-        buildPairLists();
         HIPCHECK(hipStreamSynchronize(stream));
         needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;
         stats.n_rebuilds++;
         stats.last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
-    // 1-4 and exclusion-correction lists in sorted indices (Q6: ReferenceNonbondedSlicingKernels.cpp:99-112, 129-131)
-    void buildPairLists() {
+    // Static (sort-independent) device data: 1-4 list and exclusion CSR in USER indices (Q6:
+    // ReferenceNonbondedSlicingKernels.cpp:99-112, 129-131), per-atom parameters in user order, the padded subset layout.
+    void uploadStatic() {
         const size_t m = excPairs.size() / 2;
-        std::vector<int2> p14, pex; std::vector<T4> q14, qex;
+        std::vector<int2> p14; std::vector<T4> q14;
         auto sl = [](int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
+        std::vector<int> hStart((size_t)N + 1, 0), hList(2 * m);
         for (size_t k = 0; k < m; k++) {
             const int a = excPairs[2 * k], b = excPairs[2 * k + 1];
-            const int sa = userToSorted[a], sb = userToSorted[b];
-            const int slice = sl(subset[a], subset[b]);
             if (excQQ[k] != 0.0 || excEps[k] != 0.0 || excForce14[k]) {
-                p14.push_back(make_int2(sa, sb));
-                T4 v; v.x = (Real)excSigma[k]; v.y = (Real)(4.0 * excEps[k]); v.z = (Real)(SNB_ONE_4PI_EPS0 * excQQ[k]); v.w = (Real)slice;
+                p14.push_back(make_int2(a, b));
+                T4 v; v.x = (Real)excSigma[k]; v.y = (Real)(4.0 * excEps[k]); v.z = (Real)(SNB_ONE_4PI_EPS0 * excQQ[k]); v.w = (Real)sl(subset[a], subset[b]);
                 q14.push_back(v);
             }
-            pex.push_back(make_int2(sa, sb));
-            T4 v; v.x = (Real)(SNB_ONE_4PI_EPS0 * charge[a] * charge[b]);
-            const double c6a = 8.0 * std::pow(0.5 * sigma[a], 3.0) * 2.0 * std::sqrt(epsilon[a]), c6b = 8.0 * std::pow(0.5 * sigma[b], 3.0) * 2.0 * std::sqrt(epsilon[b]);
-            v.y = (Real)(c6a * c6b); v.z = 0; v.w = (Real)slice;
-            qex.push_back(v);
+            hStart[a + 1]++; hStart[b + 1]++;
         }
-        n14 = (int)p14.size(); nExcl = (int)pex.size();
+        for (int i = 0; i < N; i++) hStart[i + 1] += hStart[i];
+        { std::vector<int> fill(N, 0); for (size_t k = 0; k < m; k++) { const int a = excPairs[2 * k], b = excPairs[2 * k + 1]; hList[hStart[a] + fill[a]++] = b; hList[hStart[b] + fill[b]++] = a; } }
+        n14 = (int)p14.size(); nExcl = (int)m;
         pairs14.upload(p14, stream); params14.upload(q14, stream);
-        // exclusion CSR over sorted atoms (each pair listed from both ends)
-        std::vector<int> hStart((size_t)Npad + 1, 0), hList(2 * pex.size());
-        for (auto& pr : pex) { hStart[pr.x + 1]++; hStart[pr.y + 1]++; }
-        for (int i = 0; i < Npad; i++) hStart[i + 1] += hStart[i];
-        { std::vector<int> fill(Npad, 0); for (auto& pr : pex) { hList[hStart[pr.x] + fill[pr.x]++] = pr.y; hList[hStart[pr.y] + fill[pr.y]++] = pr.x; } }
         exclStart.upload(hStart, stream); exclList.upload(hList, stream);
         stats.n_14 = n14; stats.n_exclusions = nExcl;
+        // user-order parameters
+        std::vector<Real> hq(N); std::vector<T2> hse(N);
+        for (int i = 0; i < N; i++) { hq[i] = (Real)charge[i]; hse[i].x = (Real)(0.5 * sigma[i]); hse[i].y = (Real)(2.0 * std::sqrt(epsilon[i])); }
+        dUCharge.upload(hq, stream); dUSigEps.upload(hse, stream); dUSubset.upload(std::vector<int>(subset.begin(), subset.end()), stream);
+        // padded subset layout (depends on subset populations only)
+        std::vector<int> cnt(nsub, 0);
+        for (int i = 0; i < N; i++) cnt[subset[i]]++;
+        hSubsetStart.assign(nsub + 1, 0); hSubsetPaddedStart.assign(nsub + 1, 0);
+        for (int k = 0; k < nsub; k++) { hSubsetStart[k + 1] = hSubsetStart[k] + cnt[k]; hSubsetPaddedStart[k + 1] = hSubsetPaddedStart[k] + ((cnt[k] + 31) / 32) * 32; }
+        staticNpad = hSubsetPaddedStart[nsub];
+        std::vector<unsigned char> pad(std::max(staticNpad, 1), 0);
+        staticBlkSubset.clear();
+        for (int k = 0; k < nsub; k++) {
+            for (int x = hSubsetPaddedStart[k] + cnt[k]; x < hSubsetPaddedStart[k + 1]; x++) pad[x] = 1;
+            for (int bb = hSubsetPaddedStart[k] / 32; bb < hSubsetPaddedStart[k + 1] / 32; bb++) staticBlkSubset.push_back(k);
+        }
+        dSubsetStart.upload(hSubsetStart, stream); dSubsetPaddedStart.upload(hSubsetPaddedStart, stream); dPadFlag.upload(pad, stream);
+        std::vector<int> slot(nsub, -1);
+        if (cfg.shard_count == 1) std::iota(slot.begin(), slot.end(), 0); else for (size_t g = 0; g < ownedSubsets.size(); g++) slot[ownedSubsets[g]] = (int)g;
+        dSlotOfSubset.upload(slot, stream);
+        HIPCHECK(hipStreamSynchronize(stream));
+        staticDirty = false;
     }
 
-    // parameters changed but the sort is still valid: refresh the sorted parameter arrays in place
-    void refreshParameters() {
-        dropGraph();
-        std::vector<T2> hSigeps(Npad); std::vector<Real> hq(Npad, Real(0));
-        for (int s = 0; s < Npad; s++) {
-            int u = sortedToUser[s];
-            if (u >= 0) { hSigeps[s].x = (Real)(0.5 * sigma[u]); hSigeps[s].y = (Real)(2.0 * std::sqrt(epsilon[u])); hq[s] = (Real)charge[u]; }
-            else { hSigeps[s].x = 0; hSigeps[s].y = 0; }
+    // ------------------------------------------------------------------------------------------
+    // GPU neighbour build (neighbor.hip): rectangular periodic boxes with cutoff.  Returns false when the
+    // host builder must take over (per-pair-wrap regime, gather-capacity overflow).
+    // ------------------------------------------------------------------------------------------
+    bool gpuRebuild() {
+        if (!isPeriodic() || cfg.method == SNB_NoCutoff || N < 64) return false;
+        if (!(box[3] == 0 && box[6] == 0 && box[7] == 0)) return false;
+        const double R = cfg.cutoff + cfg.neighbor_padding;
+        const double volume = box[0] * box[4] * box[8];
+        const double aTarget = std::cbrt(32.0 * volume / std::max(N, 1));
+        for (int d = 0; d < 3; d++) if (!(4.0 * aTarget + 2 * R < box[4 * d])) return false;   // tile-image scheme needs extent + 2R < L (checked exactly on the GPU too)
+        auto t0 = std::chrono::steady_clock::now();
+        int ncx = std::max(1, std::min(2048, (int)std::lround(box[0] / aTarget)));
+        int ncy = std::max(1, std::min(2048, (int)std::lround(box[4] / aTarget)));
+        colCells[0] = colCells[1] = 0;
+        if (isPme() && nGrids > 0) {
+            auto pick = [&](int n, double L) {
+                int best = 0; double bestErr = 1e300;
+                for (int d = 5; d <= 16 && d <= n; d++) if (n % d == 0) { double er = std::fabs(d * L / n - aTarget); if (er < bestErr) { bestErr = er; best = d; } }
+                return best;
+            };
+            const int px = pick(pme.d.nx, box[0]), py = pick(pme.d.ny, box[4]);
+            if (px > 0 && py > 0 && sizeof(double) * (size_t)px * py * pme.d.nz <= 60 * 1024) { colCells[0] = px; colCells[1] = py; ncx = pme.d.nx / px; ncy = pme.d.ny / py; }
         }
-        sigeps.upload(hSigeps, stream);
-        // charges live in posq.w: strided copy
-        HIPCHECK(hipMemcpy2DAsync(reinterpret_cast<char*>(posq.p) + 3 * sizeof(Real), sizeof(T4), hq.data(), sizeof(Real), sizeof(Real), Npad, hipMemcpyHostToDevice, stream));
-        buildPairLists();
-        HIPCHECK(hipStreamSynchronize(stream));
-        paramsDirty = false;
+        Npad = staticNpad; numBlocks = Npad / 32;
+        // outputs / scratch
+        posq.resize(Npad); sigeps.resize(Npad); imageOffset.resize((size_t)3 * Npad);
+        dSortedToUser.resize(Npad); dUserToSorted.resize(N); atomSubset.resize(Npad); atomGrid.resize(Npad);
+        colRange.resize((size_t)nsub * ncx * ncy);
+        forceBuf.resize((size_t)6 * Npad);
+        fx.p = forceBuf.p; fy.p = fx.p + Npad; fz.p = fy.p + Npad; fpx.p = fz.p + Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
+        blockSubset.upload(staticBlkSubset, stream);
+        dWrapped.resize((size_t)3 * N); dOffsetU.resize((size_t)3 * N); dKeysIn.resize(N); dKeysOut.resize(N); dValsIn.resize(N); dValsOut.resize(N);
+        dBlockCenter.resize((size_t)3 * numBlocks); dBlockHalf.resize((size_t)3 * numBlocks); dCounters.resize(8);
+        const size_t tempBytes = nbSortTempBytes<Real>(N);
+        dSortTemp.resize(tempBytes);
+        if (tileCap < (size_t)numBlocks * 40) tileCap = (size_t)numBlocks * 40;
+        for (int attempt = 0; attempt < 3; attempt++) {
+            tileJ.resize(tileCap * 32); tileInfo.resize(tileCap); masks.resize(tileCap * 32); workItems.resize(tileCap / 4 + 2 * numBlocks + 16); workItemsPartial.resize(tileCap / 4 + 2 * numBlocks + 16);
+            NbParams<Real> p;
+            std::memset(&p, 0, sizeof(p));
+            p.nAtoms = N; p.nPadded = Npad; p.nBlocks = numBlocks; p.nSubsets = nsub; p.ncx = ncx; p.ncy = ncy;
+            p.subsetBits = 1; while ((1 << p.subsetBits) < nsub) p.subsetBits++;
+            p.boxd[0] = box[0]; p.boxd[1] = box[4]; p.boxd[2] = box[8]; p.listCutoff = (float)R;
+            p.uSubset = dUSubset.p; p.uCharge = dUCharge.p; p.uSigEps = dUSigEps.p; p.uExclStart = exclStart.p; p.uExclList = exclList.p;
+            p.subsetStart = dSubsetStart.p; p.subsetPaddedStart = dSubsetPaddedStart.p; p.slotOfSubset = dSlotOfSubset.p; p.padFlag = dPadFlag.p; p.blockSubset = blockSubset.p;
+            p.wrapped = dWrapped.p; p.offsetU = dOffsetU.p; p.keysIn = dKeysIn.p; p.keysOut = dKeysOut.p; p.valsIn = dValsIn.p; p.valsOut = dValsOut.p;
+            p.blockCenter = dBlockCenter.p; p.blockHalf = dBlockHalf.p;
+            p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
+            p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p;
+            p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.workItems = workItems.p; p.workItemsPartial = workItemsPartial.p; p.counters = dCounters.p;
+            p.tileCapacity = (int)tileCap; p.workCapacity = (int)(tileCap / 4 + 2 * numBlocks + 16); p.maskCapacity = (int)tileCap;
+            launchNeighborBuild<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream);
+            int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+            HIPCHECK(hipStreamSynchronize(stream));
+            if (h[3] == 0) {
+                if (h[4] > 0) HIPCHECK(hipMemcpyAsync(workItems.p + h[1], workItemsPartial.p, sizeof(int4) * h[4], hipMemcpyDeviceToDevice, stream));
+                numTiles = h[0]; numWorkItems = h[1] + h[4]; numMaskTiles = h[2]; wrapMode = false;
+                shardTiles = numTiles / cfg.shard_count;
+                gpuBuilt = true;
+                needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;
+                stats.n_rebuilds++;
+                stats.last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                return true;
+            }
+            if (getenv("SNB_VERBOSE")) fprintf(stderr, "[snb] gpu neighbour build attempt %d: tiles %d work %d masks %d overflow %d (cap %zu)\n", attempt, h[0], h[1], h[2], h[3], tileCap);
+            if ((size_t)h[0] > tileCap || (size_t)h[2] > tileCap) { tileCap = (size_t)std::max(h[0], h[2]) * 5 / 4 + 1024; continue; }   // capacity: grow and retry
+            return false;   // a block gathered more than its LDS list holds, or a block is too extended for tile images: host path
+        }
+        return false;
     }
 
     // ------------------------------------------------------------------------------------------
@@ -656,8 +739,7 @@ public:
         }
         if (cfg.method == SNB_Ewald && includeRecip) { err = "classic Ewald reciprocal sum is not implemented in the HIP engine yet (use PME)"; throw (int)SNB_ERR_UNSUPPORTED; }
         if (dLambdas.p == nullptr) setLambdas(lambdas.data());
-        if (needRebuild || cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval || cfg.neighbor_padding <= 0) rebuild();
-        else if (paramsDirty) refreshParameters();
+        if (needRebuild || paramsDirty || cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval || cfg.neighbor_padding <= 0) rebuild();
         stepsSinceRebuild++;
         const bool energy = includeEnergy != 0;
         lastRecip = includeRecip && isPme();
@@ -740,7 +822,7 @@ public:
             q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.sliceE = sliceE.p; q.lambdas = dLambdas.p;
             const bool exPeriodic = (cfg.method == SNB_NoCutoff || cfg.method == SNB_CutoffNonPeriodic) ? false : cfg.exceptions_periodic != 0;
             q.periodic = exPeriodic ? 1 : 0; q.imageOffset = imageOffset.p;
-            q.sigeps = sigeps.p; q.blockSubset = blockSubset.p; q.exclStart = exclStart.p; q.exclList = exclList.p; q.nSlices = S;
+            q.sigeps = sigeps.p; q.blockSubset = blockSubset.p; q.exclStart = exclStart.p; q.exclList = exclList.p; q.nSlices = S; q.sortedToUser = dSortedToUser.p; q.userToSorted = dUserToSorted.p;
             for (int i = 0; i < 9; i++) q.box[i] = (Real)box[i];
             q.alpha = (Real)cfg.alpha; q.alphaD = (Real)cfg.alpha_d; q.ljpme = cfg.method == SNB_LJPME;
             q.pairs = pairs14.p; q.params = params14.p; q.n = n14;

@@ -58,10 +58,11 @@ template <typename Real> struct PairListParams {  // 1-4 exceptions: one thread 
     const typename Vec<Real>::T4* posq;
     const typename Vec<Real>::T2* sigeps;
     const int* blockSubset;
-    const int* exclStart;     // [Npad+1] CSR over sorted atoms (exclusion corrections: n = Npad)
-    const int* exclList;      // sorted partner indices
+    const int* exclStart;     // [N+1] exclusion CSR in USER order (static across re-sorts)
+    const int* exclList;      // user partner indices
+    const int* sortedToUser; const int* userToSorted;
     int nSlices;
-    const int2* pairs;        // sorted indices
+    const int2* pairs;        // 1-4 pairs, USER indices (mapped through userToSorted in the kernel)
     const typename Vec<Real>::T4* params;   // 1-4: (sigma, 4 eps, k*qq, slice bits) ; exclusion: (k*qi*qj, c6i*c6j, -, slice bits)
     int n;
     Real* fx; Real* fy; Real* fz;
@@ -105,6 +106,29 @@ template <typename Real> struct PmeParams {
     int colCellsX, colCellsY;  // brick spreading: sort-column size in grid cells (0 = use the atomic fallback)
     const int2* colRange;      // [nsubTotal][ncx*ncy] sorted-atom range of every (subset, xy column)
 };
+
+// GPU neighbour build (neighbor.hip)
+template <typename Real> struct NbParams {
+    int nAtoms, nPadded, nBlocks, nSubsets, subsetBits, ncx, ncy;
+    double boxd[3];
+    float listCutoff;
+    // static, user order
+    const int* uSubset; const Real* uCharge; const typename Vec<Real>::T2* uSigEps;
+    const int* uExclStart; const int* uExclList;
+    const int* subsetStart; const int* subsetPaddedStart; const int* slotOfSubset; const unsigned char* padFlag;
+    const int* blockSubset;
+    // scratch
+    Real* wrapped; Real* offsetU; unsigned long long* keysIn; unsigned long long* keysOut; int* valsIn; int* valsOut;
+    float* blockCenter; float* blockHalf;
+    // outputs
+    int* sortedToUser; int* userToSorted; typename Vec<Real>::T4* posq; typename Vec<Real>::T2* sigeps; Real* imageOffset;
+    int* atomSubset; int* atomGrid; int2* colRange;
+    int* tileJ; int4* tileInfo; unsigned* masks; int4* workItems; int4* workItemsPartial;
+    int* counters;   // [0] tiles, [1] full work items, [2] masks, [3] overflow events, [4] partial work items
+    int tileCapacity, workCapacity, maskCapacity;
+};
+template <typename Real> size_t nbSortTempBytes(int n);
+template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, const void* userPos, int isDouble, int stride4, void* sortTemp, size_t sortTempBytes, hipStream_t s);
 
 // ---- launchers implemented in the .hip translation units -------------------------------------
 template <typename Real> void launchDirect(const DirectParams<Real>& p, int methodClass, bool wrap, bool energy, hipStream_t s);
