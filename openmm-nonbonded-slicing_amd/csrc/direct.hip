@@ -15,6 +15,7 @@
 // per-pair slice arithmetic at all (the reference computes the slice index and loads LAMBDA[slice] per pair).
 #include "snb_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace snb {
 
@@ -163,6 +164,67 @@ __device__ __forceinline__ void tileSteps(const DirectParams<Real>& p, const typ
         }
 }
 
+// ---- packed single-precision variant of the 16 pair steps ---------------------------------------------------------
+// On gfx950 v_pk_mul_f32 / v_pk_add_f32 issue at the cost of their scalar forms (measured, tools/ubench_valu.hip), so a
+// lane that works on TWO j-slots at once halves the issue cost of every plain multiply/add (FMAs and transcendentals
+// cost the same either way).  8 steps; at step s lane c meets slots (c-2s) [component .x] and (c-2s-1) [component .y];
+// each component's j-force accumulator follows its slot with a two-lane DPP rotation per step.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ inline float rowRor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true)); }
+
+template <int MC, bool MASKED>
+__device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float4* rdPos, const float2* rdSe, const float4 pi, const float2 sei,
+                                                const float qiS, const float epsiS, const unsigned maskWord, const int c,
+                                                v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz) {
+    v2f ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};      // j-force accumulators: .x follows slot c-2s, .y slot c-2s-1
+    const v2f pix = {pi.x, pi.x}, piy = {pi.y, pi.y}, piz = {pi.z, pi.z};
+#pragma unroll 2
+    for (int s = 0; s < 8; s++) {
+        const float4 xa = rdPos[-2 * s], xb = rdPos[-2 * s - 1];
+        const float2 sa = rdSe[-2 * s], sb = rdSe[-2 * s - 1];
+        const v2f dx = pix - (v2f){xa.x, xb.x}, dy = piy - (v2f){xa.y, xb.y}, dz = piz - (v2f){xa.z, xb.z};
+        const v2f r2 = dx * dx + dy * dy + dz * dz;
+        const v2f invR = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+        // Lennard-Jones
+        const v2f sig = (v2f){sei.x, sei.x} + (v2f){sa.x, sb.x};
+        v2f s2 = sig * invR; s2 = s2 * s2;
+        const v2f s6 = s2 * s2 * s2;
+        const v2f es6 = ((v2f){epsiS, epsiS} * (v2f){sa.y, sb.y}) * s6;
+        v2f f = es6 * (s6 * 12.0f - 6.0f);
+        // Coulomb
+        const v2f qq = (v2f){qiS, qiS} * (v2f){xa.w, xb.w};
+        if (MC == MC_EWALD) {
+            const v2f r = r2 * invR;
+            const v2f ar = r * p.alpha;
+            const v2f e2 = r2 * (-p.alpha2l2e);
+            const v2f ex = {__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
+            const v2f den = ar * 0.3275911f + 1.0f;
+            const v2f tt = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            v2f poly = tt * 1.061405429f + (-1.453152027f);
+            poly = poly * tt + 1.421413741f;
+            poly = poly * tt + (-0.284496736f);
+            poly = poly * tt + 0.254829592f;
+            const v2f erfcv = poly * tt * ex;
+            f = f + (qq * invR) * (erfcv + (ar * ex) * 1.1283791670955126f);
+        } else if (MC == MC_RF) {
+            f = f + qq * (invR - r2 * (2.0f * p.krf));
+        } else {
+            f = f + qq * invR;
+        }
+        f = f * (invR * invR);
+        bool inA = MC == MC_NOCUTOFF ? true : (r2.x < p.cutoff2), inB = MC == MC_NOCUTOFF ? true : (r2.y < p.cutoff2);
+        if (MASKED) { inA = inA && !((maskWord >> ((c - 2 * s) & 15)) & 1u); inB = inB && !((maskWord >> ((c - 2 * s - 1) & 15)) & 1u); }
+        f.x = inA ? f.x : 0.0f; f.y = inB ? f.y : 0.0f;
+        const v2f gx = f * dx, gy = f * dy, gz = f * dz;
+        fix = fix + gx; fiy = fiy + gy; fiz = fiz + gz;
+        ax = (v2f){rowRor2(ax.x), rowRor2(ax.y)} - gx;
+        ay = (v2f){rowRor2(ay.x), rowRor2(ay.y)} - gy;
+        az = (v2f){rowRor2(az.x), rowRor2(az.y)} - gz;
+    }
+    // bring every slot home: component .x sits two lanes ahead, component .y one lane ahead
+    fjx = rowRor2(ax.x) + rowRor1(ax.y); fjy = rowRor2(ay.x) + rowRor1(ay.y); fjz = rowRor2(az.x) + rowRor1(az.y);
+}
+
 // ---- the tile kernel ----------------------------------------------------------------------------
 // Work item = (i-block, run of <= 8 tiles).  Lane layout: 4 DPP rows of 16 lanes; row r works on the 16x16 sub-tile
 // (i-half r&1, j-half r>>1).  At step s lane c of a row meets j-slot (c-s)&15 of its j-half; the j-force accumulator
@@ -170,7 +232,7 @@ __device__ __forceinline__ void tileSteps(const DirectParams<Real>& p, const typ
 // so after 16 steps lane c holds the force on j-slot c.  j-atom data is read from LDS (staged once per tile, each
 // 16-atom half stored twice so the rotated index c+16-s needs no wrap).
 template <typename Real, int MC, bool WRAP, bool ENERGY>
-__global__ __launch_bounds__(256, 6) void k_direct(const DirectParams<Real> p) {
+__global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
     using T4 = typename Vec<Real>::T4;
     using T2 = typename Vec<Real>::T2;
     __shared__ T4 s_pos[4][64];
@@ -245,16 +307,28 @@ __global__ __launch_bounds__(256, 6) void k_direct(const DirectParams<Real> p) {
         const Real epsiS = sei.y * lamL;
         Real fjx = 0, fjy = 0, fjz = 0;
 
-        if (p.useSwitch && MC != MC_LJPME && MC != MC_NOCUTOFF) {
-            if (hasMask) tileSteps<Real, MC, WRAP, ENERGY, true, true>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-            else tileSteps<Real, MC, WRAP, ENERGY, false, true>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-        } else {
-            if (hasMask) tileSteps<Real, MC, WRAP, ENERGY, true, false>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-            else tileSteps<Real, MC, WRAP, ENERGY, false, false>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+        bool donePacked = false;
+        if constexpr (std::is_same<Real, float>::value && !ENERGY && !WRAP && MC != MC_LJPME) {
+            if (!p.useSwitch) {
+                v2f pfx = {0.f, 0.f}, pfy = {0.f, 0.f}, pfz = {0.f, 0.f};
+                if (hasMask) tileStepsPacked<MC, true>(p, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
+                else tileStepsPacked<MC, false>(p, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
+                fix += pfx.x + pfx.y; fiy += pfy.x + pfy.y; fiz += pfz.x + pfz.y;
+                donePacked = true;
+            }
         }
-        // rotate-then-add leaves lane c holding slot c+1: one more rotation brings every slot home; then add the two
-        // i-halves (rows r and r^1) and flush
-        fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
+        if (!donePacked) {
+        if (p.useSwitch && MC != MC_LJPME && MC != MC_NOCUTOFF) {
+                if (hasMask) tileSteps<Real, MC, WRAP, ENERGY, true, true>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+                else tileSteps<Real, MC, WRAP, ENERGY, false, true>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+            } else {
+                if (hasMask) tileSteps<Real, MC, WRAP, ENERGY, true, false>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+                else tileSteps<Real, MC, WRAP, ENERGY, false, false>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+            }
+            // rotate-then-add leaves lane c holding slot c+1: one more rotation brings every slot home
+            fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
+        }
+        // add the two i-halves (rows r and r^1) and flush
         fjx += __shfl_xor(fjx, 16, 64); fjy += __shfl_xor(fjy, 16, 64); fjz += __shfl_xor(fjz, 16, 64);
         if ((row & 1) == 0 && curCode != -1) {            // lanes 0-15 (j-half 0) and 32-47 (j-half 1): entry `lane` == j-slot
             const int jidx = curCode & SNB_JIDX_MASK;
