@@ -16,6 +16,7 @@
 //    evaluation and the convolution run in one kernel without leaving LDS: 5 grid passes instead of 8;
 //  * the real axis (z) is transformed with the imaginary half implied, writing nz/2+1 complex outputs.
 #include "snb_internal.h"
+#include <cstdlib>
 
 namespace snb {
 
@@ -282,9 +283,100 @@ __device__ inline void fftStage(const Cx<Real>* a, Cx<Real>* b, int n, int len, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Two-pass line FFT, n = R1 * R2 with whole R1- and R2-point FFTs held in registers (R <= 16).  Per element it needs
+// ~6x fewer instructions than the stage-by-stage Stockham above (one LDS round trip, indices computed once per
+// R-point transform, compile-time inner twiddles), which matters because every FFT kernel here is VALU-issue-bound.
+//   pass 1 (in place): for each n2 < R2:  y[k1][n2] = W_n^{n2 k1} * sum_{n1} x[n1*R2 + n2] W_R1^{n1 k1}
+//   pass 2 (a -> b):   for each k1 < R1:  X[k1 + R1*k2] = sum_{n2} y[k1][n2] W_R2^{n2 k2}
+// ---------------------------------------------------------------------------------------------------
+template <int N> struct FirstFactor { static constexpr int value = (N % 4 == 0 && N > 4) ? 4 : (N % 2 == 0 && N > 2) ? 2 : (N % 3 == 0 && N > 3) ? 3 : (N % 5 == 0 && N > 5) ? 5 : N; };
+
+template <typename Real, int N> __device__ __forceinline__ void fftReg(Cx<Real>* v, int sign) {
+    constexpr int A = FirstFactor<N>::value;
+    if constexpr (A == N) {
+        butterflyP<Real, N>(v, sign);
+    } else {
+        constexpr int B = N / A;
+        Cx<Real> out[N];
+#pragma unroll
+        for (int n2 = 0; n2 < B; n2++) {
+            Cx<Real> t[A];
+#pragma unroll
+            for (int n1 = 0; n1 < A; n1++) t[n1] = v[n1 * B + n2];
+            butterflyP<Real, A>(t, sign);
+#pragma unroll
+            for (int k1 = 0; k1 < A; k1++) {
+                Cx<Real> o = t[k1];
+                if (k1 > 0 && n2 > 0) {
+                    const double ang = -2.0 * SNB_PI * (double)(n2 * k1) / N;
+                    const Real c = (Real)__builtin_cos(ang), sf = (Real)__builtin_sin(ang);
+                    const Cx<Real> w = {c, sign < 0 ? sf : -sf};
+                    o = cmul(o, w);
+                }
+                v[k1 * B + n2] = o;
+            }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < A; k1++) {
+            fftReg<Real, B>(&v[k1 * B], sign);
+#pragma unroll
+            for (int k2 = 0; k2 < B; k2++) out[k1 + A * k2] = v[k1 * B + k2];
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = out[k];
+    }
+}
+
+template <typename Real, int R1>
+__device__ __forceinline__ void fftPass1(Cx<Real>* a, int r2, int sign, const Cx<Real>* tw, int nb, int BS, int tid, int nthreads) {
+    const int tasks = nb * r2;
+    const float invNb = 1.0f / nb;
+    for (int t = tid; t < tasks; t += nthreads) {
+        const int n2 = (int)((t + 0.5f) * invNb);
+        const int b = t - n2 * nb;
+        Cx<Real> v[R1];
+#pragma unroll
+        for (int n1 = 0; n1 < R1; n1++) v[n1] = a[(n1 * r2 + n2) * BS + b];
+        fftReg<Real, R1>(v, sign);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; k1++) {
+            Cx<Real> o = v[k1];
+            if (k1 > 0 && n2 > 0) { Cx<Real> w = tw[n2 * k1]; if (sign > 0) w.y = -w.y; o = cmul(o, w); }
+            a[(k1 * r2 + n2) * BS + b] = o;
+        }
+    }
+}
+template <typename Real, int R2>
+__device__ __forceinline__ void fftPass2(const Cx<Real>* a, Cx<Real>* bOut, int r1, int sign, int nb, int BS, int tid, int nthreads) {
+    const int tasks = nb * r1;
+    const float invNb = 1.0f / nb;
+    for (int t = tid; t < tasks; t += nthreads) {
+        const int k1 = (int)((t + 0.5f) * invNb);
+        const int b = t - k1 * nb;
+        Cx<Real> v[R2];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; n2++) v[n2] = a[(k1 * R2 + n2) * BS + b];
+        fftReg<Real, R2>(v, sign);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) bOut[(k1 + r1 * k2) * BS + b] = v[k2];
+    }
+}
+
+// The kernels are instantiated per (R1, R2) pair (inlining every radix into one runtime switch made them allocate 248 VGPRs);
+// sizes outside this list use the staged Stockham path (R1 = 0).
+#define SNB_FFT_PAIRS(X) X(6, 7) X(6, 9) X(8, 8) X(8, 10) X(9, 10) X(8, 12) X(10, 10) X(9, 12) X(8, 15) X(8, 16) X(12, 12) X(10, 16) X(12, 15) X(12, 16) X(15, 16) X(16, 16)
+
 // Runs all stages; returns the buffer holding the result.  Caller must __syncthreads() before reading it.
-template <typename Real>
+template <typename Real, int R1 = 0, int R2 = 0>
 __device__ inline Cx<Real>* fftLines(Cx<Real>* a, Cx<Real>* b, int n, const int* factors, int nf, int sign, const Cx<Real>* tw, int nb, int BS, int tid, int nthreads) {
+    if constexpr (R1 > 0) {
+        __syncthreads();
+        fftPass1<Real, R1>(a, R2, sign, tw, nb, BS, tid, nthreads);
+        __syncthreads();
+        fftPass2<Real, R2>(a, b, R1, sign, nb, BS, tid, nthreads);
+        return b;
+    }
     int len = n, s = 1;
     for (int f = 0; f < nf; f++) {
         const int P = factors[f];
@@ -305,7 +397,7 @@ __device__ inline Cx<Real>* fftLines(Cx<Real>* a, Cx<Real>* b, int n, const int*
 extern __shared__ __align__(16) unsigned char s_dyn[];
 
 // ---- z axis: real <-> half-complex.  One work-group transforms NL contiguous lines. ----------------
-template <typename Real, bool FORWARD> __global__ __launch_bounds__(256) void k_fftZ(const PmeParams<Real> p, int NL) {
+template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bounds__(256) void k_fftZ(const PmeParams<Real> p, int NL) {
     const int nz = p.d.nz, nzc = p.d.nzc;
     const int BS = NL + 1;   // padded batch stride (bank spread for the transposing LDS accesses)
     Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
@@ -321,7 +413,7 @@ template <typename Real, bool FORWARD> __global__ __launch_bounds__(256) void k_
             const int l = it / nz, k = it - l * nz;
             A[k * BS + l] = {p.gridReal[(line0 + l) * nz + k], Real(0)};
         }
-        Cx<Real>* R = fftLines<Real>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, 256);
+        Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, 256);
         __syncthreads();
         Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.gridCplx);
         for (int it = tid; it < nb * nzc; it += 256) {
@@ -336,7 +428,7 @@ template <typename Real, bool FORWARD> __global__ __launch_bounds__(256) void k_
             A[k * BS + l] = v;
             if (k > 0 && nz - k >= nzc) A[(nz - k) * BS + l] = {v.x, -v.y};   // Hermitian half
         }
-        Cx<Real>* R = fftLines<Real>(A, B, nz, p.d.fz, p.d.nfz, +1, tw, nb, BS, tid, 256);
+        Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, +1, tw, nb, BS, tid, 256);
         __syncthreads();
         for (int it = tid; it < nb * nz; it += 256) {
             const int l = it / nz, k = it - l * nz;
@@ -347,7 +439,7 @@ template <typename Real, bool FORWARD> __global__ __launch_bounds__(256) void k_
 
 // ---- strided axis (y): tiles of NB adjacent lines (adjacent = consecutive complex elements in memory) ----
 // address(a, b, k) = a*strideA + b + k*strideK, b in [0, nbTotal)
-template <typename Real> __global__ __launch_bounds__(256) void k_fftStrided(const PmeParams<Real> p, int n, size_t strideA, int nbTotal, size_t strideK,
+template <typename Real, int R1, int R2> __global__ __launch_bounds__(256) void k_fftStrided(const PmeParams<Real> p, int n, size_t strideA, int nbTotal, size_t strideK,
                                                                           int NB, int tilesPerA, int sign, int axis) {
     const int a = blockIdx.x / tilesPerA, tile = blockIdx.x - a * tilesPerA;
     const int b0 = tile * NB;
@@ -362,7 +454,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_fftStrided(con
         const int k = it / nb, b = it - k * nb;
         A[k * NB + b] = g[(size_t)k * strideK + b];
     }
-    Cx<Real>* R = fftLines<Real>(A, B, n, axis == 1 ? p.d.fy : p.d.fx, axis == 1 ? p.d.nfy : p.d.nfx, sign, tw, nb, NB, tid, 256);
+    Cx<Real>* R = fftLines<Real, R1, R2>(A, B, n, axis == 1 ? p.d.fy : p.d.fx, axis == 1 ? p.d.nfy : p.d.nfx, sign, tw, nb, NB, tid, 256);
     __syncthreads();
     for (int it = tid; it < n * nb; it += 256) {
         const int k = it / nb, b = it - k * nb;
@@ -400,7 +492,7 @@ template <typename Real> __device__ inline Real recipTerm(const PmeParams<Real>&
 
 // ---- fused x-axis kernel: forward FFT_x, sliced energy, lambda-mixed convolution, inverse FFT_x ---------
 // One work-group owns NB adjacent (ky,kz) columns for ALL held subsets: batch index = sub*NB + col.
-template <typename Real> __global__ __launch_bounds__(512) void k_convolveX(const PmeParams<Real> p, int NB, int nCols) {
+template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void k_convolveX(const PmeParams<Real> p, int NB, int nCols) {
     constexpr int NT = 512;
     const int nx = p.d.nx, nsub = p.nsub;
     const int BS = nsub * NB;
@@ -424,7 +516,7 @@ template <typename Real> __global__ __launch_bounds__(512) void k_convolveX(cons
         A[k * BS + bb] = v;
     }
     for (int k = tid; k < nx; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twx)[k];
-    Cx<Real>* S = fftLines<Real>(A, B, nx, p.d.fx, p.d.nfx, -1, tw, BS, BS, tid, NT);
+    Cx<Real>* S = fftLines<Real, R1, R2>(A, B, nx, p.d.fx, p.d.nfx, -1, tw, BS, BS, tid, NT);
     Cx<Real>* O = (S == A) ? B : A;
     __syncthreads();
     // eterm per (kx, col)
@@ -490,13 +582,37 @@ template <typename Real> __global__ __launch_bounds__(512) void k_convolveX(cons
             O[it] = {acc.x * e, acc.y * e};
         }
     }
-    Cx<Real>* R = fftLines<Real>(O, S, nx, p.d.fx, p.d.nfx, +1, tw, BS, BS, tid, NT);
+    Cx<Real>* R = fftLines<Real, R1, R2>(O, S, nx, p.d.fx, p.d.nfx, +1, tw, BS, BS, tid, NT);
     __syncthreads();
     for (int it = tid; it < nx * BS; it += NT) {
         const int k = it / BS, bb = it - k * BS;
         const int sub = bb / NB, col = bb - sub * NB;
         if (col < nbc) g[sub * strideSub + (size_t)k * strideK + c0 + col] = R[it];
     }
+}
+
+// ---- launch dispatch over the instantiated (R1, R2) pairs ------------------------------------------
+template <typename Real, bool FWD> static void launchFftZ(int r1, int r2, dim3 grid, size_t lds, hipStream_t s, const PmeParams<Real>& p, int NL) {
+#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, FWD, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((k_fftZ<Real, FWD, A, B>), grid, dim3(256), lds, s, p, NL); return; }
+    SNB_FFT_PAIRS(X)
+#undef X
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, FWD, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_fftZ<Real, FWD, 0, 0>), grid, dim3(256), lds, s, p, NL);
+}
+template <typename Real> static void launchFftStrided(int r1, int r2, dim3 grid, size_t lds, hipStream_t s, const PmeParams<Real>& p, int n, size_t strideA, int nbTotal, size_t strideK, int NB,
+                                                      int tilesPerA, int sign, int axis) {
+#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((k_fftStrided<Real, A, B>), grid, dim3(256), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis); return; }
+    SNB_FFT_PAIRS(X)
+#undef X
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_fftStrided<Real, 0, 0>), grid, dim3(256), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis);
+}
+template <typename Real> static void launchConvolveX(int r1, int r2, dim3 grid, size_t lds, hipStream_t s, const PmeParams<Real>& p, int NB, int nCols) {
+#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((k_convolveX<Real, A, B>), grid, dim3(512), lds, s, p, NB, nCols); return; }
+    SNB_FFT_PAIRS(X)
+#undef X
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_convolveX<Real, 0, 0>), grid, dim3(512), lds, s, p, NB, nCols);
 }
 
 static size_t ldsBudget() { return 96 * 1024; }
@@ -517,17 +633,14 @@ template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipS
         if (NL < 2) NL = 2;
         const size_t lds = (size_t)2 * nz * (NL + 1) * sizeof(Cx<Real>) + (size_t)nz * sizeof(Cx<Real>);
         const size_t nlines = (size_t)p.nsub * nx * ny;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_fftZ<Real, true>), dim3((unsigned)((nlines + NL - 1) / NL)), dim3(256), lds, s, p, NL);
+        launchFftZ<Real, true>(p.d.rz1, p.d.rz2, dim3((unsigned)((nlines + NL - 1) / NL)), lds, s, p, NL);
     }
     // y
     {
         const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), 16);
         const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>) + (size_t)ny * sizeof(Cx<Real>);
         const int tilesPerA = (nzc + NB - 1) / NB;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_fftStrided<Real>), dim3((unsigned)(p.nsub * nx * tilesPerA)), dim3(256), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB,
-                           tilesPerA, -1, 1);
+        launchFftStrided<Real>(p.d.ry1, p.d.ry2, dim3((unsigned)(p.nsub * nx * tilesPerA)), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB, tilesPerA, -1, 1);
     }
 }
 
@@ -540,8 +653,7 @@ template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hip
     if (NB > 16) NB = 16;
     if (NB < 1) NB = 1;
     const size_t lds = perCol * NB + twBytes;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_convolveX<Real>), dim3((unsigned)((nCols + NB - 1) / NB)), dim3(512), lds, s, p, NB, nCols);
+    launchConvolveX<Real>(p.d.rx1, p.d.rx2, dim3((unsigned)((nCols + NB - 1) / NB)), lds, s, p, NB, nCols);
 }
 
 template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipStream_t s) {
@@ -550,9 +662,7 @@ template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipS
         const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), 16);
         const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>) + (size_t)ny * sizeof(Cx<Real>);
         const int tilesPerA = (nzc + NB - 1) / NB;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_fftStrided<Real>), dim3((unsigned)(p.nsub * nx * tilesPerA)), dim3(256), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB,
-                           tilesPerA, +1, 1);
+        launchFftStrided<Real>(p.d.ry1, p.d.ry2, dim3((unsigned)(p.nsub * nx * tilesPerA)), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB, tilesPerA, +1, 1);
     }
     {
         int NL = pickBatch<Real>((size_t)2 * nz * sizeof(Cx<Real>), 17) - 1;   // padded stride NL+1 must be odd
@@ -560,8 +670,7 @@ template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipS
         if (NL < 2) NL = 2;
         const size_t lds = (size_t)2 * nz * (NL + 1) * sizeof(Cx<Real>) + (size_t)nz * sizeof(Cx<Real>);
         const size_t nlines = (size_t)p.nsub * nx * ny;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_fftZ<Real, false>), dim3((unsigned)((nlines + NL - 1) / NL)), dim3(256), lds, s, p, NL);
+        launchFftZ<Real, false>(p.d.rz1, p.d.rz2, dim3((unsigned)((nlines + NL - 1) / NL)), lds, s, p, NL);
     }
 }
 
@@ -571,9 +680,7 @@ template <typename Real> void launchPmeFFTX(const PmeParams<Real>& p, int sign, 
     const int NB = pickBatch<Real>((size_t)2 * nx * sizeof(Cx<Real>), 16);
     const size_t lds = (size_t)2 * nx * NB * sizeof(Cx<Real>) + (size_t)nx * sizeof(Cx<Real>);
     const int tilesPerA = (nCols + NB - 1) / NB;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_fftStrided<Real>), dim3((unsigned)(p.nsub * tilesPerA)), dim3(256), lds, s, p, nx, (size_t)nx * nCols, nCols, (size_t)nCols, NB,
-                       tilesPerA, sign, 0);
+    launchFftStrided<Real>(p.d.rx1, p.d.rx2, dim3((unsigned)(p.nsub * tilesPerA)), lds, s, p, nx, (size_t)nx * nCols, nCols, (size_t)nCols, NB, tilesPerA, sign, 0);
 }
 template void launchPmeFFTX<float>(const PmeParams<float>&, int, hipStream_t);
 template void launchPmeFFTX<double>(const PmeParams<double>&, int, hipStream_t);
@@ -762,6 +869,15 @@ bool factorize(int n, int* factors, int* nf) {
     while (n % 7 == 0) { factors[k++] = 7; n /= 7; }
     *nf = k;
     return n == 1 && k <= 16;
+}
+
+// n = r1 * r2 for one of the instantiated (R1, R2) pairs; false (and 0, 0) if n is not in the list
+bool splitTwoPass(int n, int* r1, int* r2) {
+#define X(A, B) if (n == (A) * (B)) { *r1 = A; *r2 = B; return true; }
+    SNB_FFT_PAIRS(X)
+#undef X
+    *r1 = *r2 = 0;
+    return false;
 }
 
 int legalGridSize(int n) {

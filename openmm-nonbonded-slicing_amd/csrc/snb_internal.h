@@ -79,6 +79,7 @@ struct PmePlanDims {
     int nx, ny, nz, nzc;      // nzc = nz/2+1
     int nfx, nfy, nfz;        // number of radix factors per axis
     int fx[16], fy[16], fz[16];
+    int rx1, rx2, ry1, ry2, rz1, rz2;   // two-pass register-FFT split n = r1*r2 per axis (0 = use the staged Stockham path)
 };
 
 template <typename Real> struct PmeParams {
@@ -147,5 +148,6 @@ template <typename Real> void launchFinishForces(const Real* fx, const Real* fy,
 
 int legalGridSize(int n);
 bool factorize(int n, int* factors, int* nfactors);
+bool splitTwoPass(int n, int* r1, int* r2);
 
 }  // namespace snb
