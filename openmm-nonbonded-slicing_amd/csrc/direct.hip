@@ -172,8 +172,8 @@ __device__ __forceinline__ void tileSteps(const DirectParams<Real>& p, const typ
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ inline float rowRor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true)); }
 
-template <int MC, bool MASKED>
-__device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float4* rdPos, const float2* rdSe, const float4 pi, const float2 sei,
+template <int MC, bool MASKED, bool TABLE>
+__device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float2* __restrict__ tab, const float4* rdPos, const float2* rdSe, const float4 pi, const float2 sei,
                                                 const float qiS, const float epsiS, const unsigned maskWord, const int c,
                                                 v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz) {
     v2f ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};      // j-force accumulators: .x follows slot c-2s, .y slot c-2s-1
@@ -193,7 +193,19 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
         v2f f = es6 * (s6 * 12.0f - 6.0f);
         // Coulomb
         const v2f qq = (v2f){qiS, qiS} * (v2f){xa.w, xb.w};
-        if (MC == MC_EWALD) {
+        if (MC == MC_EWALD && TABLE) {
+            // real-space Ewald force factor  [erfc(ar) + 2ar/sqrt(pi) e^{-(ar)^2}] / r^3 = 1/r^3 - Bt(r^2): the smooth, bounded part
+            // Bt is tabulated over r^2 in LDS (linear interpolation, error < 3e-7 relative to Bt); replaces exp + rcp + 9 VALU ops
+            const v2f u = r2 * p.tabScale;
+            const v2f fl = {__builtin_floorf(u.x), __builtin_floorf(u.y)};
+            const v2f fr = u - fl;
+            int ia = (int)fl.x, ib = (int)fl.y;
+            ia = ia < p.tabN ? ia : p.tabN; ib = ib < p.tabN ? ib : p.tabN;
+            const float2 ta = tab[ia], tb = tab[ib];
+            const v2f bt = (v2f){ta.x, tb.x} + fr * (v2f){ta.y, tb.y};
+            const v2f invR2 = invR * invR;
+            f = f * invR2 + qq * (invR * invR2 - bt);
+        } else if (MC == MC_EWALD) {
             const v2f r = r2 * invR;
             const v2f ar = r * p.alpha;
             const v2f e2 = r2 * (-p.alpha2l2e);
@@ -211,7 +223,7 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
         } else {
             f = f + qq * invR;
         }
-        f = f * (invR * invR);
+        if (!(MC == MC_EWALD && TABLE)) f = f * (invR * invR);
         bool inA = MC == MC_NOCUTOFF ? true : (r2.x < p.cutoff2), inB = MC == MC_NOCUTOFF ? true : (r2.y < p.cutoff2);
         if (MASKED) { inA = inA && !((maskWord >> ((c - 2 * s) & 15)) & 1u); inB = inB && !((maskWord >> ((c - 2 * s - 1) & 15)) & 1u); }
         f.x = inA ? f.x : 0.0f; f.y = inB ? f.y : 0.0f;
@@ -237,11 +249,18 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
     using T2 = typename Vec<Real>::T2;
     __shared__ T4 s_pos[4][64];
     __shared__ T2 s_se[4][64];
+    extern __shared__ __align__(16) unsigned char s_tabRaw[];
+    const float2* tab = reinterpret_cast<const float2*>(s_tabRaw);
+    constexpr bool kTable = std::is_same<Real, float>::value && !ENERGY && !WRAP && MC == MC_EWALD;
+    if (kTable && p.tabN > 0) {     // stage the Ewald force table once per work-group (work-groups loop over work items)
+        float2* w = reinterpret_cast<float2*>(s_tabRaw);
+        for (int k = threadIdx.x; k <= p.tabN; k += 256) w[k] = p.ewaldTable[k];
+        __syncthreads();
+    }
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * 4 + wid;
-    if (item >= p.numWork) return;                       // whole wave leaves; no block-level barrier is used below
+    for (int item = blockIdx.x * 4 + wid; item < p.numWork; item += gridDim.x * 4) {   // no block-level barrier inside the loop
     const int4 wi = p.workItems[p.workStart + item * p.workStride];
     const int I = __builtin_amdgcn_readfirstlane(wi.x);
     const int tBegin = __builtin_amdgcn_readfirstlane(wi.y), tEnd = tBegin + __builtin_amdgcn_readfirstlane(wi.z);
@@ -311,8 +330,13 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
         if constexpr (std::is_same<Real, float>::value && !ENERGY && !WRAP && MC != MC_LJPME) {
             if (!p.useSwitch) {
                 v2f pfx = {0.f, 0.f}, pfy = {0.f, 0.f}, pfz = {0.f, 0.f};
-                if (hasMask) tileStepsPacked<MC, true>(p, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
-                else tileStepsPacked<MC, false>(p, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
+                if (kTable && p.tabN > 0) {
+                    if (hasMask) tileStepsPacked<MC, true, true>(p, tab, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
+                    else tileStepsPacked<MC, false, true>(p, tab, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
+                } else {
+                    if (hasMask) tileStepsPacked<MC, true, false>(p, tab, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
+                    else tileStepsPacked<MC, false, false>(p, tab, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
+                }
                 fix += pfx.x + pfx.y; fiy += pfy.x + pfy.y; fiz += pfz.x + pfz.y;
                 donePacked = true;
             }
@@ -342,18 +366,25 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
         double a = waveSum((double)ecl), b = waveSum((double)elj);
         if (lane == 0) { atomicAdd(&p.sliceE[2 * curSlice], a); atomicAdd(&p.sliceE[2 * curSlice + 1], b); }
     }
+    __builtin_amdgcn_wave_barrier();
+    }   // work-item loop
 }
 
 template <typename Real, int MC> static void launchDirectMC(const DirectParams<Real>& p, bool wrap, bool energy, hipStream_t s) {
     const int myItems = p.numWork;
     if (myItems <= 0) return;
-    dim3 grid((myItems + 3) / 4), block(256);
+    int nwg = (myItems + 3) / 4;
+    const bool table = std::is_same<Real, float>::value && !energy && !wrap && MC == MC_EWALD && p.tabN > 0;
+    // with the table every work-group first stages 16 KB, so work-groups are made persistent-ish: 256 CUs x 4 resident groups, looping
+    if (table && nwg > 256 * 4 * 2) nwg = 256 * 4 * 2;
+    const size_t lds = table ? sizeof(float2) * (size_t)(p.tabN + 1) : 0;
+    dim3 grid(nwg), block(256);
     if (wrap) {
         if (energy) hipLaunchKernelGGL((k_direct<Real, MC, true, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((k_direct<Real, MC, true, false>), grid, block, 0, s, p);
     } else {
         if (energy) hipLaunchKernelGGL((k_direct<Real, MC, false, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((k_direct<Real, MC, false, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((k_direct<Real, MC, false, false>), grid, block, lds, s, p);
     }
 }
 

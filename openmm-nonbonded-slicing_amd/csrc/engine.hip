@@ -18,6 +18,7 @@
 #include <numeric>
 #include <set>
 #include <tuple>
+#include <type_traits>
 
 namespace snb {
 
@@ -202,6 +203,7 @@ public:
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
+    DevBuf<float2> ewaldTable; int ewaldTabN = 0; float ewaldTabScale = 0;
     struct GraphKey { const void* pos; int isDouble, stride4; bool direct, recip; bool operator==(const GraphKey& o) const { return pos == o.pos && isDouble == o.isDouble && stride4 == o.stride4 && direct == o.direct && recip == o.recip; } };
     hipGraphExec_t graphExec = nullptr; GraphKey graphKey{}; long long execCount = 0;
     void dropGraph() { if (graphExec) { (void)hipGraphExecDestroy(graphExec); graphExec = nullptr; } }
@@ -219,6 +221,9 @@ public:
         lambdas.assign((size_t)S * 2, 1.0); dispCoef.assign(S, 0.0); hostSliceE.assign((size_t)S * 2, 0.0);
         sliceE.resize((size_t)S * 2);
         if (cfg.shard_count < 1) cfg.shard_count = 1;
+        // tabulated Ewald force factor: opt-in.  Measured on MI355X it only trades 4 % of the VALU instructions for LDS gathers (the packed
+        // analytic erfc is already cheap) and leaves the kernel time unchanged, so the analytic form stays the default.
+        if (std::is_same<Real, float>::value && cfg.method >= SNB_Ewald && getenv("SNB_EWALD_TABLE")) buildEwaldTable();
         for (int s = 0; s < nsub; s++) if (s % cfg.shard_count == cfg.shard_rank) ownedSubsets.push_back(s);
         nGrids = cfg.shard_count == 1 ? nsub : (int)ownedSubsets.size();
         if (isPme()) {
@@ -240,6 +245,23 @@ public:
         dropGraph();
         for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
         if (ownStream) (void)hipStreamDestroy(stream);
+    }
+    // Bt(r^2) = [erf(ar) - 2ar/sqrt(pi) exp(-(ar)^2)] / r^3  (bounded, smooth; Bt(0) = 4 a^3 / (3 sqrt(pi))): the real-space Ewald
+    // force factor is 1/r^3 - Bt.  2048 intervals over [0, (cutoff+skin)^2], linear interpolation.
+    void buildEwaldTable() {
+        const int n = 2048;
+        const double rmax = cfg.cutoff + std::max(cfg.neighbor_padding, 0.0) + 0.05;
+        const double h = rmax * rmax / n, a = cfg.alpha;
+        auto bt = [&](double r2) {
+            const double r = std::sqrt(r2), z = a * r;
+            if (z < 1e-3) return a * a * a * (4.0 / (3.0 * std::sqrt(SNB_PI))) * (1.0 - 0.6 * z * z);
+            return (std::erf(z) - 2.0 * z / std::sqrt(SNB_PI) * std::exp(-z * z)) / (r2 * r);
+        };
+        std::vector<float2> t(n + 2);
+        for (int i = 0; i <= n + 1; i++) { const double v0 = bt(i * h), v1 = bt((i + 1) * h); t[i].x = (float)v0; t[i].y = (float)(v1 - v0); }
+        ewaldTable.upload(t, stream);
+        HIPCHECK(hipStreamSynchronize(stream));
+        ewaldTabN = n; ewaldTabScale = (float)(1.0 / h);
     }
     bool isPme() const { return cfg.method == SNB_PME || cfg.method == SNB_LJPME; }
     bool isPeriodic() const { return cfg.method >= SNB_CutoffPeriodic; }
@@ -801,6 +823,7 @@ public:
             p.crf = (Real)((1.0 / cfg.cutoff) * (3.0 * cfg.rf_dielectric) / (2.0 * cfg.rf_dielectric + 1.0));
             p.alpha = (Real)cfg.alpha; p.alphaD = (Real)cfg.alpha_d; p.k4pe = (Real)SNB_ONE_4PI_EPS0;
             p.alpha2l2e = (Real)(cfg.alpha * cfg.alpha * 1.4426950408889634);
+            p.ewaldTable = ewaldTable.p; p.tabN = ewaldTabN; p.tabScale = ewaldTabScale;
             const double ic2 = 1.0 / (cfg.cutoff * cfg.cutoff), ic6 = ic2 * ic2 * ic2;
             const double dar2 = cfg.alpha_d * cfg.alpha_d * cfg.cutoff * cfg.cutoff;
             p.invCut6 = (Real)ic6; p.multShift6 = (Real)(ic6 * (1.0 - std::exp(-dar2) * (1.0 + dar2 + 0.5 * dar2 * dar2)));

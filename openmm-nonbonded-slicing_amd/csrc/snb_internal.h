@@ -48,6 +48,7 @@ template <typename Real> struct DirectParams {
     int nsub;
     Real cutoff2, krf, crf, alpha, alphaD, k4pe;          // k4pe = ONE_4PI_EPS0
     Real alpha2l2e;                                        // alpha^2 * log2(e)
+    const float2* ewaldTable; int tabN; float tabScale;    // single-precision forces-only path: Bt(r^2) table, tabN intervals over [0, (cutoff+skin)^2]
     Real invCut6, multShift6;                              // LJPME potential shifts
     int useSwitch; Real switchDist, invSwitchWidth;
     Real box[9]; Real invBoxDiag[3];                       // for the per-pair wrap variant
