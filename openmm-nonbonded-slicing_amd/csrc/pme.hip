@@ -17,6 +17,7 @@
 //  * the real axis (z) is transformed with the imaginary half implied, writing nz/2+1 complex outputs.
 #include "snb_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace snb {
 
@@ -561,7 +562,54 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
             }
     }
     // convolution with the lambda mix:  O_I = eterm * sum_J lambda[slice(I,J)][term] * S_J   (mix=0: O_I = eterm * S_I)
-    {
+    bool mixedOnMatrixCores = false;
+    if constexpr (std::is_same<Real, float>::value) {
+        if (p.mix && nsub <= 16) {
+            // The mix is a dense [n x n] x [n x points] contraction: it runs on the matrix cores.  v_mfma_f32_16x16x4_f32:
+            // A[i][k] (lane: i = l&15, k = l>>4) = lambda matrix (rows = output subset, K = input subset, 4 per instruction),
+            // B[k][j] (lane: k = l>>4, j = l&15) = 16 spectral values (re/im are separate "points"), D rows (l>>4)*4+r, column l&15.
+            mixedOnMatrixCores = true;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const int term = p.dispersion ? 1 : 0;
+            const int lane = tid & 63, wave = tid >> 6, nWaves = NT / 64;
+            const int ai = lane & 15, ak = lane >> 4;
+            float aReg[4];
+#pragma unroll
+            for (int kc = 0; kc < 4; kc++) {
+                const int J = kc * 4 + ak;
+                float v = 0.f;
+                if (ai < nsub && J < nsub) {
+                    const int gi = p.gridSubset[ai], gj = p.gridSubset[J];
+                    v = p.lambdas[2 * (gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi) + term];
+                }
+                aReg[kc] = v;
+            }
+            const int nPts = nx * NB * 2, nGroups = (nPts + 15) / 16, nK = (nsub + 3) / 4;
+            const float* Sf = reinterpret_cast<const float*>(S);
+            float* Of = reinterpret_cast<float*>(O);
+            for (int g = wave; g < nGroups; g += nWaves) {
+                const int pt = 16 * g + ai;
+                const bool valid = pt < nPts;
+                const int k = pt / (2 * NB), rem = pt - k * 2 * NB, col = rem >> 1, c = rem & 1;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) {
+                    if (kc < nK) {
+                        const int J = kc * 4 + ak;
+                        const float b = (valid && J < nsub) ? Sf[2 * (k * BS + J * NB + col) + c] : 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aReg[kc], b, acc, 0, 0, 0);
+                    }
+                }
+                const float e = valid ? (float)et[k * NB + col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int I = ak * 4 + r;
+                    if (valid && I < nsub) Of[2 * (k * BS + I * NB + col) + c] = acc[r] * e;
+                }
+            }
+        }
+    }
+    if (!mixedOnMatrixCores) {
         const int term = p.dispersion ? 1 : 0;
         for (int it = tid; it < nx * BS; it += NT) {
             const int k = it / BS, bb = it - k * BS;
