@@ -41,6 +41,33 @@ def calcPMEParameters(force, boxVectors, lj=False):
     return alpha, nx, ny, nz
 
 
+def calcEwaldParameters(force, boxVectors):
+    """OpenMM ``NonbondedForceImpl::calcEwaldParameters`` (third-party, SURVEY a13; restated from OpenMM 8.x, NOT pinned by a
+    reference fixture).  A mesh-less explicit override for parity runs: ``force.ewaldKmax = (kx, ky, kz)`` with the alpha of
+    ``setPMEParameters``."""
+    alpha = force.getPMEParameters()[0]
+    tol = force.getEwaldErrorTolerance()
+    if alpha == 0.0:
+        alpha = math.sqrt(-math.log(2 * tol)) / force.getCutoffDistance()
+    explicit = getattr(force, "ewaldKmax", None)
+    if explicit is not None:
+        return (alpha,) + tuple(int(k) for k in explicit)
+
+    def find(width):
+        f = lambda k: tol - 0.05 * math.sqrt(width * alpha) * k * math.exp(-(k * math.pi / (width * alpha)) ** 2)
+        k = 10
+        v = f(k)
+        if v > 0.0:
+            while v > 0.0 and k > 0:
+                k -= 1; v = f(k)
+            k += 1
+        else:
+            while v < 0.0:
+                k += 1; v = f(k)
+        return k if k % 2 == 1 else k + 1
+    return alpha, find(boxVectors[0][0]), find(boxVectors[1][1]), find(boxVectors[2][2])
+
+
 class HipCalcSlicedNonbondedForceKernel:
     """MI355X kernel object behind the reference's ``CalcSlicedNonbondedForceKernel`` interface."""
 
@@ -97,11 +124,8 @@ class HipCalcSlicedNonbondedForceKernel:
             a, nx, ny, nz = calcPMEParameters(force, box, True)
             cfg.alpha_d = a; cfg.dgrid[0], cfg.dgrid[1], cfg.dgrid[2] = nx, ny, nz
         if method == SlicedNonbondedForce.Ewald:
-            a = force.getPMEParameters()[0]
-            if a == 0.0:
-                tol = force.getEwaldErrorTolerance()
-                a = math.sqrt(-math.log(2 * tol)) / force.getCutoffDistance()
-            cfg.alpha = a
+            a, kx, ky, kz = calcEwaldParameters(force, box)
+            cfg.alpha = a; cfg.kmax[0], cfg.kmax[1], cfg.kmax[2] = kx, ky, kz
         cfg.neighbor_padding = self.neighbor_padding; cfg.rebuild_interval = self.rebuild_interval
         cfg.shard_rank = self.shard_rank; cfg.shard_count = self.shard_count
         cfg.stream = self.stream

@@ -204,6 +204,7 @@ public:
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
     DevBuf<float2> ewaldTable; int ewaldTabN = 0; float ewaldTabScale = 0;
+    std::vector<int3> hKvec; DevBuf<int3> dKvec; DevBuf<Real> dCosSin;
     struct GraphKey { const void* pos; int isDouble, stride4; bool direct, recip; bool operator==(const GraphKey& o) const { return pos == o.pos && isDouble == o.isDouble && stride4 == o.stride4 && direct == o.direct && recip == o.recip; } };
     hipGraphExec_t graphExec = nullptr; GraphKey graphKey{}; long long execCount = 0;
     void dropGraph() { if (graphExec) { (void)hipGraphExecDestroy(graphExec); graphExec = nullptr; } }
@@ -763,12 +764,15 @@ public:
             const double minAllowed = 1.999999 * cfg.cutoff;
             if (box[0] < minAllowed || box[4] < minAllowed || box[8] < minAllowed) { err = "The periodic box size has decreased to less than twice the nonbonded cutoff."; throw (int)SNB_ERR_BOX_TOO_SMALL; }
         }
-        if (cfg.method == SNB_Ewald && includeRecip) { err = "classic Ewald reciprocal sum is not implemented in the HIP engine yet (use PME)"; throw (int)SNB_ERR_UNSUPPORTED; }
+        if (cfg.method == SNB_Ewald && includeRecip) {
+            if (cfg.kmax[0] < 1 || cfg.kmax[1] < 1 || cfg.kmax[2] < 1) { err = "Ewald: kmax must be given explicitly (snb_config.kmax)"; throw (int)SNB_ERR_INVALID_ARGUMENT; }
+            if (box[3] != 0 || box[6] != 0 || box[7] != 0) { err = "SlicedNonbondedForce: Ewald is not supported with non-rectangular boxes.  Use PME instead."; throw (int)SNB_ERR_UNSUPPORTED; }
+        }
         if (dLambdas.p == nullptr) setLambdas(lambdas.data());
         if (needRebuild || paramsDirty || cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval || cfg.neighbor_padding <= 0) rebuild();
         stepsSinceRebuild++;
         const bool energy = includeEnergy != 0;
-        lastRecip = includeRecip && isPme();
+        lastRecip = includeRecip && (isPme() || cfg.method == SNB_Ewald);
         // Forces-only steps replay a captured hipGraph (the ~14 small launches of a step are host-launch-bound otherwise:
         // 7-8 us of idle GPU between kernels).  Every 8th step -- and every energy step -- is enqueued eagerly with HIP events
         // around the pair kernel and the reciprocal pipeline; those samples feed snb_stats' kernel timers.
@@ -866,7 +870,30 @@ public:
                 if (cfg.method == SNB_LJPME) { fillPme(pp, dpme, energy); runPme(pp); }
             }
         }
+        if (includeRecip && cfg.method == SNB_Ewald && cfg.shard_rank == 0) runEwald(energy);
         if (ev) HIPCHECK(hipEventRecord(ev->e[4], stream));
+    }
+
+    // classic Ewald: half-space k-vectors in the reference's enumeration order (ReferenceSlicedLJCoulombIxn.cpp:288-355)
+    void runEwald(bool energy) {
+        if (hKvec.empty()) {
+            int lowry = 0, lowrz = 1;
+            for (int rx = 0; rx < cfg.kmax[0]; rx++) {
+                for (int ry = lowry; ry < cfg.kmax[1]; ry++) {
+                    for (int rz = lowrz; rz < cfg.kmax[2]; rz++) { hKvec.push_back(make_int3(rx, ry, rz)); lowrz = 1 - cfg.kmax[2]; }
+                    lowry = 1 - cfg.kmax[1];
+                }
+            }
+            dKvec.upload(hKvec, stream);
+            dCosSin.resize(hKvec.size() * 2 * nsub);
+        }
+        EwaldParams<Real> q;
+        std::memset(&q, 0, sizeof(q));
+        q.natoms = Npad; q.nsub = nsub; q.nk = (int)hKvec.size(); q.posq = posq.p; q.atomSubset = atomSubset.p; q.kvec = dKvec.p; q.cosSin = dCosSin.p;
+        q.recipBox[0] = (Real)(2 * SNB_PI / box[0]); q.recipBox[1] = (Real)(2 * SNB_PI / box[4]); q.recipBox[2] = (Real)(2 * SNB_PI / box[8]);
+        q.factorEwald = -1 / (4 * cfg.alpha * cfg.alpha); q.recipCoeff = SNB_ONE_4PI_EPS0 * 4 * SNB_PI / (box[0] * box[4] * box[8]);
+        q.lambdas = dLambdas.p; q.sliceE = sliceE.p; q.wantEnergy = energy ? 1 : 0; q.fpx = fpx.p; q.fpy = fpy.p; q.fpz = fpz.p;
+        launchEwald<Real>(q, stream);
     }
 
     void harvest(EvSet& ev) {

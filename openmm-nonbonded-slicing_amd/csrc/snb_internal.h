@@ -109,6 +109,19 @@ template <typename Real> struct PmeParams {
     const int2* colRange;      // [nsubTotal][ncx*ncy] sorted-atom range of every (subset, xy column)
 };
 
+// classic Ewald reciprocal sum (ewald.hip)
+template <typename Real> struct EwaldParams {
+    int natoms, nsub, nk;
+    const typename Vec<Real>::T4* posq; const int* atomSubset;
+    const int3* kvec;          // [nk] half-space k-vectors in the reference's enumeration order (ReferenceSlicedLJCoulombIxn.cpp:288-355)
+    Real* cosSin;              // [nk][2*nsub] per-subset structure factors
+    Real recipBox[3];          // 2 pi / L
+    double factorEwald, recipCoeff;
+    const Real* lambdas; double* sliceE; int wantEnergy;
+    Real* fpx; Real* fpy; Real* fpz;
+};
+template <typename Real> void launchEwald(const EwaldParams<Real>& p, hipStream_t s);
+
 // GPU neighbour build (neighbor.hip)
 template <typename Real> struct NbParams {
     int nAtoms, nPadded, nBlocks, nSubsets, subsetBits, ncx, ncy;

@@ -75,13 +75,24 @@ def test_switching_function(snb, F, prec):
         K.testSwitchingFunction(make_ev(snb, prec), F, 4, pme=(2.0, 30, 30, 30), tol=tol)
 
 
-@pytest.mark.parametrize("method", [0, 1, 2, 4, 5])
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("exceptions", [False, True])
 @pytest.mark.parametrize("lj", [False, True])
 def test_nonbonded_slicing(method, exceptions, lj, snb, F, prec):
     n = 28 if exceptions else 40
-    K.testNonbondedSlicing(make_ev(snb, prec), F, method, exceptions, lj, tol=2e-3 if prec == "single" else K.TOL,
-                           pme=(1.0, n, n, n) if method in (4, 5) else None, ljpme=(1.0, n, n, n) if method == 5 else None)
+    Fm = F
+    if method == 3:   # classic Ewald: explicit alpha and kmax (auto-selection is OpenMM's calcEwaldParameters, unpinned)
+        def Fm(nsub):
+            f = F(nsub); f.ewaldKmax = (8, 8, 8); return f
+    K.testNonbondedSlicing(make_ev(snb, prec), Fm, method, exceptions, lj, tol=2e-3 if prec == "single" else K.TOL,
+                           pme=(1.0, n, n, n) if method in (4, 5) else ((1.0, 0, 0, 0) if method == 3 else None), ljpme=(1.0, n, n, n) if method == 5 else None)
+
+
+def test_ewald_vs_oracle(snb, F, oev, prec):
+    """Classic Ewald k-sum kernels (ewald.hip) against the oracle's restatement of ReferenceSlicedLJCoulombIxn.cpp:256-358."""
+    force, pos, box = systems.random_box(F, 1500, 3, 3, 2.6, 1.0, pme=(2.6283, 0, 0, 0))
+    force.ewaldKmax = (11, 11, 11)
+    _compare(make_ev(snb, prec), oev, force, pos, box, TOLS[prec], kmax=(11, 11, 11))
 
 
 def _compare(ev, oev, force, pos, box, tol, **okw):
