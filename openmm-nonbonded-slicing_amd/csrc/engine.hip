@@ -750,9 +750,17 @@ public:
         p.alpha = (Real)plan.alpha; p.volume = (Real)det; p.dispersion = plan.dispersion ? 1 : 0;
         p.lambdas = dLambdas.p; p.gridSubset = gridSubset.p; p.nsubTotal = nsub; p.mix = cfg.shard_count == 1 ? 1 : 0;
         p.sliceE = sliceE.p; p.fpx = fpx.p; p.fpy = fpy.p; p.fpz = fpz.p; p.wantEnergy = wantEnergy ? 1 : 0;
-        // brick spreading needs the plan's mesh to be the one the sort columns were cut for (the LJPME dispersion mesh falls back)
-        const bool brick = colCells[0] > 0 && plan.d.nx == pme.d.nx && plan.d.ny == pme.d.ny && plan.d.nz == pme.d.nz;
-        p.colCellsX = brick ? colCells[0] : 0; p.colCellsY = brick ? colCells[1] : 0; p.colRange = brick ? colRange.p : nullptr;
+        // brick kernels: the sort columns were cut for the Coulomb mesh; any mesh whose cells tile those columns can use them,
+        // with bricks of `group` columns when one column is narrower than 5 cells (stencil 4 + 1 cell of drift)
+        p.sortNcx = p.sortNcy = 0; p.groupX = p.groupY = 1; p.colRange = nullptr;
+        if (colCells[0] > 0) {
+            const int ncx = pme.d.nx / colCells[0], ncy = pme.d.ny / colCells[1];
+            auto group = [](int n, int ncols) { if (n % ncols) return 0; const int cpc = n / ncols; for (int g = 1; g <= 4; g++) if (g * cpc >= 5 && ncols % g == 0) return g; return 0; };
+            const int gx = group(plan.d.nx, ncx), gy = group(plan.d.ny, ncy);
+            if (gx > 0 && gy > 0 && sizeof(double) * (size_t)(gx * plan.d.nx / ncx) * (gy * plan.d.ny / ncy) * plan.d.nz <= 100 * 1024) {
+                p.sortNcx = ncx; p.sortNcy = ncy; p.groupX = gx; p.groupY = gy; p.colRange = colRange.p;
+            }
+        }
     }
 
     void execute(int includeForces, int includeEnergy, int includeDirect, int includeRecip, double* energyOut) override {

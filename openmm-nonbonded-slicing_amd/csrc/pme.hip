@@ -118,11 +118,14 @@ template <typename Real> __global__ __launch_bounds__(256) void k_spread(const P
 template <typename Real> __global__ __launch_bounds__(1024) void k_spreadBrick(const PmeParams<Real> p) {
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
     constexpr int NT = 1024, LISTCAP = 2048;
-    const int cx = p.colCellsX, cy = p.colCellsY, ncx = p.d.nx / cx, ncy = p.d.ny / cy, nz = p.d.nz;
+    // a brick spans groupX x groupY sort columns (1 x 1 for the Coulomb mesh; more when a coarser mesh makes one column < 5 cells)
+    const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
+    const int cx = p.groupX * (p.d.nx / ncx), cy = p.groupY * (p.d.ny / ncy);       // brick size in cells of THIS mesh
+    const int nbx = ncx / p.groupX, nby = ncy / p.groupY;
     const int ncol = ncx * ncy;
-    const int slot = blockIdx.x / ncol, col = blockIdx.x - slot * ncol;
-    const int Cx = col / ncy, Cy = col - Cx * ncy;
-    const int x0 = Cx * cx, y0 = Cy * cy;
+    const int slot = blockIdx.x / (nbx * nby), bcol = blockIdx.x - slot * (nbx * nby);
+    const int Bx = bcol / nby, By = bcol - Bx * nby;
+    const int x0 = Bx * cx, y0 = By * cy;
     const int npts = cx * cy * nz;
     double* brick = reinterpret_cast<double*>(s_brick_raw);
     int* list = reinterpret_cast<int*>(brick + npts);       // [LISTCAP] atoms of the current column whose stencil overlaps the brick
@@ -132,12 +135,15 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_spreadBrick(c
     if (tid == 0) s_count = 0;
     __syncthreads();
     const int2* ranges = p.colRange + (size_t)p.gridSubset[slot] * ncol;
-    for (int dcx = -1; dcx <= 1; dcx++) {
-        int ccx = Cx + dcx; if (ccx < 0) ccx += ncx; if (ccx >= ncx) ccx -= ncx;
-        if (!(dcx == 0 || ncx >= 3 || (ncx == 2 && dcx == -1))) continue;   // fewer than 3 columns: never visit a column twice
-        for (int dcy = -1; dcy <= 1; dcy++) {
-            int ccy = Cy + dcy; if (ccy < 0) ccy += ncy; if (ccy >= ncy) ccy -= ncy;
-            if (!(dcy == 0 || ncy >= 3 || (ncy == 2 && dcy == -1))) continue;
+    // candidate columns: the brick's own columns, mLo columns below (stencil reach 4 cells + 1 cell of drift) and one above
+    // (drift), each distinct column once
+    const int cpcx = p.d.nx / ncx, cpcy = p.d.ny / ncy;
+    const int mLoX = (5 + cpcx - 1) / cpcx, mLoY = (5 + cpcy - 1) / cpcy;
+    const int nvx = (p.groupX + mLoX + 1 < ncx) ? p.groupX + mLoX + 1 : ncx, nvy = (p.groupY + mLoY + 1 < ncy) ? p.groupY + mLoY + 1 : ncy;
+    for (int tx = 0; tx < nvx; tx++) {
+        int ccx = (Bx * p.groupX - mLoX + tx) % ncx; if (ccx < 0) ccx += ncx;
+        for (int ty = 0; ty < nvy; ty++) {
+            int ccy = (By * p.groupY - mLoY + ty) % ncy; if (ccy < 0) ccy += ncy;
             const int2 rg = ranges[ccx * ncy + ccy];
             for (int chunk = rg.x; chunk < rg.y; chunk += LISTCAP) {
                 const int chunkEnd = (chunk + LISTCAP < rg.y) ? chunk + LISTCAP : rg.y;
@@ -197,9 +203,10 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_spreadBrick(c
 }
 
 template <typename Real> void launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
-    if (p.colCellsX > 0 && p.colRange != nullptr) {
-        const size_t lds = sizeof(double) * (size_t)p.colCellsX * p.colCellsY * p.d.nz + sizeof(int) * 2048;
-        const int nblocks = p.nsub * (p.d.nx / p.colCellsX) * (p.d.ny / p.colCellsY);
+    if (p.sortNcx > 0 && p.colRange != nullptr) {
+        const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
+        const size_t lds = sizeof(double) * (size_t)cx * cy * p.d.nz + sizeof(int) * 2048;
+        const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_spreadBrick<Real>), dim3(nblocks), dim3(1024), lds, s, p);
         return;
@@ -819,13 +826,17 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
     constexpr int NT = 1024, HALO_LO = 1, EXTRA = 6;
     Real* brick = reinterpret_cast<Real*>(s_brick_raw);
-    const int cx = p.colCellsX, cy = p.colCellsY, ncx = p.d.nx / cx, ncy = p.d.ny / cy, nz = p.d.nz;
+    const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
+    const int cx = p.groupX * (p.d.nx / ncx), cy = p.groupY * (p.d.ny / ncy);
+    const int nbx = ncx / p.groupX, nby = ncy / p.groupY;
     const int ncol = ncx * ncy;
-    const int slot = blockIdx.x / ncol, col = blockIdx.x - slot * ncol;
-    const int2 rg = p.colRange[(size_t)p.gridSubset[slot] * ncol + col];
-    if (rg.y <= rg.x) return;                                 // empty column of this subset: nothing to interpolate
-    const int Cx = col / ncy, Cy = col - Cx * ncy;
-    const int x0 = Cx * cx, y0 = Cy * cy;
+    const int slot = blockIdx.x / (nbx * nby), bcol = blockIdx.x - slot * (nbx * nby);
+    const int Bx = bcol / nby, By = bcol - Bx * nby;
+    const int2* ranges = p.colRange + (size_t)p.gridSubset[slot] * ncol;
+    bool any = false;
+    for (int gx = 0; gx < p.groupX; gx++) for (int gy = 0; gy < p.groupY; gy++) { const int2 r0 = ranges[(Bx * p.groupX + gx) * ncy + By * p.groupY + gy]; any = any || (r0.y > r0.x); }
+    if (!any) return;                                         // no atom of this subset in the brick's columns
+    const int x0 = Bx * cx, y0 = By * cy;
     const int bx = cx + EXTRA, by = cy + EXTRA;
     const int tid = threadIdx.x;
     const Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
@@ -837,7 +848,8 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
         brick[i] = g[((size_t)x * p.d.ny + y) * nz + z];
     }
     __syncthreads();
-    const int term = p.dispersion ? 1 : 0; (void)term;
+    for (int gx = 0; gx < p.groupX; gx++) for (int gy = 0; gy < p.groupY; gy++) {
+    const int2 rg = ranges[(Bx * p.groupX + gx) * ncy + By * p.groupY + gy];
     for (int a = rg.x + tid; a < rg.y; a += NT) {
         const Real q = pmeCharge(p, a);
         const auto pos = p.posq[a];
@@ -874,19 +886,23 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
             }
         }
         const Real nx = p.d.nx, ny = p.d.ny, nzr = p.d.nz;
-        p.fpx[a] = -q * (fx * nx * p.recip[0]);
-        p.fpy[a] = -q * (fx * nx * p.recip[3] + fy * ny * p.recip[4]);
-        p.fpz[a] = -q * (fx * nx * p.recip[6] + fy * ny * p.recip[7] + fz * nzr * p.recip[8]);
+        const Real gx_ = -q * (fx * nx * p.recip[0]);
+        const Real gy_ = -q * (fx * nx * p.recip[3] + fy * ny * p.recip[4]);
+        const Real gz_ = -q * (fx * nx * p.recip[6] + fy * ny * p.recip[7] + fz * nzr * p.recip[8]);
+        if (p.dispersion) { p.fpx[a] += gx_; p.fpy[a] += gy_; p.fpz[a] += gz_; }   // second (dispersion) pipeline of LJPME adds
+        else { p.fpx[a] = gx_; p.fpy[a] = gy_; p.fpz[a] = gz_; }
+    }
     }
 }
 
 template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s) {
     if (p.natoms <= 0) return;
-    if (p.mix && !p.dispersion && p.colCellsX > 0 && p.colRange != nullptr) {
-        const size_t lds = sizeof(Real) * (size_t)(p.colCellsX + 6) * (p.colCellsY + 6) * p.d.nz;
+    if (p.mix && p.sortNcx > 0 && p.colRange != nullptr) {
+        const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
+        const size_t lds = sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * p.d.nz;
         if (lds <= 150 * 1024) {
             // padding atoms and atoms of empty columns are never visited: the engine clears all force views once per step
-            const int nblocks = p.nsub * (p.d.nx / p.colCellsX) * (p.d.ny / p.colCellsY);
+            const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBrick<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((k_interpolateBrick<Real>), dim3(nblocks), dim3(1024), lds, s, p);
             return;

@@ -105,7 +105,8 @@ template <typename Real> struct PmeParams {
     double* sliceE;
     Real* fpx; Real* fpy; Real* fpz;   // reciprocal force accumulators (plain stores when unsharded)
     int wantEnergy;
-    int colCellsX, colCellsY;  // brick spreading: sort-column size in grid cells (0 = use the atomic fallback)
+    int sortNcx, sortNcy;      // brick kernels: number of sort columns (0 = use the atomic / gather fallbacks)
+    int groupX, groupY;        // sort columns per brick (brick = group * nx/sortNcx cells, at least 5)
     const int2* colRange;      // [nsubTotal][ncx*ncy] sorted-atom range of every (subset, xy column)
 };
 

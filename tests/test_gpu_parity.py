@@ -127,6 +127,7 @@ CASES = [
     ("pme_4096_n2", 4096, 2, 4, 3.5, 1.0, (2.6283, 32, 32, 32), None, False),
     ("pme_6000_n4", 6000, 4, 4, 4.0, 1.0, (2.6283, 36, 36, 36), None, True),
     ("ljpme_3000_n4", 3000, 4, 5, 3.2, 1.0, (2.6283, 28, 28, 28), (2.6283, 20, 20, 20), False),
+    ("ljpme_brickgroup2_6000_n3", 6000, 3, 5, 4.0, 1.0, (2.6283, 36, 36, 36), (2.6283, 18, 18, 18), False),
     ("pme_smallbox_wrap_600_n2", 600, 2, 4, 2.05, 1.0, (2.6283, 20, 20, 20), None, False),
 ]
 
