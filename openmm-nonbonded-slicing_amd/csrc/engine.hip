@@ -753,6 +753,9 @@ public:
         // brick kernels: the sort columns were cut for the Coulomb mesh; any mesh whose cells tile those columns can use them,
         // with bricks of `group` columns when one column is narrower than 5 cells (stencil 4 + 1 cell of drift)
         p.sortNcx = p.sortNcy = 0; p.groupX = p.groupY = 1; p.colRange = nullptr;
+        p.zSlabs = 1;
+        if (plan.d.nz % 2 == 0 && plan.d.nz >= 32) p.zSlabs = 2;   // measured on c3: 1 slab 110 us, 2 slabs 105 us, 4 slabs 145 us (phase-1 rescans)
+        if (const char* zs = getenv("SNB_ZSLABS")) { const int k = atoi(zs); if (k >= 1 && plan.d.nz % k == 0) p.zSlabs = k; }
         if (colCells[0] > 0) {
             const int ncx = pme.d.nx / colCells[0], ncy = pme.d.ny / colCells[1];
             auto group = [](int n, int ncols) { if (n % ncols) return 0; const int cpc = n / ncols; for (int g = 1; g <= 4; g++) if (g * cpc >= 5 && ncols % g == 0) return g; return 0; };

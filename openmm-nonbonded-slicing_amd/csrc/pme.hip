@@ -115,18 +115,21 @@ template <typename Real> __global__ __launch_bounds__(256) void k_spread(const P
 // sorted ranges of its 3x3 column neighbourhood (one column of margin on each side covers the drift since the last
 // re-sort: < skin/2 < one grid cell).  Every grid point is written exactly once, coalesced along z.
 // ---------------------------------------------------------------------------------------------------
-template <typename Real> __global__ __launch_bounds__(1024) void k_spreadBrick(const PmeParams<Real> p) {
+template <typename Real> __global__ __launch_bounds__(512) void k_spreadBrick(const PmeParams<Real> p) {
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
-    constexpr int NT = 1024, LISTCAP = 2048;
+    constexpr int NT = 512, LISTCAP = 2048;
     // a brick spans groupX x groupY sort columns (1 x 1 for the Coulomb mesh; more when a coarser mesh makes one column < 5 cells)
     const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
     const int cx = p.groupX * (p.d.nx / ncx), cy = p.groupY * (p.d.ny / ncy);       // brick size in cells of THIS mesh
     const int nbx = ncx / p.groupX, nby = ncy / p.groupY;
     const int ncol = ncx * ncy;
-    const int slot = blockIdx.x / (nbx * nby), bcol = blockIdx.x - slot * (nbx * nby);
+    // ... and one of zSlabs slabs along z (more, smaller work-groups: the bulk subset alone has only ~#columns busy bricks)
+    const int sz = nz / p.zSlabs;
+    const int zs = blockIdx.x % p.zSlabs, brickId = blockIdx.x / p.zSlabs;
+    const int slot = brickId / (nbx * nby), bcol = brickId - slot * (nbx * nby);
     const int Bx = bcol / nby, By = bcol - Bx * nby;
-    const int x0 = Bx * cx, y0 = By * cy;
-    const int npts = cx * cy * nz;
+    const int x0 = Bx * cx, y0 = By * cy, z0 = zs * sz;
+    const int npts = cx * cy * sz;
     double* brick = reinterpret_cast<double*>(s_brick_raw);
     int* list = reinterpret_cast<int*>(brick + npts);       // [LISTCAP] atoms of the current column whose stencil overlaps the brick
     __shared__ int s_count;
@@ -154,7 +157,9 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_spreadBrick(c
                     gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
                     int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
                     int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
-                    if (rx + 4 >= 0 && rx < cx && ry + 4 >= 0 && ry < cy && pmeCharge(p, a) != Real(0)) list[atomicAdd(&s_count, 1)] = a;
+                    int rz = idx[2] - z0; if (rz > nz / 2) rz -= nz; else if (rz < -(nz / 2)) rz += nz;
+                    const bool zHit = p.zSlabs == 1 || (rz + 4 >= 0 && rz < sz);
+                    if (zHit && rx + 4 >= 0 && rx < cx && ry + 4 >= 0 && ry < cy && pmeCharge(p, a) != Real(0)) list[atomicAdd(&s_count, 1)] = a;
                 }
                 __syncthreads();
                 const int count = s_count;
@@ -169,9 +174,12 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_spreadBrick(c
                     int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
                     Real tx[5], ty[5], tz[5], dtmp[5];
                     bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
-                    int zi[5];
+                    int zi[5];      // z index inside the slab, or -1 when the point belongs to another slab
 #pragma unroll
-                    for (int iz = 0; iz < 5; iz++) { int z = idx[2] + iz; zi[iz] = z >= nz ? z - nz : z; }
+                    for (int iz = 0; iz < 5; iz++) {
+                        int z = idx[2] + iz - z0; if (z >= nz) z -= nz; else if (z < 0) z += nz;
+                        zi[iz] = z < sz ? z : -1;
+                    }
 #pragma unroll
                     for (int ix = 0; ix < 5; ix++) {
                         const int lx = rx + ix;
@@ -181,10 +189,10 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_spreadBrick(c
                             const int ly = ry + iy;
                             if (ly < 0 || ly >= cy) continue;
                             const Real wxy = q * tx[ix] * ty[iy];
-                            double* line = brick + (size_t)(lx * cy + ly) * nz;
+                            double* line = brick + (size_t)(lx * cy + ly) * sz;
 #pragma unroll
                             for (int iz = 0; iz < 5; iz++)
-                                __hip_atomic_fetch_add(&line[zi[iz]], (double)(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (zi[iz] >= 0) __hip_atomic_fetch_add(&line[zi[iz]], (double)(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                 }
@@ -196,19 +204,19 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_spreadBrick(c
     }
     Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
     for (int i = tid; i < npts; i += NT) {
-        const int l = i / nz, z = i - l * nz;
+        const int l = i / sz, z = i - l * sz;
         const int lx = l / cy, ly = l - lx * cy;
-        g[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z] = (Real)brick[i];
+        g[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z0 + z] = (Real)brick[i];
     }
 }
 
 template <typename Real> void launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
     if (p.sortNcx > 0 && p.colRange != nullptr) {
         const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
-        const size_t lds = sizeof(double) * (size_t)cx * cy * p.d.nz + sizeof(int) * 2048;
-        const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
+        const size_t lds = sizeof(double) * (size_t)cx * cy * (p.d.nz / p.zSlabs) + sizeof(int) * 2048;
+        const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * p.zSlabs;
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_spreadBrick<Real>), dim3(nblocks), dim3(1024), lds, s, p);
+        hipLaunchKernelGGL((k_spreadBrick<Real>), dim3(nblocks), dim3(512), lds, s, p);
         return;
     }
     // fallback (triclinic boxes, meshes without a usable column divisor): global float atomics

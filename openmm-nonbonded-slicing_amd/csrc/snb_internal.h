@@ -107,6 +107,7 @@ template <typename Real> struct PmeParams {
     int wantEnergy;
     int sortNcx, sortNcy;      // brick kernels: number of sort columns (0 = use the atomic / gather fallbacks)
     int groupX, groupY;        // sort columns per brick (brick = group * nx/sortNcx cells, at least 5)
+    int zSlabs;                // bricks are also cut into this many slabs along z (nz % zSlabs == 0)
     const int2* colRange;      // [nsubTotal][ncx*ncy] sorted-atom range of every (subset, xy column)
 };
 
