@@ -25,6 +25,10 @@ import os
 import sys
 import time
 
+# the GPU box reports every host core but grants a 16-core share: keep the CPU-baseline leg's OpenMP team inside it
+if "OMP_NUM_THREADS" not in os.environ:
+    os.environ["OMP_NUM_THREADS"] = str(min(16, len(os.sched_getaffinity(0))))
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -352,24 +356,31 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_direct (direct-space sliced tile kernel)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(bytes_direct), "avg_launch_ms": round(direct_ms, 4)},
     }
+    # HBM-side traffic of the same kernel: PMC passes cannot run inside this process, so the figure comes from the committed
+    # summary of `tools/pmc_hbm.sh` (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes over this command)
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_%s_pmc_hbm.json" % cfg_name)
+    if os.path.exists(pmc_file) and world == 1:
+        try:
+            rec = json.load(open(pmc_file))["k_direct_forces"]
+            out["roofline"]["traffic"] = int(rec["traffic_bytes_per_launch"])
+            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_file) + ": " + rec["formula"]
+        except Exception as exc:   # a malformed summary must not hide the measurement
+            out["roofline"]["traffic_source"] = "unreadable %s (%s)" % (pmc_file, exc)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: the same workload generator at 24k atoms (same density, cutoff, alpha, grid spacing), a few evaluations
         ws = build_workload(24000, 6.2145, min(nsub, 4), np.random.default_rng(SEED))
-        reps = 3; tsum = 0.0; pairs = 0
+        import oracle as _o
+        cores = int(_o.lib().orc_num_threads())
+        reps = 10; tsum = 0.0; pairs = 0
         for _ in range(reps):
             _, _, dt, pairs = oracle_eval(ws, 4 if method == 4 else 5, 54, 27 if method == 5 else 0)
             tsum += dt
         cpu_ms = tsum / reps * 1e3
-        import multiprocessing
-        try:
-            import oracle as _o
-            cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or multiprocessing.cpu_count()
-        except Exception:
-            cores = 1
-        out["cpu_baseline"] = {"value": round(86.4 * 2.0 / cpu_ms, 5), "unit": "ns/day", "cores": cores, "kind": "port",
+        cpu_full_ms = cpu_ms * N / len(ws["q"])
+        out["cpu_baseline"] = {"value": round(86.4 * 2.0 / cpu_full_ms, 5), "unit": "ns/day", "cores": cores, "kind": "port",
                                "sample": "CPU oracle (C restatement of the Reference platform; pair loop serial like the reference, PME FFT/interpolation OpenMP), "
                                          "%d evaluations of a %d-atom/%d-subset box of the same generator (density, cutoff, alpha, 54^3 grid): %.0f ms per evaluation, %d pairs; "
-                                         "per-atom cost scaled to the full workload: %.0f ms per evaluation" % (reps, len(ws["q"]), ws["nsub"], cpu_ms, pairs, cpu_ms * N / len(ws["q"])),
+                                         "value = the per-atom cost scaled to the full workload: %.0f ms per evaluation" % (reps, len(ws["q"]), ws["nsub"], cpu_ms, pairs, cpu_full_ms),
                                "ms_per_step_sample": round(cpu_ms, 1), "ms_per_step_scaled": round(cpu_ms * N / len(ws["q"]), 1)}
     if args.check and rank == 0 and world == 1:
         fo, so, _, _ = oracle_eval(w, method, grid, dgrid)

@@ -177,6 +177,7 @@ public:
     hipStream_t stream = nullptr; bool ownStream = false;
     // ring of per-execute event sets, harvested lazily into cumulative kernel times (no per-step host sync)
     static constexpr int RING = 32;
+    hipEvent_t evRebuild[2] = {nullptr, nullptr};
     struct EvSet { hipEvent_t e[5]; bool pending = false; };   // start, direct0, direct1(=recip0 after pair lists), recip1, end
     std::vector<EvSet> ring; int ringPos = 0;
     // host-side definition
@@ -245,6 +246,7 @@ public:
         (void)hipStreamSynchronize(stream);
         dropGraph();
         for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
+        for (int k = 0; k < 2; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
         if (ownStream) (void)hipStreamDestroy(stream);
     }
     // Bt(r^2) = [erf(ar) - 2ar/sqrt(pi) exp(-(ar)^2)] / r^3  (bounded, smooth; Bt(0) = 4 a^3 / (3 sqrt(pi))): the real-space Ewald
@@ -717,7 +719,10 @@ public:
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p;
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.workItems = workItems.p; p.workItemsPartial = workItemsPartial.p; p.counters = dCounters.p;
             p.tileCapacity = (int)tileCap; p.workCapacity = (int)(tileCap / 4 + 2 * numBlocks + 16); p.maskCapacity = (int)tileCap;
+            if (!evRebuild[0]) { HIPCHECK(hipEventCreate(&evRebuild[0])); HIPCHECK(hipEventCreate(&evRebuild[1])); }
+            HIPCHECK(hipEventRecord(evRebuild[0], stream));
             launchNeighborBuild<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream);
+            HIPCHECK(hipEventRecord(evRebuild[1], stream));
             int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(h), hipMemcpyDeviceToHost, stream));
             HIPCHECK(hipStreamSynchronize(stream));
@@ -728,7 +733,10 @@ public:
                 gpuBuilt = true;
                 needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;
                 stats.n_rebuilds++;
-                stats.last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                float gpuMs = 0;   // device time of the build (the host clock would also count the queued steps this call waited for)
+                HIPCHECK(hipEventElapsedTime(&gpuMs, evRebuild[0], evRebuild[1]));
+                stats.last_rebuild_ms = gpuMs;
+                (void)t0;
                 return true;
             }
             if (getenv("SNB_VERBOSE")) fprintf(stderr, "[snb] gpu neighbour build attempt %d: tiles %d work %d masks %d overflow %d (cap %zu)\n", attempt, h[0], h[1], h[2], h[3], tileCap);

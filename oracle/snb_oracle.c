@@ -809,3 +809,6 @@ int orc_evaluate(const orc_config* cfg, const double* pos, const double* box,
     free(sig); free(eps); free_exclusions(&ex); free(pl.ij);
     return 0;
 }
+
+/* number of OpenMP threads the PME sections of the oracle use (the pair loop is serial, like the reference's) */
+int orc_num_threads(void) { return omp_get_max_threads(); }

@@ -83,7 +83,11 @@ void orc_fft3d(double* data, int nx, int ny, int nz, int sign);
 /* Number of within-cutoff, non-excluded pairs found by the last orc_evaluate() in this thread's process. */
 long long orc_last_pair_count(void);
 
+/* OpenMP threads used by the PME sections (the pair loop is serial like the reference's). */
+int orc_num_threads(void);
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif
