@@ -170,72 +170,7 @@ __device__ __forceinline__ void tileSteps(const DirectParams<Real>& p, const typ
 // cost the same either way).  8 steps; at step s lane c meets slots (c-2s) [component .x] and (c-2s-1) [component .y];
 // each component's j-force accumulator follows its slot with a two-lane DPP rotation per step.
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ inline float rowRor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true)); }
-
-template <int MC, bool MASKED, bool TABLE>
-__device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float2* __restrict__ tab, const float4* rdPos, const float2* rdSe, const float4 pi, const float2 sei,
-                                                const float qiS, const float epsiS, const unsigned maskWord, const int c,
-                                                v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz) {
-    v2f ax = {0.f, 0.f}, ay = {0.f, 0.f}, az = {0.f, 0.f};      // j-force accumulators: .x follows slot c-2s, .y slot c-2s-1
-    const v2f pix = {pi.x, pi.x}, piy = {pi.y, pi.y}, piz = {pi.z, pi.z};
-#pragma unroll 2
-    for (int s = 0; s < 8; s++) {
-        const float4 xa = rdPos[-2 * s], xb = rdPos[-2 * s - 1];
-        const float2 sa = rdSe[-2 * s], sb = rdSe[-2 * s - 1];
-        const v2f dx = pix - (v2f){xa.x, xb.x}, dy = piy - (v2f){xa.y, xb.y}, dz = piz - (v2f){xa.z, xb.z};
-        const v2f r2 = dx * dx + dy * dy + dz * dz;
-        const v2f invR = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
-        // Lennard-Jones
-        const v2f sig = (v2f){sei.x, sei.x} + (v2f){sa.x, sb.x};
-        v2f s2 = sig * invR; s2 = s2 * s2;
-        const v2f s6 = s2 * s2 * s2;
-        const v2f es6 = ((v2f){epsiS, epsiS} * (v2f){sa.y, sb.y}) * s6;
-        v2f f = es6 * (s6 * 12.0f - 6.0f);
-        // Coulomb
-        const v2f qq = (v2f){qiS, qiS} * (v2f){xa.w, xb.w};
-        if (MC == MC_EWALD && TABLE) {
-            // real-space Ewald force factor  [erfc(ar) + 2ar/sqrt(pi) e^{-(ar)^2}] / r^3 = 1/r^3 - Bt(r^2): the smooth, bounded part
-            // Bt is tabulated over r^2 in LDS (linear interpolation, error < 3e-7 relative to Bt); replaces exp + rcp + 9 VALU ops
-            const v2f u = r2 * p.tabScale;
-            const v2f fl = {__builtin_floorf(u.x), __builtin_floorf(u.y)};
-            const v2f fr = u - fl;
-            int ia = (int)fl.x, ib = (int)fl.y;
-            ia = ia < p.tabN ? ia : p.tabN; ib = ib < p.tabN ? ib : p.tabN;
-            const float2 ta = tab[ia], tb = tab[ib];
-            const v2f bt = (v2f){ta.x, tb.x} + fr * (v2f){ta.y, tb.y};
-            const v2f invR2 = invR * invR;
-            f = f * invR2 + qq * (invR * invR2 - bt);
-        } else if (MC == MC_EWALD) {
-            const v2f r = r2 * invR;
-            const v2f ar = r * p.alpha;
-            const v2f e2 = r2 * (-p.alpha2l2e);
-            const v2f ex = {__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
-            const v2f den = ar * 0.3275911f + 1.0f;
-            const v2f tt = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-            v2f poly = tt * 1.061405429f + (-1.453152027f);
-            poly = poly * tt + 1.421413741f;
-            poly = poly * tt + (-0.284496736f);
-            poly = poly * tt + 0.254829592f;
-            const v2f erfcv = poly * tt * ex;
-            f = f + (qq * invR) * (erfcv + (ar * ex) * 1.1283791670955126f);
-        } else if (MC == MC_RF) {
-            f = f + qq * (invR - r2 * (2.0f * p.krf));
-        } else {
-            f = f + qq * invR;
-        }
-        if (!(MC == MC_EWALD && TABLE)) f = f * (invR * invR);
-        bool inA = MC == MC_NOCUTOFF ? true : (r2.x < p.cutoff2), inB = MC == MC_NOCUTOFF ? true : (r2.y < p.cutoff2);
-        if (MASKED) { inA = inA && !((maskWord >> ((c - 2 * s) & 15)) & 1u); inB = inB && !((maskWord >> ((c - 2 * s - 1) & 15)) & 1u); }
-        f.x = inA ? f.x : 0.0f; f.y = inB ? f.y : 0.0f;
-        const v2f gx = f * dx, gy = f * dy, gz = f * dz;
-        fix = fix + gx; fiy = fiy + gy; fiz = fiz + gz;
-        ax = (v2f){rowRor2(ax.x), rowRor2(ax.y)} - gx;
-        ay = (v2f){rowRor2(ay.x), rowRor2(ay.y)} - gy;
-        az = (v2f){rowRor2(az.x), rowRor2(az.y)} - gz;
-    }
-    // bring every slot home: component .x sits two lanes ahead, component .y one lane ahead
-    fjx = rowRor2(ax.x) + rowRor1(ax.y); fjy = rowRor2(ay.x) + rowRor1(ay.y); fjz = rowRor2(az.x) + rowRor1(az.y);
-}
+__device__ inline float rowRor8(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); }
 
 // ---- the tile kernel ----------------------------------------------------------------------------
 // Work item = (i-block, run of <= 8 tiles).  Lane layout: 4 DPP rows of 16 lanes; row r works on the 16x16 sub-tile
@@ -249,14 +184,6 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
     using T2 = typename Vec<Real>::T2;
     __shared__ T4 s_pos[4][64];
     __shared__ T2 s_se[4][64];
-    extern __shared__ __align__(16) unsigned char s_tabRaw[];
-    const float2* tab = reinterpret_cast<const float2*>(s_tabRaw);
-    constexpr bool kTable = std::is_same<Real, float>::value && !ENERGY && !WRAP && MC == MC_EWALD;
-    if (kTable && p.tabN > 0) {     // stage the Ewald force table once per work-group (work-groups loop over work items)
-        float2* w = reinterpret_cast<float2*>(s_tabRaw);
-        for (int k = threadIdx.x; k <= p.tabN; k += 256) w[k] = p.ewaldTable[k];
-        __syncthreads();
-    }
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -284,8 +211,9 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
     const T4* rdPos = myPos + 32 * jh + c + 16;          // entry for step s is rdPos[-s]
     const T2* rdSe = mySe + 32 * jh + c + 16;
 
-    // software pipeline: the j-atoms of tile t+1 are fetched while tile t is computed
-    int jcode = p.tileJ[tBegin * 32 + stageJ];
+    // software pipeline, two tiles deep: while tile t is computed the j-atoms, mask word and lambdas of tile t+1 are in flight
+    // (their addresses come from tileJ/tileInfo words loaded one tile earlier) and the tileJ/tileInfo words of tile t+2 are
+    // requested, so no load at the head of a tile waits on another load
     T4 pj; T2 sej;
     auto fetch = [&](int code, T4& x, T2& se) {
         if (code != -1) {   // -1 = padding slot (image codes use bits 27..31, so the sign bit is NOT a validity flag)
@@ -297,19 +225,37 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
             }
         } else { x.x = Real(3e9) + Real(1e6) * c; x.y = Real(-5e9); x.z = Real(7e9); x.w = 0; se.x = 0; se.y = 0; }
     };
+    struct TileHead { int sj, maskIdx; };
+    auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x, v.y}; };
+    auto loadMask = [&](const TileHead& h) { return (h.maskIdx >= 0 && !(p.dbg & 4)) ? p.masks[h.maskIdx * 32 + il] : 0u; };
+    int jcode = p.tileJ[tBegin * 32 + stageJ];
+    TileHead head = loadHead(tBegin);
+    int jcodeNext = -1; TileHead headNext = head;
+    if (tBegin + 1 < tEnd) { jcodeNext = p.tileJ[(tBegin + 1) * 32 + stageJ]; headNext = loadHead(tBegin + 1); }
     fetch(jcode, pj, sej);
+    unsigned maskPre = loadMask(head);
+    int slicePre = sliceOf(si, head.sj);
+    Real lamCPre = p.lambdas[2 * slicePre], lamLPre = p.lambdas[2 * slicePre + 1];
 
     for (int t = tBegin; t < tEnd; t++) {
-        const int4 info = p.tileInfo[t];
         __builtin_amdgcn_wave_barrier();
         myPos[lane] = pj; mySe[lane] = sej;
         const int curCode = jcode;
+        const bool hasMask = head.maskIdx >= 0 && !(p.dbg & 4);
+        unsigned maskWord = maskPre;
+        const int slice = slicePre;
+        const Real lamC = lamCPre, lamL = lamLPre;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (t + 1 < tEnd) { jcode = p.tileJ[(t + 1) * 32 + stageJ]; fetch(jcode, pj, sej); }
+        jcode = jcodeNext; head = headNext;
+        if (t + 1 < tEnd) {
+            fetch(jcode, pj, sej);
+            maskPre = loadMask(head);
+            slicePre = sliceOf(si, head.sj);
+            lamCPre = p.lambdas[2 * slicePre]; lamLPre = p.lambdas[2 * slicePre + 1];
+        }
+        if (t + 2 < tEnd) { jcodeNext = p.tileJ[(t + 2) * 32 + stageJ]; headNext = loadHead(t + 2); }
 
-        const int sj = info.x;
-        const int slice = sliceOf(si, sj);
         if (ENERGY && slice != curSlice) {
             if (curSlice >= 0) {
                 double a = waveSum((double)ecl), b = waveSum((double)elj);
@@ -317,31 +263,12 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
             }
             ecl = 0; elj = 0; curSlice = slice;
         }
-        const Real lamC = p.lambdas[2 * slice], lamL = p.lambdas[2 * slice + 1];
-        const bool hasMask = info.y >= 0;
-        unsigned maskWord = hasMask ? p.masks[info.y * 32 + il] : 0u;
         maskWord >>= 16 * jh;                            // my j-half's 16 bits
         // lambda folded into the i-side parameters once per tile (forces only need the scaled values)
         const Real qiS = qi * lamC;
         const Real epsiS = sei.y * lamL;
         Real fjx = 0, fjy = 0, fjz = 0;
 
-        bool donePacked = false;
-        if constexpr (std::is_same<Real, float>::value && !ENERGY && !WRAP && MC != MC_LJPME) {
-            if (!p.useSwitch) {
-                v2f pfx = {0.f, 0.f}, pfy = {0.f, 0.f}, pfz = {0.f, 0.f};
-                if (kTable && p.tabN > 0) {
-                    if (hasMask) tileStepsPacked<MC, true, true>(p, tab, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
-                    else tileStepsPacked<MC, false, true>(p, tab, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
-                } else {
-                    if (hasMask) tileStepsPacked<MC, true, false>(p, tab, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
-                    else tileStepsPacked<MC, false, false>(p, tab, rdPos, rdSe, pi, sei, qiS, epsiS, maskWord, c, pfx, pfy, pfz, fjx, fjy, fjz);
-                }
-                fix += pfx.x + pfx.y; fiy += pfy.x + pfy.y; fiz += pfz.x + pfz.y;
-                donePacked = true;
-            }
-        }
-        if (!donePacked) {
         if (p.useSwitch && MC != MC_LJPME && MC != MC_NOCUTOFF) {
                 if (hasMask) tileSteps<Real, MC, WRAP, ENERGY, true, true>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
                 else tileSteps<Real, MC, WRAP, ENERGY, false, true>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
@@ -350,11 +277,10 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
                 else tileSteps<Real, MC, WRAP, ENERGY, false, false>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
             }
             // rotate-then-add leaves lane c holding slot c+1: one more rotation brings every slot home
-            fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
-        }
+        fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
         // add the two i-halves (rows r and r^1) and flush
         fjx += __shfl_xor(fjx, 16, 64); fjy += __shfl_xor(fjy, 16, 64); fjz += __shfl_xor(fjz, 16, 64);
-        if ((row & 1) == 0 && curCode != -1) {            // lanes 0-15 (j-half 0) and 32-47 (j-half 1): entry `lane` == j-slot
+        if ((row & 1) == 0 && curCode != -1 && !(p.dbg & 1)) {            // lanes 0-15 (j-half 0) and 32-47 (j-half 1): entry `lane` == j-slot
             const int jidx = curCode & SNB_JIDX_MASK;
             gAdd(&p.fx[jidx], fjx); gAdd(&p.fy[jidx], fjy); gAdd(&p.fz[jidx], fjz);
         }
@@ -370,21 +296,168 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
     }   // work-item loop
 }
 
+// ---- single-precision forces-only tile kernel with packed math ---------------------------------------
+// Same work items, tiles and masks as k_direct, different lane layout: lane (row r, column c) holds TWO i-atoms (c and c+16)
+// as the halves of float2 registers and meets ONE j-slot per step, slot 8r + ((c - s) & 7) of j-quarter r, for 8 steps.
+// All pair arithmetic issues as v_pk_*_f32 on (i_c, j) and (i_c+16, j): the j-side operands are broadcast by op_sel (no register
+// shuffling), the i-side operands are packed once per work item, and one LDS read (b128 + b64) feeds two pair slots.  The
+// j-force accumulator travels with its slot by a one-lane row rotation fused into the subtract (v_sub_f32_dpp); lanes c and
+// c+8 carry two partial sums of the same slot and are merged by an 8-lane rotation at the end of the tile.
+// Staging: entry e (0..15) of quarter r holds atom 8r + (e & 7), so the rotated read index (c & 7) + 8 - s needs no wrap.
+template <int MC, bool MASKED>
+__device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float4* rdPos, const float2* rdSe, const v2f pix, const v2f piy, const v2f piz,
+                                                const v2f sigi, const v2f qiS, const v2f epsiS, const unsigned maskA, const unsigned maskB, const int c,
+                                                v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz) {
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const float4 xj = rdPos[-s];
+        const float2 sj = rdSe[-s];
+        const v2f dx = pix - xj.x, dy = piy - xj.y, dz = piz - xj.z;
+        const v2f r2 = dx * dx + dy * dy + dz * dz;
+        const v2f invR = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+        // Lennard-Jones (sigeps holds sigma/2 and 2 sqrt(eps))
+        v2f s2 = (sigi + sj.x) * invR; s2 = s2 * s2;
+        const v2f s6 = s2 * s2 * s2;
+        const v2f es6 = (epsiS * sj.y) * s6;
+        v2f f = es6 * (s6 * 12.0f - 6.0f);
+        // Coulomb
+        const v2f qq = qiS * xj.w;
+        if (MC == MC_EWALD) {
+            const v2f r = r2 * invR;
+            const v2f ar = r * p.alpha;
+            const v2f e2 = r2 * (-p.alpha2l2e);
+            const v2f ex = {__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
+            const v2f den = ar * 0.3275911f + 1.0f;
+            const v2f tt = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            v2f poly = tt * 1.061405429f + (-1.453152027f);
+            poly = poly * tt + 1.421413741f;
+            poly = poly * tt + (-0.284496736f);
+            poly = poly * tt + 0.254829592f;
+            const v2f erfcv = poly * tt * ex;
+            f = f + (qq * invR) * (erfcv + (ar * ex) * 1.1283791670955126f);
+        } else if (MC == MC_RF) {
+            f = f + qq * (invR - r2 * (2.0f * p.krf));
+        } else {
+            f = f + qq * invR;
+        }
+        f = f * (invR * invR);
+        bool inA = MC == MC_NOCUTOFF ? true : (r2.x < p.cutoff2), inB = MC == MC_NOCUTOFF ? true : (r2.y < p.cutoff2);
+        if (MASKED) { const int k = (c - s) & 7; inA = inA && !((maskA >> k) & 1u); inB = inB && !((maskB >> k) & 1u); }
+        f.x = inA ? f.x : 0.0f; f.y = inB ? f.y : 0.0f;
+        const v2f gx = f * dx, gy = f * dy, gz = f * dz;
+        fix = fix + gx; fiy = fiy + gy; fiz = fiz + gz;
+        fjx = rowRor1(fjx) - (gx.x + gx.y); fjy = rowRor1(fjy) - (gy.x + gy.y); fjz = rowRor1(fjz) - (gz.x + gz.y);
+    }
+}
+
+template <int MC>
+__global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<float> p) {
+    __shared__ float4 s_pos[4][64];
+    __shared__ float2 s_se[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int item = blockIdx.x * 4 + wid; item < p.numWork; item += gridDim.x * 4) {   // no block-level barrier inside the loop
+    const int4 wi = p.workItems[p.workStart + item * p.workStride];
+    const int I = __builtin_amdgcn_readfirstlane(wi.x);
+    const int tBegin = __builtin_amdgcn_readfirstlane(wi.y), tEnd = tBegin + __builtin_amdgcn_readfirstlane(wi.z);
+    const int c = lane & 15, row = lane >> 4;
+    const int stageJ = 8 * row + (c & 7);                // j-atom this lane stages (entry c of quarter `row`)
+
+    const float4 pa = p.posq[I * 32 + c], pb = p.posq[I * 32 + 16 + c];
+    const float2 sa = p.sigeps[I * 32 + c], sb = p.sigeps[I * 32 + 16 + c];
+    const int si = p.blockSubset[I];
+    const v2f pix = {pa.x, pb.x}, piy = {pa.y, pb.y}, piz = {pa.z, pb.z};
+    const v2f qi = {pa.w * p.k4pe, pb.w * p.k4pe}, sigi = {sa.x, sb.x}, epsi = {sa.y, sb.y};
+    v2f fix = {0.f, 0.f}, fiy = {0.f, 0.f}, fiz = {0.f, 0.f};
+
+    float4* myPos = s_pos[wid];
+    float2* mySe = s_se[wid];
+    const float4* rdPos = myPos + 16 * row + (c & 7) + 8;   // entry for step s is rdPos[-s]
+    const float2* rdSe = mySe + 16 * row + (c & 7) + 8;
+
+    // two-tile-deep software pipeline, as in k_direct
+    float4 pj; float2 sej;
+    auto fetch = [&](int code, float4& x, float2& se) {
+        if (code != -1) {
+            const int idx = code & SNB_JIDX_MASK;
+            x = p.posq[idx]; se = p.sigeps[idx];
+            const int sc = (code >> SNB_JSHIFT_BITS) & 31;
+            x.x += p.shifts[sc * 3]; x.y += p.shifts[sc * 3 + 1]; x.z += p.shifts[sc * 3 + 2];
+        } else { x.x = 3e9f + 1e6f * c; x.y = -5e9f; x.z = 7e9f; x.w = 0; se.x = 0; se.y = 0; }
+    };
+    struct TileHead { int sj, maskIdx; };
+    auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x, v.y}; };
+    int jcode = p.tileJ[tBegin * 32 + stageJ];
+    TileHead head = loadHead(tBegin);
+    int jcodeNext = -1; TileHead headNext = head;
+    if (tBegin + 1 < tEnd) { jcodeNext = p.tileJ[(tBegin + 1) * 32 + stageJ]; headNext = loadHead(tBegin + 1); }
+    fetch(jcode, pj, sej);
+    unsigned maskAPre = 0, maskBPre = 0;
+    if (head.maskIdx >= 0) { maskAPre = p.masks[head.maskIdx * 32 + c]; maskBPre = p.masks[head.maskIdx * 32 + 16 + c]; }
+    int slicePre = sliceOf(si, head.sj);
+    float lamCPre = p.lambdas[2 * slicePre], lamLPre = p.lambdas[2 * slicePre + 1];
+
+    for (int t = tBegin; t < tEnd; t++) {
+        __builtin_amdgcn_wave_barrier();
+        myPos[lane] = pj; mySe[lane] = sej;
+        const int curCode = jcode;
+        const bool hasMask = head.maskIdx >= 0;
+        const unsigned maskA = maskAPre >> (8 * row), maskB = maskBPre >> (8 * row);   // my j-quarter's 8 bits
+        const float lamC = lamCPre, lamL = lamLPre;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        jcode = jcodeNext; head = headNext;
+        if (t + 1 < tEnd) {
+            fetch(jcode, pj, sej);
+            maskAPre = 0; maskBPre = 0;
+            if (head.maskIdx >= 0) { maskAPre = p.masks[head.maskIdx * 32 + c]; maskBPre = p.masks[head.maskIdx * 32 + 16 + c]; }
+            slicePre = sliceOf(si, head.sj);
+            lamCPre = p.lambdas[2 * slicePre]; lamLPre = p.lambdas[2 * slicePre + 1];
+        }
+        if (t + 2 < tEnd) { jcodeNext = p.tileJ[(t + 2) * 32 + stageJ]; headNext = loadHead(t + 2); }
+
+        // lambda folded into the i-side parameters once per tile
+        const v2f qiS = qi * lamC, epsiS = epsi * lamL;
+        float fjx = 0, fjy = 0, fjz = 0;
+        if (hasMask) tileStepsPacked<MC, true>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz);
+        else tileStepsPacked<MC, false>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz);
+        // rotate-then-subtract leaves lane c holding slot (c+1)&7: one more rotation brings every slot home, then the two
+        // partial sums of a slot (lanes c and c+8) are merged
+        fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
+        fjx += rowRor8(fjx); fjy += rowRor8(fjy); fjz += rowRor8(fjz);
+        if (c < 8 && curCode != -1) {                    // entry c < 8 of quarter `row` == j-slot 8*row + c == the atom this lane staged
+            const int jidx = curCode & SNB_JIDX_MASK;
+            gAdd(&p.fx[jidx], fjx); gAdd(&p.fy[jidx], fjy); gAdd(&p.fz[jidx], fjz);
+        }
+    }
+    // the four rows hold partial sums for the same i-atoms (different j-quarters)
+    float ox = fix.x, oy = fiy.x, oz = fiz.x, ux = fix.y, uy = fiy.y, uz = fiz.y;
+    ox += __shfl_xor(ox, 16, 64); oy += __shfl_xor(oy, 16, 64); oz += __shfl_xor(oz, 16, 64);
+    ux += __shfl_xor(ux, 16, 64); uy += __shfl_xor(uy, 16, 64); uz += __shfl_xor(uz, 16, 64);
+    ox += __shfl_xor(ox, 32, 64); oy += __shfl_xor(oy, 32, 64); oz += __shfl_xor(oz, 32, 64);
+    ux += __shfl_xor(ux, 32, 64); uy += __shfl_xor(uy, 32, 64); uz += __shfl_xor(uz, 32, 64);
+    if (row == 0) { gAdd(&p.fx[I * 32 + c], ox); gAdd(&p.fy[I * 32 + c], oy); gAdd(&p.fz[I * 32 + c], oz); }
+    if (row == 1) { gAdd(&p.fx[I * 32 + 16 + c], ux); gAdd(&p.fy[I * 32 + 16 + c], uy); gAdd(&p.fz[I * 32 + 16 + c], uz); }
+    __builtin_amdgcn_wave_barrier();
+    }   // work-item loop
+}
+
+
 template <typename Real, int MC> static void launchDirectMC(const DirectParams<Real>& p, bool wrap, bool energy, hipStream_t s) {
     const int myItems = p.numWork;
     if (myItems <= 0) return;
     int nwg = (myItems + 3) / 4;
-    const bool table = std::is_same<Real, float>::value && !energy && !wrap && MC == MC_EWALD && p.tabN > 0;
-    // with the table every work-group first stages 16 KB, so work-groups are made persistent-ish: 256 CUs x 4 resident groups, looping
-    if (table && nwg > 256 * 4 * 2) nwg = 256 * 4 * 2;
-    const size_t lds = table ? sizeof(float2) * (size_t)(p.tabN + 1) : 0;
+    { static const int cap = getenv("SNB_DIRECT_WGS") ? atoi(getenv("SNB_DIRECT_WGS")) : 0; if (cap > 0 && nwg > cap) nwg = cap; }
     dim3 grid(nwg), block(256);
+    if constexpr (std::is_same<Real, float>::value && MC != MC_LJPME) {
+        if (!wrap && !energy && !p.useSwitch) { hipLaunchKernelGGL((k_directPacked<MC>), grid, block, 0, s, p); return; }
+    }
     if (wrap) {
         if (energy) hipLaunchKernelGGL((k_direct<Real, MC, true, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((k_direct<Real, MC, true, false>), grid, block, 0, s, p);
     } else {
         if (energy) hipLaunchKernelGGL((k_direct<Real, MC, false, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((k_direct<Real, MC, false, false>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((k_direct<Real, MC, false, false>), grid, block, 0, s, p);
     }
 }
 

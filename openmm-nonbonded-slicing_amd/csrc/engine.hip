@@ -847,6 +847,7 @@ public:
             p.alpha = (Real)cfg.alpha; p.alphaD = (Real)cfg.alpha_d; p.k4pe = (Real)SNB_ONE_4PI_EPS0;
             p.alpha2l2e = (Real)(cfg.alpha * cfg.alpha * 1.4426950408889634);
             p.ewaldTable = ewaldTable.p; p.tabN = ewaldTabN; p.tabScale = ewaldTabScale;
+            { static const int dbgBits = getenv("SNB_DBG") ? atoi(getenv("SNB_DBG")) : 0; p.dbg = dbgBits; }
             const double ic2 = 1.0 / (cfg.cutoff * cfg.cutoff), ic6 = ic2 * ic2 * ic2;
             const double dar2 = cfg.alpha_d * cfg.alpha_d * cfg.cutoff * cfg.cutoff;
             p.invCut6 = (Real)ic6; p.multShift6 = (Real)(ic6 * (1.0 - std::exp(-dar2) * (1.0 + dar2 + 0.5 * dar2 * dar2)));
