@@ -412,43 +412,66 @@ __device__ inline Cx<Real>* fftLines(Cx<Real>* a, Cx<Real>* b, int n, const int*
 
 extern __shared__ __align__(16) unsigned char s_dyn[];
 
-// ---- z axis: real <-> half-complex.  One work-group transforms NL contiguous lines. ----------------
+// x / d for 0 <= x < 2^22 without the ~35-instruction integer division: (x + 0.5) * (1/d) never lands within rounding error of an integer
+struct FastDiv {
+    float inv; int d;
+    __device__ explicit FastDiv(int d_) : inv(1.0f / (float)d_), d(d_) {}
+    __device__ int div(int x) const { return (int)(((float)x + 0.5f) * inv); }
+};
+
+// ---- z axis: real <-> half-complex.  One work-group transforms NL contiguous real lines, TWO PER COMPLEX FFT: lines 2c and 2c+1
+// travel as the real and imaginary part of complex line c (z = a + i b, Z = A + i B with A, B Hermitian), so the z passes do half
+// the butterflies of a zero-imaginary transform.  forward: A_k = (Z_k + conj Z_{n-k})/2, B_k = (Z_k - conj Z_{n-k})/(2i);
+// inverse: Z_k = A_k + i B_k for k <= n/2 and conj(A_{n-k}) + i conj(B_{n-k}) above, then a = Re z, b = Im z.
 template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bounds__(256) void k_fftZ(const PmeParams<Real> p, int NL) {
     const int nz = p.d.nz, nzc = p.d.nzc;
-    const int BS = NL + 1;   // padded batch stride (bank spread for the transposing LDS accesses)
+    const int NC = NL >> 1;
+    const int BS = NC + 1;   // padded batch stride (bank spread for the transposing LDS accesses)
     Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
     Cx<Real>* B = A + (size_t)nz * BS;
     Cx<Real>* tw = B + (size_t)nz * BS;                 // roots of unity staged in LDS (the butterflies index them per item)
     const size_t nlines = (size_t)p.nsub * p.d.nx * p.d.ny;
     const size_t line0 = (size_t)blockIdx.x * NL;
-    const int nb = (int)((nlines - line0) < (size_t)NL ? (nlines - line0) : (size_t)NL);
+    const int nl = (int)((nlines - line0) < (size_t)NL ? (nlines - line0) : (size_t)NL);   // real lines here
+    const int nb = (nl + 1) >> 1;                                                           // complex lines here
     const int tid = threadIdx.x;
+    const FastDiv dz(nz), dzc(nzc);
     for (int k = tid; k < nz; k += 256) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
     if (FORWARD) {
+        const Real* in = p.gridReal + line0 * nz;
         for (int it = tid; it < nb * nz; it += 256) {
-            const int l = it / nz, k = it - l * nz;
-            A[k * BS + l] = {p.gridReal[(line0 + l) * nz + k], Real(0)};
+            const int c = dz.div(it), k = it - c * nz;
+            const Real a = in[(2 * c) * nz + k];
+            const Real b = (2 * c + 1 < nl) ? in[(2 * c + 1) * nz + k] : Real(0);
+            A[k * BS + c] = {a, b};
         }
         Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, 256);
         __syncthreads();
-        Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.gridCplx);
+        Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.gridCplx) + line0 * nzc;
         for (int it = tid; it < nb * nzc; it += 256) {
-            const int l = it / nzc, k = it - l * nzc;
-            out[(line0 + l) * nzc + k] = R[k * BS + l];
+            const int c = dzc.div(it), k = it - c * nzc;
+            const Cx<Real> z = R[k * BS + c], m = R[(k == 0 ? 0 : nz - k) * BS + c];
+            out[(2 * c) * nzc + k] = {Real(0.5) * (z.x + m.x), Real(0.5) * (z.y - m.y)};
+            if (2 * c + 1 < nl) out[(2 * c + 1) * nzc + k] = {Real(0.5) * (z.y + m.y), Real(0.5) * (m.x - z.x)};
         }
     } else {
-        const Cx<Real>* in = reinterpret_cast<const Cx<Real>*>(p.gridCplx);
+        const Cx<Real>* in = reinterpret_cast<const Cx<Real>*>(p.gridCplx) + line0 * nzc;
         for (int it = tid; it < nb * nzc; it += 256) {
-            const int l = it / nzc, k = it - l * nzc;
-            const Cx<Real> v = in[(line0 + l) * nzc + k];
-            A[k * BS + l] = v;
-            if (k > 0 && nz - k >= nzc) A[(nz - k) * BS + l] = {v.x, -v.y};   // Hermitian half
+            const int c = dzc.div(it), k = it - c * nzc;
+            const Cx<Real> a = in[(2 * c) * nzc + k];
+            Cx<Real> b = {Real(0), Real(0)};
+            if (2 * c + 1 < nl) b = in[(2 * c + 1) * nzc + k];
+            A[k * BS + c] = {a.x - b.y, a.y + b.x};                                         // A_k + i B_k
+            if (k > 0 && nz - k >= nzc) A[(nz - k) * BS + c] = {a.x + b.y, b.x - a.y};      // conj(A_k) + i conj(B_k)
         }
         Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, +1, tw, nb, BS, tid, 256);
         __syncthreads();
+        Real* out = p.gridReal + line0 * nz;
         for (int it = tid; it < nb * nz; it += 256) {
-            const int l = it / nz, k = it - l * nz;
-            p.gridReal[(line0 + l) * nz + k] = R[k * BS + l].x;
+            const int c = dz.div(it), k = it - c * nz;
+            const Cx<Real> z = R[k * BS + c];
+            out[(2 * c) * nz + k] = z.x;
+            if (2 * c + 1 < nl) out[(2 * c + 1) * nz + k] = z.y;
         }
     }
 }
@@ -466,14 +489,15 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(256) void 
     Cx<Real>* g = reinterpret_cast<Cx<Real>*>(p.gridCplx) + (size_t)a * strideA + b0;
     const int tid = threadIdx.x;
     for (int k = tid; k < n; k += 256) tw[k] = reinterpret_cast<const Cx<Real>*>(axis == 1 ? p.twy : p.twx)[k];
+    const FastDiv dnb(nb);
     for (int it = tid; it < n * nb; it += 256) {
-        const int k = it / nb, b = it - k * nb;
+        const int k = dnb.div(it), b = it - k * nb;
         A[k * NB + b] = g[(size_t)k * strideK + b];
     }
     Cx<Real>* R = fftLines<Real, R1, R2>(A, B, n, axis == 1 ? p.d.fy : p.d.fx, axis == 1 ? p.d.nfy : p.d.nfx, sign, tw, nb, NB, tid, 256);
     __syncthreads();
     for (int it = tid; it < n * nb; it += 256) {
-        const int k = it / nb, b = it - k * nb;
+        const int k = dnb.div(it), b = it - k * nb;
         g[(size_t)k * strideK + b] = R[k * NB + b];
     }
 }
@@ -524,9 +548,10 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
     Cx<Real>* g = reinterpret_cast<Cx<Real>*>(p.gridCplx);
     const int tid = threadIdx.x;
     // load: when nbc < NB the unused batch slots are zero-filled so the FFT can run on the full batch shape
+    const FastDiv dBS(BS), dNB(NB), dNzc(p.d.nzc);
     for (int it = tid; it < nx * BS; it += NT) {
-        const int k = it / BS, bb = it - k * BS;
-        const int sub = bb / NB, col = bb - sub * NB;
+        const int k = dBS.div(it), bb = it - k * BS;
+        const int sub = dNB.div(bb), col = bb - sub * NB;
         Cx<Real> v = {Real(0), Real(0)};
         if (col < nbc) v = g[sub * strideSub + (size_t)k * strideK + c0 + col];
         A[k * BS + bb] = v;
@@ -537,11 +562,11 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
     __syncthreads();
     // eterm per (kx, col)
     for (int it = tid; it < nx * NB; it += NT) {
-        const int kx = it / NB, col = it - kx * NB;
+        const int kx = dNB.div(it), col = it - kx * NB;
         Real e = 0;
         if (col < nbc) {
             const int c = c0 + col;
-            const int ky = c / p.d.nzc, kz = c - ky * p.d.nzc;
+            const int ky = dNzc.div(c), kz = c - ky * p.d.nzc;
             e = recipTerm<Real>(p, kx, ky, kz);
         }
         et[it] = e;
@@ -555,9 +580,9 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
             for (int J = 0; J <= I; J++) {
                 double acc = 0;
                 for (int it = tid; it < nx * NB; it += NT) {
-                    const int kx = it / NB, col = it - kx * NB;
+                    const int kx = dNB.div(it), col = it - kx * NB;
                     if (col >= nbc) continue;
-                    const int kz = (c0 + col) % p.d.nzc;
+                    const int kz = (c0 + col) - dNzc.div(c0 + col) * p.d.nzc;
                     const Real w = (kz == 0 || (2 * kz == p.d.nz)) ? Real(1) : Real(2);
                     const Cx<Real> a = S[kx * BS + I * NB + col], b = S[kx * BS + J * NB + col];
                     acc += (double)(w * et[it] * (a.x * b.x + a.y * b.y));
@@ -605,7 +630,7 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
             for (int g = wave; g < nGroups; g += nWaves) {
                 const int pt = 16 * g + ai;
                 const bool valid = pt < nPts;
-                const int k = pt / (2 * NB), rem = pt - k * 2 * NB, col = rem >> 1, c = rem & 1;
+                const int k = dNB.div(pt >> 1), rem = pt - k * 2 * NB, col = rem >> 1, c = rem & 1;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kc = 0; kc < 4; kc++) {
@@ -627,8 +652,8 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
     if (!mixedOnMatrixCores) {
         const int term = p.dispersion ? 1 : 0;
         for (int it = tid; it < nx * BS; it += NT) {
-            const int k = it / BS, bb = it - k * BS;
-            const int I = bb / NB, col = bb - I * NB;
+            const int k = dBS.div(it), bb = it - k * BS;
+            const int I = dNB.div(bb), col = bb - I * NB;
             Cx<Real> acc = {Real(0), Real(0)};
             if (p.mix) {
                 const int gi = p.gridSubset[I];
@@ -648,8 +673,8 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
     Cx<Real>* R = fftLines<Real, R1, R2>(O, S, nx, p.d.fx, p.d.nfx, +1, tw, BS, BS, tid, NT);
     __syncthreads();
     for (int it = tid; it < nx * BS; it += NT) {
-        const int k = it / BS, bb = it - k * BS;
-        const int sub = bb / NB, col = bb - sub * NB;
+        const int k = dBS.div(it), bb = it - k * BS;
+        const int sub = dNB.div(bb), col = bb - sub * NB;
         if (col < nbc) g[sub * strideSub + (size_t)k * strideK + c0 + col] = R[it];
     }
 }
@@ -691,10 +716,11 @@ template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipS
     const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc;
     // z: real -> half complex
     {
-        int NL = pickBatch<Real>((size_t)2 * nz * sizeof(Cx<Real>), 17) - 1;   // padded stride NL+1 must be odd
-        NL &= ~1;
-        if (NL < 2) NL = 2;
-        const size_t lds = (size_t)2 * nz * (NL + 1) * sizeof(Cx<Real>) + (size_t)nz * sizeof(Cx<Real>);
+        int NC = pickBatch<Real>((size_t)2 * nz * sizeof(Cx<Real>), 17) - 1;   // complex lines per work-group (two real lines each)
+        NC &= ~1;
+        if (NC < 2) NC = 2;
+        const int NL = 2 * NC;
+        const size_t lds = (size_t)2 * nz * (NC + 1) * sizeof(Cx<Real>) + (size_t)nz * sizeof(Cx<Real>);
         const size_t nlines = (size_t)p.nsub * nx * ny;
         launchFftZ<Real, true>(p.d.rz1, p.d.rz2, dim3((unsigned)((nlines + NL - 1) / NL)), lds, s, p, NL);
     }
@@ -728,10 +754,11 @@ template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipS
         launchFftStrided<Real>(p.d.ry1, p.d.ry2, dim3((unsigned)(p.nsub * nx * tilesPerA)), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB, tilesPerA, +1, 1);
     }
     {
-        int NL = pickBatch<Real>((size_t)2 * nz * sizeof(Cx<Real>), 17) - 1;   // padded stride NL+1 must be odd
-        NL &= ~1;
-        if (NL < 2) NL = 2;
-        const size_t lds = (size_t)2 * nz * (NL + 1) * sizeof(Cx<Real>) + (size_t)nz * sizeof(Cx<Real>);
+        int NC = pickBatch<Real>((size_t)2 * nz * sizeof(Cx<Real>), 17) - 1;   // complex lines per work-group (two real lines each)
+        NC &= ~1;
+        if (NC < 2) NC = 2;
+        const int NL = 2 * NC;
+        const size_t lds = (size_t)2 * nz * (NC + 1) * sizeof(Cx<Real>) + (size_t)nz * sizeof(Cx<Real>);
         const size_t nlines = (size_t)p.nsub * nx * ny;
         launchFftZ<Real, false>(p.d.rz1, p.d.rz2, dim3((unsigned)((nlines + NL - 1) / NL)), lds, s, p, NL);
     }
