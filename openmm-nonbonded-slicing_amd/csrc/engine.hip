@@ -178,6 +178,10 @@ public:
     // ring of per-execute event sets, harvested lazily into cumulative kernel times (no per-step host sync)
     static constexpr int RING = 32;
     hipEvent_t evRebuild[2] = {nullptr, nullptr};
+    hipStream_t stream2 = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // measured on c3: serial 0.80 ms/step, forked 0.87 (default priority) / 1.32 (high or low priority): the graph's cross-stream
+    // dependencies cost more than the overlap returns, so the fork is opt-in
+    bool concurrentPme = getenv("SNB_CONCURRENT_PME") && atoi(getenv("SNB_CONCURRENT_PME"));
     struct EvSet { hipEvent_t e[5]; bool pending = false; };   // start, direct0, direct1(=recip0 after pair lists), recip1, end
     std::vector<EvSet> ring; int ringPos = 0;
     // host-side definition
@@ -247,6 +251,7 @@ public:
         dropGraph();
         for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
         for (int k = 0; k < 2; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
+        if (stream2) { (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); (void)hipStreamDestroy(stream2); }
         if (ownStream) (void)hipStreamDestroy(stream);
     }
     // Bt(r^2) = [erf(ar) - 2ar/sqrt(pi) exp(-(ar)^2)] / r^3  (bounded, smooth; Bt(0) = 4 a^3 / (3 sqrt(pi))): the real-space Ewald
@@ -805,6 +810,12 @@ public:
             GraphKey key{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0};
             if (!graphExec || !(key == graphKey)) {
                 dropGraph();
+                if (!stream2 && concurrentPme) {   // created outside the capture
+                    int lo = 0, hi = 0;
+                    HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                    HIPCHECK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, getenv("SNB_PME_PRIO_LOW") ? lo : (getenv("SNB_PME_PRIO_HIGH") ? hi : (lo + hi) / 2)));
+                    HIPCHECK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
+                }
                 hipGraph_t graph = nullptr;
                 HIPCHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
                 try { enqueueStep(false, includeDirect != 0, includeRecip != 0, nullptr); }
@@ -832,6 +843,15 @@ public:
         HIPCHECK(hipMemsetAsync(forceBuf.p, 0, sizeof(Real) * 6 * Npad, stream));
         if (energy) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2, stream));
         const bool ew = cfg.method >= SNB_Ewald;
+        // Opt-in (SNB_CONCURRENT_PME=1): forces-only graph steps run the reciprocal pipeline on a second stream beside the pair
+        // kernel (disjoint force arrays fx.. / fpx..).  Timed (eager) steps stay serial so the per-kernel event timers stay clean.
+        const bool fork = !ev && !energy && includeDirect && includeRecip && isPme() && nGrids > 0 && concurrentPme && stream2;
+        hipStream_t pmeStream = stream;
+        if (fork) {
+            HIPCHECK(hipEventRecord(evFork, stream));
+            HIPCHECK(hipStreamWaitEvent(stream2, evFork, 0));
+            pmeStream = stream2;
+        }
         if (ev) HIPCHECK(hipEventRecord(ev->e[1], stream));
         if (includeDirect) {
             DirectParams<Real> p;
@@ -886,10 +906,11 @@ public:
                 PmeParams<Real> pp;
                 std::memset(&pp, 0, sizeof(pp));
                 fillPme(pp, pme, energy);
-                runPme(pp);
-                if (cfg.method == SNB_LJPME) { fillPme(pp, dpme, energy); runPme(pp); }
+                runPme(pp, pmeStream);
+                if (cfg.method == SNB_LJPME) { fillPme(pp, dpme, energy); runPme(pp, pmeStream); }
             }
         }
+        if (fork) { HIPCHECK(hipEventRecord(evJoin, stream2)); HIPCHECK(hipStreamWaitEvent(stream, evJoin, 0)); }
         if (includeRecip && cfg.method == SNB_Ewald && cfg.shard_rank == 0) runEwald(energy);
         if (ev) HIPCHECK(hipEventRecord(ev->e[4], stream));
     }
@@ -928,12 +949,12 @@ public:
     }
     void resetTimers() override { for (auto& r : ring) if (r.pending) harvest(r); stats.sum_direct_ms = stats.sum_recip_ms = stats.sum_total_ms = 0; stats.n_timed = 0; }
 
-    void runPme(PmeParams<Real>& pp) {
-        launchPmeSpread<Real>(pp, stream);
-        launchPmeForwardFFT<Real>(pp, stream);
-        launchPmeConvolution<Real>(pp, stream);
-        launchPmeInverseFFT<Real>(pp, stream);
-        launchPmeInterpolate<Real>(pp, stream);
+    void runPme(PmeParams<Real>& pp, hipStream_t st) {
+        launchPmeSpread<Real>(pp, st);
+        launchPmeForwardFFT<Real>(pp, st);
+        launchPmeConvolution<Real>(pp, st);
+        launchPmeInverseFFT<Real>(pp, st);
+        launchPmeInterpolate<Real>(pp, st);
     }
 
     // Self energy, neutralising background (ReferenceSlicedLJCoulombIxn.cpp:203-222) and dispersion correction
