@@ -197,6 +197,8 @@ public:
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
+    DevBuf<int> pmeCells;
+    double maxAbsQ = 0, maxAbsC6 = 0;
     DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset, exclStart, exclList;
     // GPU neighbour build: static user-order data and scratch
     DevBuf<int> dUSubset, dSubsetStart, dSubsetPaddedStart, dSlotOfSubset, dValsIn, dValsOut, dCounters; DevBuf<Real> dUCharge, dWrapped, dOffsetU; DevBuf<T2> dUSigEps;
@@ -280,6 +282,12 @@ public:
             if (subset[i] != sub[i] || sigma[i] != sg[i] || epsilon[i] != ep[i]) needRebuild = true;   // subsets change the sort; sigma/eps ride along
         }
         charge.assign(q, q + N); sigma.assign(sg, sg + N); epsilon.assign(ep, ep + N); subset.assign(sub, sub + N);
+        maxAbsQ = 0; maxAbsC6 = 0;   // bounds for the fixed-point LDS accumulation of the single-precision brick spreader
+        for (int i = 0; i < N; i++) {
+            maxAbsQ = std::max(maxAbsQ, std::fabs(q[i]));
+            const double hs = 0.5 * sg[i];
+            maxAbsC6 = std::max(maxAbsC6, std::fabs(8.0 * hs * hs * hs * 2.0 * std::sqrt(ep[i])));
+        }
         haveParticles = true; paramsDirty = true; staticDirty = true;
     }
     void setExceptions(int32_t m, const int32_t* pairs, const double* qq, const double* sg, const double* ep, const int32_t* f14) override {
@@ -754,6 +762,11 @@ public:
     // ------------------------------------------------------------------------------------------
     void fillPme(PmeParams<Real>& p, PmePlan<Real>& plan, bool wantEnergy) {
         p.d = plan.d; p.nsub = nGrids; p.natoms = Npad; p.posq = posq.p; p.sigeps = sigeps.p; p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p;
+        pmeCells.resize(Npad); p.cells = pmeCells.p;
+        {   // fixed point: 16 x the largest per-atom charge fits 31 bits (a grid point collects at most a few atoms' weights, each <= 1)
+            const double m = std::max(plan.dispersion ? maxAbsC6 : maxAbsQ, 1e-30);
+            p.fixScale = (Real)(std::ldexp(1.0, 30) / (16.0 * m)); p.fixInv = (Real)(1.0 / (double)p.fixScale);
+        }
         p.gridReal = plan.gridReal.p; p.gridCplx = plan.gridCplx.p; p.twx = plan.twx.p; p.twy = plan.twy.p; p.twz = plan.twz.p;
         p.modx = plan.modx.p; p.mody = plan.mody.p; p.modz = plan.modz.p;
         const double det = box[0] * box[4] * box[8], sc = 1.0 / det;
@@ -767,13 +780,17 @@ public:
         // with bricks of `group` columns when one column is narrower than 5 cells (stencil 4 + 1 cell of drift)
         p.sortNcx = p.sortNcy = 0; p.groupX = p.groupY = 1; p.colRange = nullptr;
         p.zSlabs = 1;
-        if (plan.d.nz % 2 == 0 && plan.d.nz >= 32) p.zSlabs = 2;   // measured on c3: 1 slab 110 us, 2 slabs 105 us, 4 slabs 145 us (phase-1 rescans)
+        { static const int dbgBits = getenv("SNB_DBG") ? atoi(getenv("SNB_DBG")) : 0; p.dbg = dbgBits; }
+        // measured on c3: f64 accumulation 1 slab 110 us, 2 slabs 105 us, 4 slabs 145 us; fixed-point (single precision, even nz) 1 slab 61 us, 2 slabs 67 us
+        if (plan.d.nz % 2 == 0 && plan.d.nz >= 32 && !(sizeof(Real) == 4)) p.zSlabs = 2;
         if (const char* zs = getenv("SNB_ZSLABS")) { const int k = atoi(zs); if (k >= 1 && plan.d.nz % k == 0) p.zSlabs = k; }
         if (colCells[0] > 0) {
             const int ncx = pme.d.nx / colCells[0], ncy = pme.d.ny / colCells[1];
-            auto group = [](int n, int ncols) { if (n % ncols) return 0; const int cpc = n / ncols; for (int g = 1; g <= 4; g++) if (g * cpc >= 5 && ncols % g == 0) return g; return 0; };
+            static const int gMin = getenv("SNB_BRICK_GROUP") ? atoi(getenv("SNB_BRICK_GROUP")) : 1;
+            auto group = [](int n, int ncols) { if (n % ncols) return 0; const int cpc = n / ncols; for (int g = gMin; g <= 4; g++) if (g * cpc >= 5 && ncols % g == 0) return g; return 0; };
             const int gx = group(plan.d.nx, ncx), gy = group(plan.d.ny, ncy);
-            if (gx > 0 && gy > 0 && sizeof(double) * (size_t)(gx * plan.d.nx / ncx) * (gy * plan.d.ny / ncy) * plan.d.nz <= 100 * 1024) {
+            const bool packable = plan.d.nx < 1024 && plan.d.ny < 1024 && plan.d.nz < 1024;   // k_pmeCells packs 10 bits per axis
+            if (packable && gx > 0 && gy > 0 && sizeof(double) * (size_t)(gx * plan.d.nx / ncx) * (gy * plan.d.ny / ncy) * plan.d.nz <= 100 * 1024) {
                 p.sortNcx = ncx; p.sortNcy = ncy; p.groupX = gx; p.groupY = gy; p.colRange = colRange.p;
             }
         }

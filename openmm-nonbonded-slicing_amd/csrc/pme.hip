@@ -21,6 +21,13 @@
 
 namespace snb {
 
+// x / d for 0 <= x < 2^22 without the ~35-instruction integer division: (x + 0.5) * (1/d) never lands within rounding error of an integer
+struct FastDiv {
+    float inv; int d;
+    __device__ explicit FastDiv(int d_) : inv(1.0f / (float)d_), d(d_) {}
+    __device__ int div(int x) const { return (int)(((float)x + 0.5f) * inv); }
+};
+
 template <typename Real> struct Cx { Real x, y; };
 template <typename Real> __device__ inline Cx<Real> cmul(Cx<Real> a, Cx<Real> b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 
@@ -107,6 +114,21 @@ template <typename Real> __global__ __launch_bounds__(256) void k_spread(const P
     }
 }
 
+// packed mesh cell (10 bits per axis) of every sorted atom for the brick spreader's candidate scan, -1 for atoms that carry no charge
+// on this mesh (padding included): one 4-byte load and three compares per candidate instead of a position load and gridCoord
+template <typename Real> __global__ __launch_bounds__(256) void k_pmeCells(const PmeParams<Real> p) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= p.natoms) return;
+    int cell = -1;
+    if (p.atomGrid[a] >= 0 && pmeCharge(p, a) != Real(0)) {
+        const auto pos = p.posq[a];
+        int idx[3]; Real fr[3];
+        gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, p.d.nz, idx, fr);
+        cell = idx[0] | (idx[1] << 10) | (idx[2] << 20);
+    }
+    p.cells[a] = cell;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Brick spreading (the production path for rectangular boxes): no global atomics, no grid memset.
 // One work-group owns a (cx x cy x nz) column of one subset grid in LDS (as doubles: ds_add_f64 runs at ~9 cycles
@@ -115,9 +137,9 @@ template <typename Real> __global__ __launch_bounds__(256) void k_spread(const P
 // sorted ranges of its 3x3 column neighbourhood (one column of margin on each side covers the drift since the last
 // re-sort: < skin/2 < one grid cell).  Every grid point is written exactly once, coalesced along z.
 // ---------------------------------------------------------------------------------------------------
-template <typename Real> __global__ __launch_bounds__(512) void k_spreadBrick(const PmeParams<Real> p) {
+template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_spreadBrick(const PmeParams<Real> p) {
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
-    constexpr int NT = 512, LISTCAP = 2048;
+    constexpr int NT = 512, LISTCAP = 4096;
     // a brick spans groupX x groupY sort columns (1 x 1 for the Coulomb mesh; more when a coarser mesh makes one column < 5 cells)
     const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
     const int cx = p.groupX * (p.d.nx / ncx), cy = p.groupY * (p.d.ny / ncy);       // brick size in cells of THIS mesh
@@ -130,93 +152,174 @@ template <typename Real> __global__ __launch_bounds__(512) void k_spreadBrick(co
     const int Bx = bcol / nby, By = bcol - Bx * nby;
     const int x0 = Bx * cx, y0 = By * cy, z0 = zs * sz;
     const int npts = cx * cy * sz;
-    double* brick = reinterpret_cast<double*>(s_brick_raw);
-    int* list = reinterpret_cast<int*>(brick + npts);       // [LISTCAP] atoms of the current column whose stencil overlaps the brick
+    // accumulation type in LDS: doubles with ds_add_f64 (double precision), or -- single precision -- 32-bit fixed point with two
+    // z-adjacent points packed per ds_add_u64 (sign-extended low half, so the 64-bit sum is exact): 15 instead of 25 LDS atomics
+    // per x-line (ds_add_f32 is ~20x slower than either on this chip, tools/ubench_atomics.hip).  sz and nz are even on this path.
+    using Acc = typename std::conditional<FIXED, int, double>::type;
+    Acc* brick = reinterpret_cast<Acc*>(s_brick_raw);
+    int* list = reinterpret_cast<int*>(s_brick_raw + ((sizeof(Acc) * (size_t)npts + 15) & ~(size_t)15));       // [LISTCAP] (atom, x-line) entries
     __shared__ int s_count;
+    __shared__ int s_rangeBegin[64], s_rangePrefix[65];
     const int tid = threadIdx.x;
-    for (int i = tid; i < npts; i += NT) brick[i] = 0.0;
+    for (int i = tid; i < npts; i += NT) brick[i] = Acc(0);
     if (tid == 0) s_count = 0;
-    __syncthreads();
     const int2* ranges = p.colRange + (size_t)p.gridSubset[slot] * ncol;
     // candidate columns: the brick's own columns, mLo columns below (stencil reach 4 cells + 1 cell of drift) and one above
-    // (drift), each distinct column once
+    // (drift), each distinct column once; their atom ranges are concatenated into one virtual index space
     const int cpcx = p.d.nx / ncx, cpcy = p.d.ny / ncy;
     const int mLoX = (5 + cpcx - 1) / cpcx, mLoY = (5 + cpcy - 1) / cpcy;
     const int nvx = (p.groupX + mLoX + 1 < ncx) ? p.groupX + mLoX + 1 : ncx, nvy = (p.groupY + mLoY + 1 < ncy) ? p.groupY + mLoY + 1 : ncy;
-    for (int tx = 0; tx < nvx; tx++) {
+    const int nr = nvx * nvy;                       // <= 7 * 7
+    if (tid < nr) {
+        const int tx = tid / nvy, ty = tid - tx * nvy;
         int ccx = (Bx * p.groupX - mLoX + tx) % ncx; if (ccx < 0) ccx += ncx;
-        for (int ty = 0; ty < nvy; ty++) {
-            int ccy = (By * p.groupY - mLoY + ty) % ncy; if (ccy < 0) ccy += ncy;
-            const int2 rg = ranges[ccx * ncy + ccy];
-            for (int chunk = rg.x; chunk < rg.y; chunk += LISTCAP) {
-                const int chunkEnd = (chunk + LISTCAP < rg.y) ? chunk + LISTCAP : rg.y;
-                // phase 1: one thread per candidate atom, coalesced loads, keep the atoms whose 5x5 footprint touches the brick
-                for (int a = chunk + tid; a < chunkEnd; a += NT) {
-                    const auto pos = p.posq[a];
-                    int idx[3]; Real fr[3];
-                    gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
-                    int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
-                    int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
-                    int rz = idx[2] - z0; if (rz > nz / 2) rz -= nz; else if (rz < -(nz / 2)) rz += nz;
-                    const bool zHit = p.zSlabs == 1 || (rz + 4 >= 0 && rz < sz);
-                    if (zHit && rx + 4 >= 0 && rx < cx && ry + 4 >= 0 && ry < cy && pmeCharge(p, a) != Real(0)) list[atomicAdd(&s_count, 1)] = a;
-                }
-                __syncthreads();
-                const int count = s_count;
-                // phase 2: one thread per kept atom; weights once, then the 125 stencil points (those inside the brick) into LDS
-                for (int k = tid; k < count; k += NT) {
-                    const int a = list[k];
-                    const Real q = pmeCharge(p, a);
-                    const auto pos = p.posq[a];
-                    int idx[3]; Real fr[3];
-                    gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
-                    int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
-                    int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
-                    Real tx[5], ty[5], tz[5], dtmp[5];
-                    bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
-                    int zi[5];      // z index inside the slab, or -1 when the point belongs to another slab
-#pragma unroll
-                    for (int iz = 0; iz < 5; iz++) {
-                        int z = idx[2] + iz - z0; if (z >= nz) z -= nz; else if (z < 0) z += nz;
-                        zi[iz] = z < sz ? z : -1;
-                    }
-#pragma unroll
-                    for (int ix = 0; ix < 5; ix++) {
-                        const int lx = rx + ix;
-                        if (lx < 0 || lx >= cx) continue;
-#pragma unroll
-                        for (int iy = 0; iy < 5; iy++) {
-                            const int ly = ry + iy;
-                            if (ly < 0 || ly >= cy) continue;
-                            const Real wxy = q * tx[ix] * ty[iy];
-                            double* line = brick + (size_t)(lx * cy + ly) * sz;
-#pragma unroll
-                            for (int iz = 0; iz < 5; iz++)
-                                if (zi[iz] >= 0) __hip_atomic_fetch_add(&line[zi[iz]], (double)(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) s_count = 0;
-                __syncthreads();
+        int ccy = (By * p.groupY - mLoY + ty) % ncy; if (ccy < 0) ccy += ncy;
+        const int2 rg = ranges[ccx * ncy + ccy];
+        s_rangeBegin[tid] = rg.x; s_rangePrefix[tid + 1] = rg.y - rg.x;
+    }
+    __syncthreads();
+    if (tid == 0) { int acc = 0; s_rangePrefix[0] = 0; for (int r = 0; r < nr; r++) { acc += s_rangePrefix[r + 1]; s_rangePrefix[r + 1] = acc; } }
+    __syncthreads();
+    const int total = s_rangePrefix[nr];
+    const int hx = p.d.nx / 2, hy = p.d.ny / 2, hz = nz / 2;
+    if (total == 0) {      // no atom of this subset anywhere near: the brick is all zeros
+        Real* g0 = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
+        const FastDiv dsz0(sz), dcy0(cy);
+        for (int i = tid; i < npts; i += NT) {
+            const int l = dsz0.div(i), z = i - l * sz;
+            const int lx = dcy0.div(l), ly = l - lx * cy;
+            g0[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z0 + z] = Real(0);
+        }
+        return;
+    }
+    for (int base = 0; base < ((p.dbg & 64) ? 0 : total); base += NT) {
+        // phase 1: one thread per candidate atom; every x-line (atom, ix) of its 5x5 footprint that falls inside the brick becomes a list entry
+        const int v = base + tid;
+        int nEnt = 0, ixLo = 0, aSel = 0;
+        if (v < total) {
+            int r = 0;
+            while (v >= s_rangePrefix[r + 1]) r++;
+            const int a = s_rangeBegin[r] + (v - s_rangePrefix[r]);
+            const int cell = p.cells[a];            // packed mesh cell of the atom (k_pmeCells), -1 = carries no charge on this mesh
+            const int idx[3] = {cell & 1023, (cell >> 10) & 1023, (cell >> 20) & 1023};
+            int rx = idx[0] - x0; if (rx > hx) rx -= p.d.nx; else if (rx < -hx) rx += p.d.nx;
+            int ry = idx[1] - y0; if (ry > hy) ry -= p.d.ny; else if (ry < -hy) ry += p.d.ny;
+            int rz = idx[2] - z0; if (rz > hz) rz -= nz; else if (rz < -hz) rz += nz;
+            const bool zHit = p.zSlabs == 1 || (rz + 4 >= 0 && rz < sz);
+            if (cell >= 0 && zHit && rx + 4 >= 0 && rx < cx && ry + 4 >= 0 && ry < cy) {
+                ixLo = rx < 0 ? -rx : 0;                                                   // lines with 0 <= rx + ix < cx
+                nEnt = ((cx - rx < 5) ? cx - rx : 5) - ixLo;
+                aSel = a;
             }
         }
+        {   // wave-aggregated append: one LDS atomic per wave instead of one same-address atomic per lane
+            int incl = nEnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+            int waveBase = 0;
+            if ((tid & 63) == 63 && incl > 0) waveBase = atomicAdd(&s_count, incl);
+            waveBase = __shfl(waveBase, 63, 64);
+            const int slot0 = waveBase + incl - nEnt;
+            for (int k = 0; k < nEnt; k++) list[slot0 + k] = (aSel << 3) | (ixLo + k);
+        }
+        __syncthreads();
+        const int count = s_count;
+        __syncthreads();                                                    // everyone has read the count before anyone appends again
+        if (count <= LISTCAP - 5 * NT && base + NT < total) continue;      // room for another round of candidates (uniform branch)
+        // phase 2: one thread per (atom, x-line): weights, then the line's 5x5 (y,z) points that fall inside the brick into LDS
+        for (int k = tid; k < ((p.dbg & 16) ? 0 : count); k += NT) {
+            const int e = list[k];
+            const int a = e >> 3, ix = e & 7;
+            const Real q = pmeCharge(p, a);
+            const auto pos = p.posq[a];
+            int idx[3]; Real fr[3];
+            gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
+            int rx = idx[0] - x0; if (rx > hx) rx -= p.d.nx; else if (rx < -hx) rx += p.d.nx;
+            int ry = idx[1] - y0; if (ry > hy) ry -= p.d.ny; else if (ry < -hy) ry += p.d.ny;
+            Real tx[5], ty[5], tz[5], dtmp[5];
+            bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
+            const Real wx = q * (ix == 0 ? tx[0] : ix == 1 ? tx[1] : ix == 2 ? tx[2] : ix == 3 ? tx[3] : tx[4]);
+            int zi[5];      // z index inside the slab, or -1 when the point belongs to another slab
+#pragma unroll
+            for (int iz = 0; iz < 5; iz++) {
+                int z = idx[2] + iz - z0; if (z >= nz) z -= nz; else if (z < 0) z += nz;
+                zi[iz] = z < sz ? z : -1;
+            }
+            Acc* plane = brick + (size_t)(rx + ix) * cy * sz;
+            if constexpr (FIXED) {
+                // pair slots in unwrapped z: (2P, 2P+1) for P = idx[2]>>1 + {0,1,2}; nz and the slab bounds are even, so a pair never straddles
+                // the periodic wrap or a slab boundary
+                const bool odd = idx[2] & 1;
+                int zp[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    int z = (idx[2] & ~1) + 2 * j - z0; if (z >= nz) z -= nz; else if (z < 0) z += nz;
+                    zp[j] = z < sz ? z : -1;
+                }
+                const Real wq = wx * p.fixScale;
+#pragma unroll
+                for (int iy = 0; iy < 5; iy++) {
+                    const int ly = ry + iy;
+                    if (ly < 0 || ly >= cy) continue;
+                    const Real wxy = wq * ty[iy];
+                    int v[5];
+#pragma unroll
+                    for (int iz = 0; iz < 5; iz++) v[iz] = __float2int_rn(wxy * tz[iz]);
+                    unsigned long long* line = reinterpret_cast<unsigned long long*>(plane + ly * sz);
+                    const int lo0 = odd ? 0 : v[0], hi0 = odd ? v[0] : v[1];
+                    const int lo1 = odd ? v[1] : v[2], hi1 = odd ? v[2] : v[3];
+                    const int lo2 = odd ? v[3] : v[4], hi2 = odd ? v[4] : 0;
+                    const int lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const unsigned long long packed = ((unsigned long long)(unsigned)(hi[j] + (lo[j] >> 31)) << 32) | (unsigned)lo[j];
+                        if (zp[j] >= 0 && !(p.dbg & 8)) __hip_atomic_fetch_add(&line[zp[j] >> 1], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int iy = 0; iy < 5; iy++) {
+                    const int ly = ry + iy;
+                    if (ly < 0 || ly >= cy) continue;
+                    const Real wxy = wx * ty[iy];
+                    Acc* line = plane + ly * sz;
+#pragma unroll
+                    for (int iz = 0; iz < 5; iz++)
+                        if (zi[iz] >= 0 && !(p.dbg & 8)) __hip_atomic_fetch_add(&line[zi[iz]], (double)(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_count = 0;
+        __syncthreads();
     }
     Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
+    if (p.dbg & 32) return;
+    const FastDiv dsz(sz), dcy(cy);
     for (int i = tid; i < npts; i += NT) {
-        const int l = i / sz, z = i - l * sz;
-        const int lx = l / cy, ly = l - lx * cy;
-        g[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z0 + z] = (Real)brick[i];
+        const int l = dsz.div(i), z = i - l * sz;
+        const int lx = dcy.div(l), ly = l - lx * cy;
+        g[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z0 + z] = FIXED ? (Real)brick[i] * p.fixInv : (Real)brick[i];
     }
 }
 
 template <typename Real> void launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
     if (p.sortNcx > 0 && p.colRange != nullptr) {
         const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
-        const size_t lds = sizeof(double) * (size_t)cx * cy * (p.d.nz / p.zSlabs) + sizeof(int) * 2048;
+        const bool fixed = std::is_same<Real, float>::value && p.d.nz % 2 == 0 && (p.d.nz / p.zSlabs) % 2 == 0;
+        const size_t accBytes = fixed ? sizeof(int) : sizeof(double);
+        const size_t lds = ((accBytes * (size_t)cx * cy * (p.d.nz / p.zSlabs) + 15) & ~(size_t)15) + sizeof(int) * 4096;
         const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * p.zSlabs;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_spreadBrick<Real>), dim3(nblocks), dim3(512), lds, s, p);
+        hipLaunchKernelGGL((k_pmeCells<Real>), dim3((p.natoms + 255) / 256), dim3(256), 0, s, p);
+        if constexpr (std::is_same<Real, float>::value) {
+            if (fixed) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((k_spreadBrick<Real, true>), dim3(nblocks), dim3(512), lds, s, p);
+                return;
+            }
+        }
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_spreadBrick<Real, false>), dim3(nblocks), dim3(512), lds, s, p);
         return;
     }
     // fallback (triclinic boxes, meshes without a usable column divisor): global float atomics
@@ -412,12 +515,6 @@ __device__ inline Cx<Real>* fftLines(Cx<Real>* a, Cx<Real>* b, int n, const int*
 
 extern __shared__ __align__(16) unsigned char s_dyn[];
 
-// x / d for 0 <= x < 2^22 without the ~35-instruction integer division: (x + 0.5) * (1/d) never lands within rounding error of an integer
-struct FastDiv {
-    float inv; int d;
-    __device__ explicit FastDiv(int d_) : inv(1.0f / (float)d_), d(d_) {}
-    __device__ int div(int x) const { return (int)(((float)x + 0.5f) * inv); }
-};
 
 // ---- z axis: real <-> half-complex.  One work-group transforms NL contiguous real lines, TWO PER COMPLEX FFT: lines 2c and 2c+1
 // travel as the real and imaginary part of complex line c (z = a + i b, Z = A + i B with A, B Hermitian), so the z passes do half
@@ -875,9 +972,10 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
     const int bx = cx + EXTRA, by = cy + EXTRA;
     const int tid = threadIdx.x;
     const Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
+    const FastDiv dnz(nz), dby(by);
     for (int i = tid; i < bx * by * nz; i += NT) {
-        const int l = i / nz, z = i - l * nz;
-        const int lx = l / by, ly = l - lx * by;
+        const int l = dnz.div(i), z = i - l * nz;
+        const int lx = dby.div(l), ly = l - lx * by;
         int x = x0 + lx - HALO_LO; if (x < 0) x += p.d.nx; else if (x >= p.d.nx) x -= p.d.nx;
         int y = y0 + ly - HALO_LO; if (y < 0) y += p.d.ny; else if (y >= p.d.ny) y -= p.d.ny;
         brick[i] = g[((size_t)x * p.d.ny + y) * nz + z];

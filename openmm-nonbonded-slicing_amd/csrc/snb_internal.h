@@ -92,6 +92,8 @@ template <typename Real> struct PmeParams {
     const typename Vec<Real>::T2* sigeps;
     const int* atomSubset;    // [Npad] sorted
     const int* atomGrid;      // [Npad] grid slot of the atom's subset, or -1 (not owned / padding)
+    Real fixScale, fixInv;    // single-precision brick spreader: LDS accumulation in 32-bit fixed point (value * fixScale)
+    int* cells;               // [Npad] scratch: packed mesh cell per atom (k_pmeCells), brick spreader only
     Real* gridReal;           // [nsub][nx][ny][nz]
     typename Vec<Real>::T2* gridCplx;   // [nsub][nx][ny][nzc]
     const typename Vec<Real>::T2* twx; const typename Vec<Real>::T2* twy; const typename Vec<Real>::T2* twz;   // roots of unity exp(-2 pi i k/n)
@@ -108,6 +110,7 @@ template <typename Real> struct PmeParams {
     int wantEnergy;
     int sortNcx, sortNcy;      // brick kernels: number of sort columns (0 = use the atomic / gather fallbacks)
     int groupX, groupY;        // sort columns per brick (brick = group * nx/sortNcx cells, at least 5)
+    int dbg;                   // SNB_DBG experiment bits (timing decomposition only)
     int zSlabs;                // bricks are also cut into this many slabs along z (nz % zSlabs == 0)
     const int2* colRange;      // [nsubTotal][ncx*ncy] sorted-atom range of every (subset, xy column)
 };
