@@ -967,8 +967,8 @@ public:
     void resetTimers() override { for (auto& r : ring) if (r.pending) harvest(r); stats.sum_direct_ms = stats.sum_recip_ms = stats.sum_total_ms = 0; stats.n_timed = 0; }
 
     void runPme(PmeParams<Real>& pp, hipStream_t st) {
-        launchPmeSpread<Real>(pp, st);
-        launchPmeForwardFFT<Real>(pp, st);
+        const bool zDone = launchPmeSpread<Real>(pp, st);
+        launchPmeForwardFFT<Real>(pp, st, zDone);
         launchPmeConvolution<Real>(pp, st);
         launchPmeInverseFFT<Real>(pp, st);
         launchPmeInterpolate<Real>(pp, st);
@@ -1033,7 +1033,7 @@ template <typename Real> static void testFFT(int device, int batch, int nx, int 
         std::vector<Real> h(nr);
         for (size_t i = 0; i < nr; i++) h[i] = (Real)in[i];
         HIPCHECK(hipMemcpyAsync(plan.gridReal.p, h.data(), sizeof(Real) * nr, hipMemcpyHostToDevice, s));
-        launchPmeForwardFFT<Real>(p, s);
+        launchPmeForwardFFT<Real>(p, s, false);
         launchPmeFFTX<Real>(p, -1, s);
         std::vector<typename Vec<Real>::T2> hc(ncx);
         HIPCHECK(hipMemcpyAsync(hc.data(), plan.gridCplx.p, sizeof(typename Vec<Real>::T2) * ncx, hipMemcpyDeviceToHost, s));

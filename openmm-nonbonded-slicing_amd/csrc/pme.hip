@@ -18,6 +18,8 @@
 #include "snb_internal.h"
 #include <cstdlib>
 #include <type_traits>
+#include <algorithm>
+#include <cstdlib>
 
 namespace snb {
 
@@ -29,6 +31,8 @@ struct FastDiv {
 };
 
 template <typename Real> struct Cx { Real x, y; };
+template <typename Real, int R1 = 0, int R2 = 0>
+__device__ inline Cx<Real>* fftLines(Cx<Real>* a, Cx<Real>* b, int n, const int* factors, int nf, int sign, const Cx<Real>* tw, int nb, int BS, int tid, int nthreads);
 template <typename Real> __device__ inline Cx<Real> cmul(Cx<Real> a, Cx<Real> b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 
 // ---------------------------------------------------------------------------------------------------
@@ -137,7 +141,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_pmeCells(const
 // sorted ranges of its 3x3 column neighbourhood (one column of margin on each side covers the drift since the last
 // re-sort: < skin/2 < one grid cell).  Every grid point is written exactly once, coalesced along z.
 // ---------------------------------------------------------------------------------------------------
-template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_spreadBrick(const PmeParams<Real> p) {
+template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(512) void k_spreadBrick(const PmeParams<Real> p) {
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
     constexpr int NT = 512, LISTCAP = 4096;
     // a brick spans groupX x groupY sort columns (1 x 1 for the Coulomb mesh; more when a coarser mesh makes one column < 5 cells)
@@ -183,6 +187,17 @@ template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_sp
     const int total = s_rangePrefix[nr];
     const int hx = p.d.nx / 2, hy = p.d.ny / 2, hz = nz / 2;
     if (total == 0) {      // no atom of this subset anywhere near: the brick is all zeros
+        if constexpr (FUSEZ) {
+            const int nzc = p.d.nzc;
+            Cx<Real>* o0 = reinterpret_cast<Cx<Real>*>(p.gridCplx) + (size_t)slot * p.d.nx * p.d.ny * nzc;
+            const FastDiv dzc0(nzc), dcy1(cy);
+            for (int i = tid; i < cx * cy * nzc; i += NT) {
+                const int l = dzc0.div(i), k = i - l * nzc;
+                const int lx = dcy1.div(l), ly = l - lx * cy;
+                o0[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nzc + k] = {Real(0), Real(0)};
+            }
+            return;
+        }
         Real* g0 = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
         const FastDiv dsz0(sz), dcy0(cy);
         for (int i = tid; i < npts; i += NT) {
@@ -293,6 +308,37 @@ template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_sp
         if (tid == 0) s_count = 0;
         __syncthreads();
     }
+    if constexpr (FUSEZ) {
+        // forward z FFT of the brick's own lines straight out of LDS (zSlabs == 1: the brick holds whole lines), two real lines per
+        // complex transform as in k_fftZ; the real grid is never written and the separate z pass is skipped
+        const int nzc = p.d.nzc, nl = cx * cy, nb = (nl + 1) >> 1, BS = nb + 1;
+        Cx<Real>* A = reinterpret_cast<Cx<Real>*>(list);                  // the entry list is dead by now
+        Cx<Real>* B = A + (size_t)nz * BS;
+        Cx<Real>* tw = B + (size_t)nz * BS;
+        for (int k = tid; k < nz; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
+        const FastDiv dz(nz), dzc(nzc), dcy2(cy);
+        const Real inv = FIXED ? p.fixInv : Real(1);
+        for (int it = tid; it < nb * nz; it += NT) {
+            const int c = dz.div(it), k = it - c * nz;
+            const Real a = (Real)brick[(2 * c) * nz + k] * inv;
+            const Real b = (2 * c + 1 < nl) ? (Real)brick[(2 * c + 1) * nz + k] * inv : Real(0);
+            A[k * BS + c] = {a, b};
+        }
+        Cx<Real>* R = fftLines<Real, 0, 0>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, NT);
+        __syncthreads();
+        Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.gridCplx) + (size_t)slot * p.d.nx * p.d.ny * nzc;
+        for (int it = tid; it < nb * nzc; it += NT) {
+            const int c = dzc.div(it), k = it - c * nzc;
+            const Cx<Real> z = R[k * BS + c], m = R[(k == 0 ? 0 : nz - k) * BS + c];
+            const int l0 = 2 * c, lx0 = dcy2.div(l0), ly0 = l0 - lx0 * cy;
+            out[((size_t)(x0 + lx0) * p.d.ny + (y0 + ly0)) * nzc + k] = {Real(0.5) * (z.x + m.x), Real(0.5) * (z.y - m.y)};
+            if (l0 + 1 < nl) {
+                const int l1 = l0 + 1, lx1 = dcy2.div(l1), ly1 = l1 - lx1 * cy;
+                out[((size_t)(x0 + lx1) * p.d.ny + (y0 + ly1)) * nzc + k] = {Real(0.5) * (z.y + m.y), Real(0.5) * (m.x - z.x)};
+            }
+        }
+        return;
+    }
     Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
     if (p.dbg & 32) return;
     const FastDiv dsz(sz), dcy(cy);
@@ -303,29 +349,35 @@ template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_sp
     }
 }
 
-template <typename Real> void launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
+// Returns true when the spreader also did the forward z FFT (launchPmeForwardFFT must then skip its z pass).
+template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
     if (p.sortNcx > 0 && p.colRange != nullptr) {
         const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
         const bool fixed = std::is_same<Real, float>::value && p.d.nz % 2 == 0 && (p.d.nz / p.zSlabs) % 2 == 0;
         const size_t accBytes = fixed ? sizeof(int) : sizeof(double);
-        const size_t lds = ((accBytes * (size_t)cx * cy * (p.d.nz / p.zSlabs) + 15) & ~(size_t)15) + sizeof(int) * 4096;
+        const size_t brickBytes = (accBytes * (size_t)cx * cy * (p.d.nz / p.zSlabs) + 15) & ~(size_t)15;
+        const size_t listBytes = sizeof(int) * 4096;
+        const int nbz = (cx * cy + 1) / 2;
+        const size_t fftBytes = sizeof(Cx<Real>) * ((size_t)2 * p.d.nz * (nbz + 1) + p.d.nz);
+        static const bool noFuse = getenv("SNB_NO_FUSED_Z") != nullptr;
+        const bool fuse = !noFuse && p.zSlabs == 1 && brickBytes + std::max(listBytes, fftBytes) <= 64 * 1024;
+        const size_t lds = brickBytes + (fuse ? std::max(listBytes, fftBytes) : listBytes);
         const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * p.zSlabs;
         hipLaunchKernelGGL((k_pmeCells<Real>), dim3((p.natoms + 255) / 256), dim3(256), 0, s, p);
+#define SNB_SPREAD(FX, FZ) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real, FX, FZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                             hipLaunchKernelGGL((k_spreadBrick<Real, FX, FZ>), dim3(nblocks), dim3(512), lds, s, p); }
         if constexpr (std::is_same<Real, float>::value) {
-            if (fixed) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((k_spreadBrick<Real, true>), dim3(nblocks), dim3(512), lds, s, p);
-                return;
-            }
+            if (fixed) { if (fuse) SNB_SPREAD(true, true) else SNB_SPREAD(true, false) return fuse; }
         }
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_spreadBrick<Real, false>), dim3(nblocks), dim3(512), lds, s, p);
-        return;
+        if (fuse) SNB_SPREAD(false, true) else SNB_SPREAD(false, false)
+#undef SNB_SPREAD
+        return fuse;
     }
     // fallback (triclinic boxes, meshes without a usable column divisor): global float atomics
     hipMemsetAsync(p.gridReal, 0, sizeof(Real) * (size_t)p.nsub * p.d.nx * p.d.ny * p.d.nz, s);
-    if (p.natoms <= 0) return;
+    if (p.natoms <= 0) return false;
     hipLaunchKernelGGL((k_spread<Real>), dim3((p.natoms + 7) / 8), dim3(256), 0, s, p);
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -487,7 +539,7 @@ __device__ __forceinline__ void fftPass2(const Cx<Real>* a, Cx<Real>* bOut, int 
 #define SNB_FFT_PAIRS(X) X(6, 7) X(6, 9) X(8, 8) X(8, 10) X(9, 10) X(8, 12) X(10, 10) X(9, 12) X(8, 15) X(8, 16) X(12, 12) X(10, 16) X(12, 15) X(12, 16) X(15, 16) X(16, 16)
 
 // Runs all stages; returns the buffer holding the result.  Caller must __syncthreads() before reading it.
-template <typename Real, int R1 = 0, int R2 = 0>
+template <typename Real, int R1, int R2>
 __device__ inline Cx<Real>* fftLines(Cx<Real>* a, Cx<Real>* b, int n, const int* factors, int nf, int sign, const Cx<Real>* tw, int nb, int BS, int tid, int nthreads) {
     if constexpr (R1 > 0) {
         __syncthreads();
@@ -809,10 +861,10 @@ template <typename Real> static int pickBatch(size_t bytesPerBatchElem, int maxB
     return b;
 }
 
-template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s) {
+template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s, bool zDone) {
     const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc;
-    // z: real -> half complex
-    {
+    // z: real -> half complex (unless the brick spreader already did it)
+    if (!zDone) {
         int NC = pickBatch<Real>((size_t)2 * nz * sizeof(Cx<Real>), 17) - 1;   // complex lines per work-group (two real lines each)
         NC &= ~1;
         if (NC < 2) NC = 2;
@@ -973,7 +1025,7 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
     const int tid = threadIdx.x;
     const Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
     const FastDiv dnz(nz), dby(by);
-    for (int i = tid; i < bx * by * nz; i += NT) {
+    for (int i = tid; i < ((p.dbg & 16) ? 0 : bx * by * nz); i += NT) {
         const int l = dnz.div(i), z = i - l * nz;
         const int lx = dby.div(l), ly = l - lx * by;
         int x = x0 + lx - HALO_LO; if (x < 0) x += p.d.nx; else if (x >= p.d.nx) x -= p.d.nx;
@@ -983,7 +1035,7 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
     __syncthreads();
     for (int gx = 0; gx < p.groupX; gx++) for (int gy = 0; gy < p.groupY; gy++) {
     const int2 rg = ranges[(Bx * p.groupX + gx) * ncy + By * p.groupY + gy];
-    for (int a = rg.x + tid; a < rg.y; a += NT) {
+    for (int a = rg.x + tid; a < ((p.dbg & 8) ? 0 : rg.y); a += NT) {
         const Real q = pmeCharge(p, a);
         const auto pos = p.posq[a];
         int idx[3]; Real fr[3];
@@ -1045,10 +1097,10 @@ template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hip
     hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
 }
 
-template void launchPmeSpread<float>(const PmeParams<float>&, hipStream_t);
-template void launchPmeSpread<double>(const PmeParams<double>&, hipStream_t);
-template void launchPmeForwardFFT<float>(const PmeParams<float>&, hipStream_t);
-template void launchPmeForwardFFT<double>(const PmeParams<double>&, hipStream_t);
+template bool launchPmeSpread<float>(const PmeParams<float>&, hipStream_t);
+template bool launchPmeSpread<double>(const PmeParams<double>&, hipStream_t);
+template void launchPmeForwardFFT<float>(const PmeParams<float>&, hipStream_t, bool);
+template void launchPmeForwardFFT<double>(const PmeParams<double>&, hipStream_t, bool);
 template void launchPmeConvolution<float>(const PmeParams<float>&, hipStream_t);
 template void launchPmeConvolution<double>(const PmeParams<double>&, hipStream_t);
 template void launchPmeInverseFFT<float>(const PmeParams<float>&, hipStream_t);

@@ -155,8 +155,8 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, const
 template <typename Real> void launchDirect(const DirectParams<Real>& p, int methodClass, bool wrap, bool energy, hipStream_t s);
 template <typename Real> void launchExceptions(const PairListParams<Real>& p, bool energy, hipStream_t s);
 template <typename Real> void launchExclusionCorrection(const PairListParams<Real>& p, bool energy, hipStream_t s);
-template <typename Real> void launchPmeSpread(const PmeParams<Real>& p, hipStream_t s);
-template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s);
+template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStream_t s);   // true: forward z FFT already done
+template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s, bool zDone);
 template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hipStream_t s);   // fused x-FFT, energy, convolution, inverse x-FFT
 template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipStream_t s);
 template <typename Real> void launchPmeFFTX(const PmeParams<Real>& p, int sign, hipStream_t s);   // x axis alone (test hook)
