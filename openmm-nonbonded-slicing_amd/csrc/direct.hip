@@ -474,11 +474,11 @@ template void launchDirect<float>(const DirectParams<float>&, int, bool, bool, h
 template void launchDirect<double>(const DirectParams<double>&, int, bool, bool, hipStream_t);
 
 // ---- 1-4 exceptions: ReferenceSlicedLJCoulomb14.cpp:61-95 ----------------------------------------
-template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_exceptions(const PairListParams<Real> p) {
+template <typename Real, bool ENERGY> __device__ __forceinline__ void exceptionsBody(const PairListParams<Real>& p, const int blk) {
     extern __shared__ double s_sliceE[];   // [2*S]
     const int nS2 = 2 * p.nSlices;
     if (ENERGY) { for (int i = threadIdx.x; i < nS2; i += 256) s_sliceE[i] = 0.0; __syncthreads(); }
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blk * 256 + threadIdx.x;
     double e0 = 0, e1 = 0; int slice = 0;
     if (k < p.n) {
         int2 ij = p.pairs[k];
@@ -514,11 +514,11 @@ template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_e
 // from both ends, so the force update is a plain read-modify-write of the atom's own accumulator -- no atomics
 // (2 M scattered float atomics cost 70 us on MI355X; this costs a few us).  Energies: half a pair from each end,
 // reduced per slice in LDS (ds_add_f64) and flushed with one global atomic per slice and work-group.
-template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_exclusionAtoms(const PairListParams<Real> p) {
+template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionAtomsBody(const PairListParams<Real>& p, const int blk) {
     extern __shared__ double s_sliceE[];   // [2*S]
     const int nS2 = 2 * p.nSlices;
     if (ENERGY) { for (int i = threadIdx.x; i < nS2; i += 256) s_sliceE[i] = 0.0; __syncthreads(); }
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blk * 256 + threadIdx.x;
     const int ua = a < p.n ? p.sortedToUser[a] : -1;
     if (ua >= 0) {
         const int e0 = p.exclStart[ua], e1 = p.exclStart[ua + 1];
@@ -565,7 +565,7 @@ template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_e
                 }
                 fx += f * dx; fy += f * dy; fz += f * dz;
             }
-            p.fx[a] += fx; p.fy[a] += fy; p.fz[a] += fz;
+            gAdd(&p.fx[a], fx); gAdd(&p.fy[a], fy); gAdd(&p.fz[a], fz);   // atomics: the 1-4 blocks of the same launch add to the same atoms
         }
     }
     if (ENERGY) {
@@ -574,23 +574,21 @@ template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_e
     }
 }
 
-template <typename Real> void launchExceptions(const PairListParams<Real>& p, bool energy, hipStream_t s) {
-    if (p.n <= 0) return;
-    dim3 grid((p.n + 255) / 256), block(256);
-    const size_t lds = sizeof(double) * 2 * p.nSlices;
-    if (energy) hipLaunchKernelGGL((k_exceptions<Real, true>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((k_exceptions<Real, false>), grid, block, 0, s, p);
+// One launch for both O(N) pair lists: blocks [0, nExclBlocks) run the per-atom Ewald exclusion corrections (p.nExclAtoms atoms),
+// the remaining blocks the 1-4 exceptions (p.n pairs).
+template <typename Real, bool ENERGY> __global__ __launch_bounds__(256) void k_pairLists(const PairListParams<Real> p, const int nExclBlocks) {
+    if ((int)blockIdx.x < nExclBlocks) { PairListParams<Real> q = p; q.n = p.nExclAtoms; exclusionAtomsBody<Real, ENERGY>(q, blockIdx.x); }
+    else exceptionsBody<Real, ENERGY>(p, blockIdx.x - nExclBlocks);
 }
-template <typename Real> void launchExclusionCorrection(const PairListParams<Real>& p, bool energy, hipStream_t s) {
-    if (p.n <= 0) return;
-    dim3 grid((p.n + 255) / 256), block(256);
+template <typename Real> void launchPairLists(const PairListParams<Real>& p, bool energy, hipStream_t s) {
+    const int nExclBlocks = (p.nExclAtoms + 255) / 256, nExcBlocks = (p.n + 255) / 256;
+    if (nExclBlocks + nExcBlocks <= 0) return;
+    dim3 grid(nExclBlocks + nExcBlocks), block(256);
     const size_t lds = sizeof(double) * 2 * p.nSlices;
-    if (energy) hipLaunchKernelGGL((k_exclusionAtoms<Real, true>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((k_exclusionAtoms<Real, false>), grid, block, 0, s, p);
+    if (energy) hipLaunchKernelGGL((k_pairLists<Real, true>), grid, block, lds, s, p, nExclBlocks);
+    else hipLaunchKernelGGL((k_pairLists<Real, false>), grid, block, 0, s, p, nExclBlocks);
 }
-template void launchExceptions<float>(const PairListParams<float>&, bool, hipStream_t);
-template void launchExceptions<double>(const PairListParams<double>&, bool, hipStream_t);
-template void launchExclusionCorrection<float>(const PairListParams<float>&, bool, hipStream_t);
-template void launchExclusionCorrection<double>(const PairListParams<double>&, bool, hipStream_t);
+template void launchPairLists<float>(const PairListParams<float>&, bool, hipStream_t);
+template void launchPairLists<double>(const PairListParams<double>&, bool, hipStream_t);
 
 }  // namespace snb

@@ -198,6 +198,7 @@ public:
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
     DevBuf<int> pmeCells;
+    bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
     double maxAbsQ = 0, maxAbsC6 = 0;
     DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset, exclStart, exclList;
     // GPU neighbour build: static user-order data and scratch
@@ -763,6 +764,7 @@ public:
     void fillPme(PmeParams<Real>& p, PmePlan<Real>& plan, bool wantEnergy) {
         p.d = plan.d; p.nsub = nGrids; p.natoms = Npad; p.posq = posq.p; p.sigeps = sigeps.p; p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p;
         pmeCells.resize(Npad); p.cells = pmeCells.p;
+        p.cellsReady = (!plan.dispersion && cellsFromGather) ? 1 : 0;
         {   // fixed point: 16 x the largest per-atom charge fits 31 bits (a grid point collects at most a few atoms' weights, each <= 1)
             const double m = std::max(plan.dispersion ? maxAbsC6 : maxAbsQ, 1e-30);
             p.fixScale = (Real)(std::ldexp(1.0, 30) / (16.0 * m)); p.fixInv = (Real)(1.0 / (double)p.fixScale);
@@ -856,8 +858,21 @@ public:
 
     void enqueueStep(bool energy, bool includeDirect, bool includeRecip, EvSet* ev) {
         if (ev) HIPCHECK(hipEventRecord(ev->e[0], stream));
-        launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, stream);
-        HIPCHECK(hipMemsetAsync(forceBuf.p, 0, sizeof(Real) * 6 * Npad, stream));
+        // one pass: sorted positions, cleared force arrays, and (PME on the brick path) the packed Coulomb-mesh cell of every atom
+        GatherCells<Real> gc;
+        std::memset(&gc, 0, sizeof(gc));
+        cellsFromGather = false;
+        if (includeRecip && isPme() && nGrids > 0) {
+            PmeParams<Real> pp;
+            std::memset(&pp, 0, sizeof(pp));
+            fillPme(pp, pme, false);
+            if (pp.sortNcx > 0 && pp.colRange != nullptr) {
+                for (int i = 0; i < 9; i++) gc.recip[i] = pp.recip[i];
+                gc.nx = pp.d.nx; gc.ny = pp.d.ny; gc.nz = pp.d.nz; gc.cells = pp.cells; gc.atomGrid = pp.atomGrid;
+                cellsFromGather = true;
+            }
+        }
+        launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, forceBuf.p, gc, stream);
         if (energy) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2, stream));
         const bool ew = cfg.method >= SNB_Ewald;
         // Opt-in (SNB_CONCURRENT_PME=1): forces-only graph steps run the reciprocal pipeline on a second stream beside the pair
@@ -914,8 +929,8 @@ public:
             for (int i = 0; i < 9; i++) q.box[i] = (Real)box[i];
             q.alpha = (Real)cfg.alpha; q.alphaD = (Real)cfg.alpha_d; q.ljpme = cfg.method == SNB_LJPME;
             q.pairs = pairs14.p; q.params = params14.p; q.n = n14;
-            launchExceptions<Real>(q, energy, stream);
-            if (ew && nExcl > 0) { q.n = Npad; launchExclusionCorrection<Real>(q, energy, stream); }
+            q.nExclAtoms = (ew && nExcl > 0) ? Npad : 0;
+            launchPairLists<Real>(q, energy, stream);
         }
         if (ev) HIPCHECK(hipEventRecord(ev->e[3], stream));
         if (includeRecip && isPme()) {

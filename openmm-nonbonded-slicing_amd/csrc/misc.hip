@@ -5,29 +5,44 @@
 namespace snb {
 
 // posq[s].xyz = userPos[sortedToUser[s]] + imageOffset[s]; charge (.w) is kept.  Padding slots (sortedToUser < 0)
-// keep their parked far-away coordinates.
+// keep their parked far-away coordinates.  The same pass clears the six force arrays of the atom (no separate memset node in the
+// step graph) and, when a Coulomb mesh is given, writes the atom's packed mesh cell for the brick spreader (pme.hip, k_pmeCells).
 template <typename Real, typename In>
 __global__ void k_gatherPositions(const In* __restrict__ userPos, int stride, const int* __restrict__ sortedToUser,
-                                  const Real* __restrict__ imageOffset, typename Vec<Real>::T4* __restrict__ posq, int nPadded) {
+                                  const Real* __restrict__ imageOffset, typename Vec<Real>::T4* __restrict__ posq, int nPadded,
+                                  Real* __restrict__ forces, const GatherCells<Real> gc) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nPadded) return;
+    if (forces) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) forces[(size_t)k * nPadded + s] = Real(0);
+    }
     const int u = sortedToUser[s];
-    if (u < 0) return;
+    if (u < 0) { if (gc.cells) gc.cells[s] = -1; return; }
     auto v = posq[s];
     v.x = (Real)userPos[(size_t)u * stride] + imageOffset[3 * s];
     v.y = (Real)userPos[(size_t)u * stride + 1] + imageOffset[3 * s + 1];
     v.z = (Real)userPos[(size_t)u * stride + 2] + imageOffset[3 * s + 2];
     posq[s] = v;
+    if (gc.cells) {
+        int cell = -1;
+        if (gc.atomGrid[s] >= 0 && v.w != Real(0)) {
+            int idx[3]; Real fr[3];
+            gridCoord<Real>(gc.recip, v.x, v.y, v.z, gc.nx, gc.ny, gc.nz, idx, fr);
+            cell = idx[0] | (idx[1] << 10) | (idx[2] << 20);
+        }
+        gc.cells[s] = cell;
+    }
 }
 
 template <typename Real>
 void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
-                           typename Vec<Real>::T4* posq, int nPadded, hipStream_t s) {
+                           typename Vec<Real>::T4* posq, int nPadded, Real* forces, const GatherCells<Real>& gc, hipStream_t s) {
     if (nPadded <= 0) return;
     dim3 grid((nPadded + 255) / 256), block(256);
     const int stride = stride4 ? 4 : 3;
-    if (isDouble) hipLaunchKernelGGL((k_gatherPositions<Real, double>), grid, block, 0, s, (const double*)userPos, stride, sortedToUser, imageOffset, posq, nPadded);
-    else hipLaunchKernelGGL((k_gatherPositions<Real, float>), grid, block, 0, s, (const float*)userPos, stride, sortedToUser, imageOffset, posq, nPadded);
+    if (isDouble) hipLaunchKernelGGL((k_gatherPositions<Real, double>), grid, block, 0, s, (const double*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, gc);
+    else hipLaunchKernelGGL((k_gatherPositions<Real, float>), grid, block, 0, s, (const float*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, gc);
 }
 
 template <typename Real, typename Out>
@@ -52,8 +67,8 @@ void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, const Re
     else hipLaunchKernelGGL((k_finishForces<Real, float>), grid, block, 0, s, fx, fy, fz, fpx, fpy, fpz, userToSorted, nAtoms, (float*)out, accumulate);
 }
 
-template void launchGatherPositions<float>(const void*, int, int, const int*, const float*, Vec<float>::T4*, int, hipStream_t);
-template void launchGatherPositions<double>(const void*, int, int, const int*, const double*, Vec<double>::T4*, int, hipStream_t);
+template void launchGatherPositions<float>(const void*, int, int, const int*, const float*, Vec<float>::T4*, int, float*, const GatherCells<float>&, hipStream_t);
+template void launchGatherPositions<double>(const void*, int, int, const int*, const double*, Vec<double>::T4*, int, double*, const GatherCells<double>&, hipStream_t);
 template void launchFinishForces<float>(const float*, const float*, const float*, const float*, const float*, const float*, const int*, int, void*, int, int, hipStream_t);
 template void launchFinishForces<double>(const double*, const double*, const double*, const double*, const double*, const double*, const int*, int, void*, int, int, hipStream_t);
 

@@ -68,18 +68,6 @@ template <typename Real> __device__ inline void bspline5(Real dr, Real* d, Real*
 }
 
 // grid index + fraction (ReferencePME.cpp:245-254)
-template <typename Real> __device__ inline void gridCoord(const Real* recip, Real x, Real y, Real z, int nx, int ny, int nz, int* idx, Real* frac) {
-    const int n[3] = {nx, ny, nz};
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        Real t = x * recip[d] + y * recip[3 + d] + z * recip[6 + d];
-        t = (t - floor(t)) * n[d];
-        int ti = (int)t;
-        frac[d] = t - ti;
-        idx[d] = ti >= n[d] ? ti - n[d] : ti;
-    }
-}
-
 template <typename Real> __device__ inline Real pmeCharge(const PmeParams<Real>& p, int atom) {
     if (p.dispersion) { const auto se = p.sigeps[atom]; return Real(8) * se.x * se.x * se.x * se.y; }   // c6_i (ReferenceSlicedLJCoulombIxn.cpp:247)
     return p.posq[atom].w;
@@ -253,6 +241,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
             int ry = idx[1] - y0; if (ry > hy) ry -= p.d.ny; else if (ry < -hy) ry += p.d.ny;
             Real tx[5], ty[5], tz[5], dtmp[5];
             bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
+            if ((unsigned)(rx + ix) >= (unsigned)cx) continue;   // cannot happen while the scan and this pass agree on the cell; guards the LDS bounds
             const Real wx = q * (ix == 0 ? tx[0] : ix == 1 ? tx[1] : ix == 2 ? tx[2] : ix == 3 ? tx[3] : tx[4]);
             int zi[5];      // z index inside the slab, or -1 when the point belongs to another slab
 #pragma unroll
@@ -363,7 +352,7 @@ template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStrea
         const bool fuse = !noFuse && p.zSlabs == 1 && brickBytes + std::max(listBytes, fftBytes) <= 64 * 1024;
         const size_t lds = brickBytes + (fuse ? std::max(listBytes, fftBytes) : listBytes);
         const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * p.zSlabs;
-        hipLaunchKernelGGL((k_pmeCells<Real>), dim3((p.natoms + 255) / 256), dim3(256), 0, s, p);
+        if (!p.cellsReady) hipLaunchKernelGGL((k_pmeCells<Real>), dim3((p.natoms + 255) / 256), dim3(256), 0, s, p);
 #define SNB_SPREAD(FX, FZ) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real, FX, FZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                              hipLaunchKernelGGL((k_spreadBrick<Real, FX, FZ>), dim3(nblocks), dim3(512), lds, s, p); }
         if constexpr (std::is_same<Real, float>::value) {

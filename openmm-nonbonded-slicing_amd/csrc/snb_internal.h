@@ -66,7 +66,8 @@ template <typename Real> struct PairListParams {  // 1-4 exceptions: one thread 
     int nSlices;
     const int2* pairs;        // 1-4 pairs, USER indices (mapped through userToSorted in the kernel)
     const typename Vec<Real>::T4* params;   // 1-4: (sigma, 4 eps, k*qq, slice bits) ; exclusion: (k*qi*qj, c6i*c6j, -, slice bits)
-    int n;
+    int n;                    // number of 1-4 pairs
+    int nExclAtoms;           // atoms visited by the exclusion-correction part (0: none)
     Real* fx; Real* fy; Real* fz;
     double* sliceE;
     const Real* lambdas;
@@ -93,6 +94,7 @@ template <typename Real> struct PmeParams {
     const int* atomSubset;    // [Npad] sorted
     const int* atomGrid;      // [Npad] grid slot of the atom's subset, or -1 (not owned / padding)
     Real fixScale, fixInv;    // single-precision brick spreader: LDS accumulation in 32-bit fixed point (value * fixScale)
+    int cellsReady;           // cells[] already hold this mesh's cells (written by the position-gather pass)
     int* cells;               // [Npad] scratch: packed mesh cell per atom (k_pmeCells), brick spreader only
     Real* gridReal;           // [nsub][nx][ny][nz]
     typename Vec<Real>::T2* gridCplx;   // [nsub][nx][ny][nzc]
@@ -153,16 +155,33 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, const
 
 // ---- launchers implemented in the .hip translation units -------------------------------------
 template <typename Real> void launchDirect(const DirectParams<Real>& p, int methodClass, bool wrap, bool energy, hipStream_t s);
-template <typename Real> void launchExceptions(const PairListParams<Real>& p, bool energy, hipStream_t s);
-template <typename Real> void launchExclusionCorrection(const PairListParams<Real>& p, bool energy, hipStream_t s);
+template <typename Real> void launchPairLists(const PairListParams<Real>& p, bool energy, hipStream_t s);
 template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStream_t s);   // true: forward z FFT already done
 template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s, bool zDone);
 template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hipStream_t s);   // fused x-FFT, energy, convolution, inverse x-FFT
 template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipStream_t s);
 template <typename Real> void launchPmeFFTX(const PmeParams<Real>& p, int sign, hipStream_t s);   // x axis alone (test hook)
 template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s);
+// fractional mesh coordinate of a position: cell index and offset inside the cell (ReferencePME.cpp:268-305); shared by the PME
+// kernels and the position-gather pass so that both always agree on an atom's cell
+template <typename Real> __device__ inline void gridCoord(const Real* recip, Real x, Real y, Real z, int nx, int ny, int nz, int* idx, Real* frac) {
+    const int n[3] = {nx, ny, nz};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        Real t = x * recip[d] + y * recip[3 + d] + z * recip[6 + d];
+        t = (t - floor(t)) * n[d];
+        int ti = (int)t;
+        frac[d] = t - ti;
+        idx[d] = ti >= n[d] ? ti - n[d] : ti;
+    }
+}
+
+
+// Coulomb-mesh geometry handed to the position-gather pass (cells == nullptr: no mesh / brick spreader not in use)
+template <typename Real> struct GatherCells { Real recip[9]; int nx, ny, nz; int* cells; const int* atomGrid; };
+
 template <typename Real> void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
-                                                    typename Vec<Real>::T4* posq, int nPadded, hipStream_t s);
+                                                    typename Vec<Real>::T4* posq, int nPadded, Real* forces, const GatherCells<Real>& gc, hipStream_t s);
 template <typename Real> void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, const Real* fpx, const Real* fpy, const Real* fpz,
                                                  const int* userToSorted, int nAtoms, void* out, int isDouble, int accumulate, hipStream_t s);
 
