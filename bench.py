@@ -390,7 +390,11 @@ def main():
         se = eng.slice_energies(so.shape[0])
         ferr = float(np.max(np.linalg.norm(f - fo, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)))
         eerr = float(np.max(np.abs(se - so) / np.maximum(np.abs(so), 1.0)))
-        out["check"] = {"max_force_rel_err": ferr, "max_slice_energy_rel_err": eerr}
+        rel = np.linalg.norm(f - fo, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)
+        worst = int(np.argmax(rel))
+        out["check"] = {"max_force_rel_err": ferr, "max_slice_energy_rel_err": eerr, "median_force_rel_err": float(np.median(rel)),
+                        "p999_force_rel_err": float(np.quantile(rel, 0.999)), "worst_atom": worst, "worst_atom_force_norm": float(np.linalg.norm(fo[worst])),
+                        "worst_atom_abs_err": float(np.linalg.norm(f[worst] - fo[worst])), "rms_force": float(np.sqrt(np.mean(np.sum(fo * fo, axis=1))))}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

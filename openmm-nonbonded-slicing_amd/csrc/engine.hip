@@ -197,7 +197,8 @@ public:
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
-    DevBuf<int> pmeCells;
+    DevBuf<int> pmeCells, dZIndex;
+    DevBuf<long long> dNbTrace;
     bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
     double maxAbsQ = 0, maxAbsC6 = 0;
     DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset, exclStart, exclList;
@@ -205,7 +206,7 @@ public:
     DevBuf<int> dUSubset, dSubsetStart, dSubsetPaddedStart, dSlotOfSubset, dValsIn, dValsOut, dCounters; DevBuf<Real> dUCharge, dWrapped, dOffsetU; DevBuf<T2> dUSigEps;
     DevBuf<unsigned char> dPadFlag, dSortTemp; DevBuf<unsigned long long> dKeysIn, dKeysOut; DevBuf<float> dBlockCenter, dBlockHalf;
     std::vector<int> hSubsetStart, hSubsetPaddedStart, staticBlkSubset; int staticNpad = 0; size_t tileCap = 0; bool staticDirty = true, gpuBuilt = false;
-    DevBuf<int2> pairs14, pairsExcl, colRange; DevBuf<int4> tileInfo, workItems, workItemsPartial; int numWorkItems = 0; int colCells[2] = {0, 0}; DevBuf<unsigned> masks;
+    DevBuf<int2> pairs14, pairsExcl, colRange; DevBuf<int4> tileInfo, workItems, workItemsStage, workItemsPartial; int numWorkItems = 0; int colCells[2] = {0, 0}; DevBuf<unsigned> masks;
     DevBuf<T4> params14, paramsExcl; int n14 = 0, nExcl = 0;
     DevBuf<double> sliceE;
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
@@ -709,17 +710,18 @@ public:
         // outputs / scratch
         posq.resize(Npad); sigeps.resize(Npad); imageOffset.resize((size_t)3 * Npad);
         dSortedToUser.resize(Npad); dUserToSorted.resize(N); atomSubset.resize(Npad); atomGrid.resize(Npad);
-        colRange.resize((size_t)nsub * ncx * ncy);
+        colRange.resize((size_t)nsub * ncx * ncy); dZIndex.resize((size_t)nsub * ncx * ncy * 65);
         forceBuf.resize((size_t)6 * Npad);
         fx.p = forceBuf.p; fy.p = fx.p + Npad; fz.p = fy.p + Npad; fpx.p = fz.p + Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
         blockSubset.upload(staticBlkSubset, stream);
         dWrapped.resize((size_t)3 * N); dOffsetU.resize((size_t)3 * N); dKeysIn.resize(N); dKeysOut.resize(N); dValsIn.resize(N); dValsOut.resize(N);
-        dBlockCenter.resize((size_t)3 * numBlocks); dBlockHalf.resize((size_t)3 * numBlocks); dCounters.resize(8);
+        dBlockCenter.resize((size_t)3 * numBlocks); dBlockHalf.resize((size_t)3 * numBlocks); dCounters.resize(32 * 65);
         const size_t tempBytes = nbSortTempBytes<Real>(N);
         dSortTemp.resize(tempBytes);
         if (tileCap < (size_t)numBlocks * 40) tileCap = (size_t)numBlocks * 40;
+        if (tileCap < 64 * 128) tileCap = 64 * 128;      // 64 allocation partitions, each with room for a few blocks' worth of tiles
         for (int attempt = 0; attempt < 3; attempt++) {
-            tileJ.resize(tileCap * 32); tileInfo.resize(tileCap); masks.resize(tileCap * 32); workItems.resize(tileCap / 4 + 2 * numBlocks + 16); workItemsPartial.resize(tileCap / 4 + 2 * numBlocks + 16);
+            tileJ.resize(tileCap * 32); tileInfo.resize(tileCap); masks.resize(tileCap * 32); workItems.resize(2 * (tileCap / 4 + 2 * numBlocks + 64)); workItemsStage.resize(tileCap / 4 + 2 * numBlocks + 64); workItemsPartial.resize(tileCap / 4 + 2 * numBlocks + 64);
             NbParams<Real> p;
             std::memset(&p, 0, sizeof(p));
             p.nAtoms = N; p.nPadded = Npad; p.nBlocks = numBlocks; p.nSubsets = nsub; p.ncx = ncx; p.ncy = ncy;
@@ -730,9 +732,12 @@ public:
             p.wrapped = dWrapped.p; p.offsetU = dOffsetU.p; p.keysIn = dKeysIn.p; p.keysOut = dKeysOut.p; p.valsIn = dValsIn.p; p.valsOut = dValsOut.p;
             p.blockCenter = dBlockCenter.p; p.blockHalf = dBlockHalf.p;
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
-            p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p;
-            p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.workItems = workItems.p; p.workItemsPartial = workItemsPartial.p; p.counters = dCounters.p;
-            p.tileCapacity = (int)tileCap; p.workCapacity = (int)(tileCap / 4 + 2 * numBlocks + 16); p.maskCapacity = (int)tileCap;
+            p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;
+            { static const int dbgBits = getenv("SNB_DBG") ? atoi(getenv("SNB_DBG")) : 0; p.dbg = dbgBits >> 8; }
+            static const bool nbTrace = getenv("SNB_NB_TRACE") != nullptr;
+            if (nbTrace) { dNbTrace.resize((size_t)4 * numBlocks); p.dbgOut = dNbTrace.p; }
+            p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.workItems = workItems.p; p.workItemsStage = workItemsStage.p; p.workItemsPartial = workItemsPartial.p; p.counters = dCounters.p;
+            p.tileCapacity = (int)tileCap; p.workCapacity = (int)(tileCap / 4 + 2 * numBlocks + 64); p.maskCapacity = (int)tileCap;
             if (!evRebuild[0]) { HIPCHECK(hipEventCreate(&evRebuild[0])); HIPCHECK(hipEventCreate(&evRebuild[1])); }
             HIPCHECK(hipEventRecord(evRebuild[0], stream));
             launchNeighborBuild<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream);
@@ -740,8 +745,23 @@ public:
             int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(h), hipMemcpyDeviceToHost, stream));
             HIPCHECK(hipStreamSynchronize(stream));
+            if (nbTrace && h[3] == 0) {
+                std::vector<long long> tr((size_t)4 * numBlocks);
+                HIPCHECK(hipMemcpy(tr.data(), dNbTrace.p, sizeof(long long) * tr.size(), hipMemcpyDeviceToHost));
+                long long t0min = tr[0], t1max = tr[1]; std::vector<long long> dur(numBlocks);
+                tr.resize((size_t)4 * numBlocks);
+                for (int b = 0; b < numBlocks; b++) { t0min = std::min(t0min, tr[2 * b]); t1max = std::max(t1max, tr[2 * b + 1]); dur[b] = tr[2 * b + 1] - tr[2 * b]; }
+                std::vector<long long> sorted = dur; std::sort(sorted.begin(), sorted.end());
+                fprintf(stderr, "[snb] nb trace: span %.1f us; per-block duration median %.1f us, p90 %.1f, p99 %.1f, max %.1f us; last start at %.1f us\n", (t1max - t0min) / 100.0, sorted[numBlocks / 2] / 100.0,
+                        sorted[numBlocks * 9 / 10] / 100.0, sorted[numBlocks * 99 / 100] / 100.0, sorted.back() / 100.0, (t1max - t0min) / 100.0);
+                { std::vector<long long> a(numBlocks), b(numBlocks), c(numBlocks);
+                  for (int k = 0; k < numBlocks; k++) { a[k] = tr[2 * numBlocks + 2 * k] - tr[2 * k]; b[k] = tr[2 * numBlocks + 2 * k + 1] - tr[2 * numBlocks + 2 * k]; c[k] = tr[2 * k + 1] - tr[2 * numBlocks + 2 * k + 1]; }
+                  std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end()); std::sort(c.begin(), c.end());
+                  fprintf(stderr, "[snb] nb trace: median prologue %.1f us, gather %.1f us, final flush %.1f us\n", a[numBlocks / 2] / 100.0, b[numBlocks / 2] / 100.0, c[numBlocks / 2] / 100.0); }
+                long long lastStart = 0; for (int b = 0; b < numBlocks; b++) lastStart = std::max(lastStart, tr[2 * b] - t0min);
+                fprintf(stderr, "[snb] nb trace: last block start %.1f us after the first\n", lastStart / 100.0);
+            }
             if (h[3] == 0) {
-                if (h[4] > 0) HIPCHECK(hipMemcpyAsync(workItems.p + h[1], workItemsPartial.p, sizeof(int4) * h[4], hipMemcpyDeviceToDevice, stream));
                 numTiles = h[0]; numWorkItems = h[1] + h[4]; numMaskTiles = h[2]; wrapMode = false;
                 shardTiles = numTiles / cfg.shard_count;
                 gpuBuilt = true;
@@ -754,7 +774,8 @@ public:
                 return true;
             }
             if (getenv("SNB_VERBOSE")) fprintf(stderr, "[snb] gpu neighbour build attempt %d: tiles %d work %d masks %d overflow %d (cap %zu)\n", attempt, h[0], h[1], h[2], h[3], tileCap);
-            if ((size_t)h[0] > tileCap || (size_t)h[2] > tileCap) { tileCap = (size_t)std::max(h[0], h[2]) * 5 / 4 + 1024; continue; }   // capacity: grow and retry
+            // capacity: a partition (1/64 of the arrays) ran out of tiles, masks or work items -> grow and retry
+            if ((size_t)h[5] > tileCap / 64 || (size_t)h[6] > (tileCap / 4 + 2 * numBlocks + 64) / 64) { tileCap = std::max((size_t)h[5] * 64 * 5 / 4, tileCap * 3 / 2) + 4096; continue; }
             return false;   // a block gathered more than its LDS list holds, or a block is too extended for tile images: host path
         }
         return false;

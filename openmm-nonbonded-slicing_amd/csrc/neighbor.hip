@@ -53,8 +53,19 @@ template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     const int col = cx * p.ncy + cy;
     const bool first = (t == 0) || ((p.keysOut[t - 1] >> 20) != (key >> 20));
     const bool last = (t == p.nAtoms - 1) || ((p.keysOut[t + 1] >> 20) != (key >> 20));
+    // z-bucket histogram of the (subset, column) run: 64 buckets of the key's 20-bit z (already direction-flipped for odd columns,
+    // so every run ascends in it); k_nbZPrefix turns the counts into run offsets the tile builder looks candidates up with
+    atomicAdd(&p.zIndex[((size_t)s * p.ncx * p.ncy + col) * 65 + (int)((key & 0xFFFFF) >> 14) + 1], 1);
     if (first) p.colRange[(size_t)s * p.ncx * p.ncy + col].x = si;
     if (last) p.colRange[(size_t)s * p.ncx * p.ncy + col].y = si + 1;
+}
+
+template <typename Real> __global__ void k_nbZPrefix(const NbParams<Real> p) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.nSubsets * p.ncx * p.ncy) return;
+    int* h = p.zIndex + (size_t)c * 65;
+    int acc = 0;
+    for (int b = 0; b <= 64; b++) { acc += h[b]; h[b] = acc; }     // h[b] = atoms of the run with bucket < b
 }
 
 // padding slots: static far-away coordinates with zero parameters (they are also masked out of every tile)
@@ -98,6 +109,8 @@ template <typename Real> __global__ void k_nbBounds(const NbParams<Real> p) {
 __device__ inline bool ownsPair(int I, int J) { return ((I + J) & 1) ? (I > J) : (I < J); }
 __device__ inline int lanePrefix(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0)); }
 
+constexpr int NB_PARTS = 64;         // allocation counters are partitioned (block I -> partition I % 64, one 128-byte line each): 9 k wavefronts bumping the
+                                     // same three counters were serialised in L2 and cost ~250 us of a 600 us build
 constexpr int NB_CAP = 1024;        // j entries gathered per published chunk (32 tiles); larger neighbourhoods publish several chunks
 constexpr int NB_MAXT = NB_CAP / 32;
 
@@ -127,15 +140,18 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     __shared__ int s_tileSub[4][NB_MAXT];
     __shared__ int s_query[4][128];      // exclusion partners (sorted index) still to be located in the gathered list
     __shared__ int s_qrow[4][128];       // ... and the i-row each belongs to
+    __shared__ int s_cmb[4][3][64];      // candidate runs of the current batch of (column, z image) combinations: start, exclusive prefix, image code
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int I = blockIdx.x * 4 + wid;
     if (I >= p.nBlocks) return;
+    const long long tStart = p.dbgOut ? (long long)wall_clock64() : 0;
     int* list = s_list[wid];
     unsigned (*mask)[32] = s_mask[wid];
     int* tileSub = s_tileSub[wid];
     int* query = s_query[wid];
     int* qrow = s_qrow[wid];
+    int* cmbStart = s_cmb[wid][0]; int* cmbPrefix = s_cmb[wid][1]; int* cmbCode = s_cmb[wid][2];
     const float R = p.listCutoff, R2 = R * R;
     const float cxx = p.blockCenter[3 * I], cyy = p.blockCenter[3 * I + 1], czz = p.blockCenter[3 * I + 2];
     const float hx = p.blockHalf[3 * I], hy = p.blockHalf[3 * I + 1], hz = p.blockHalf[3 * I + 2];
@@ -164,13 +180,19 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         }
         __builtin_amdgcn_wave_barrier();
         // exclusions: partners inside the block hit the diagonal tile directly; the others are looked up in the list
+        // every lane keeps its share of the gathered list in registers (entry k = lane + 64 r) and compares it with each queued partner:
+        // one LDS broadcast per query instead of a pass over the LDS list per query
+        int mine[NB_CAP / 64];
+#pragma unroll
+        for (int r = 0; r < NB_CAP / 64; r++) { const int k2 = lane + 64 * r; const int e = (k2 < count && !(hasDiag && k2 < 32)) ? list[k2] : -1; mine[r] = (e == -1) ? -1 : (e & SNB_JIDX_MASK); }
         auto resolve = [&](int nq) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (int qi = 0; qi < nq; qi++) {
                 const int target = query[qi], row = qrow[qi];
-                for (int k2 = (hasDiag ? 32 : 0) + lane; k2 < count; k2 += 64)
-                    if (list[k2] != -1 && (list[k2] & SNB_JIDX_MASK) == target) atomicOr(&mask[k2 >> 5][row], 1u << (k2 & 31));
+#pragma unroll
+                for (int r = 0; r < NB_CAP / 64; r++)
+                    if (mine[r] == target) { const int k2 = lane + 64 * r; atomicOr(&mask[k2 >> 5][row], 1u << (k2 & 31)); }
             }
             __builtin_amdgcn_wave_barrier();
         };
@@ -179,6 +201,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         int maxLen = e1 - e0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(maxLen, o, 64); maxLen = maxLen > other ? maxLen : other; }
+        if (p.dbg & 1) maxLen = 0;
         for (int k = 0; k < maxLen; k++) {
             bool want = false; int sp = -1;
             if (half == 0 && e0 + k < e1) {
@@ -201,27 +224,43 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         // ones behind the full ones so that the short items fill the tail of the launch
         int first = 0, w0 = 0, wp = 0;
         const int nFull = nT / 8, nPart = (nT & 7) ? 1 : 0;
-        if (lane == 0) { first = atomicAdd(&p.counters[0], nT); w0 = atomicAdd(&p.counters[1], nFull); wp = nPart ? atomicAdd(&p.counters[4], 1) : 0; }
+        const int part = I & (NB_PARTS - 1);
+        int* cnt = p.counters + 32 * (1 + part);
+        const int tileRegion = p.tileCapacity / NB_PARTS, workRegion = p.workCapacity / NB_PARTS;
+        if (lane == 0) { first = atomicAdd(&cnt[0], nT); w0 = atomicAdd(&cnt[1], nFull); wp = nPart ? atomicAdd(&cnt[4], 1) : 0; }
         first = __builtin_amdgcn_readfirstlane(first); w0 = __builtin_amdgcn_readfirstlane(w0); wp = __builtin_amdgcn_readfirstlane(wp);
-        if (first + nT > p.tileCapacity || w0 + nFull > p.workCapacity || wp + nPart > p.workCapacity) { failed = true; return; }
+        if (first + nT > tileRegion || w0 + nFull > workRegion || wp + nPart > workRegion) { failed = true; return; }   // the host grows the regions and retries
+        first += part * tileRegion; w0 += part * workRegion; wp += part * workRegion;
+        if (p.dbg & 2) return;
         for (int k = lane; k < count; k += 64) p.tileJ[(size_t)first * 32 + k] = list[k];
-        for (int t = 0; t < nT; t++) {
-            const unsigned row = (lane < 32) ? mask[t][lane] : 0u;
-            const bool any = __ballot(row != 0u) != 0ull;
-            int mi = -1;
-            if (any) {
-                if (lane == 0) mi = atomicAdd(&p.counters[2], 1);
-                mi = __builtin_amdgcn_readfirstlane(mi);
-                if (mi >= p.maskCapacity) { failed = true; return; }
-                if (lane < 32) p.masks[(size_t)mi * 32 + lane] = row;
-            }
-            if (lane == 0) p.tileInfo[first + t] = make_int4(tileSub[t], mi, 0, 0);
+        // mask words: lanes 0..31 handle the rows of even tiles, lanes 32..63 of odd tiles; one allocation for all masked tiles of the chunk
+        unsigned long long anyBits = 0ull;      // bit t = tile t has a non-zero mask
+        for (int t2 = 0; t2 < nT; t2 += 2) {
+            const int t = t2 + half;
+            const unsigned row = (t < nT) ? mask[t][il] : 0u;
+            const unsigned long long bal = __ballot(row != 0u);
+            if ((unsigned)bal) anyBits |= 1ull << t2;
+            if ((unsigned)(bal >> 32)) anyBits |= 1ull << (t2 + 1);
         }
-        for (int k = lane; k < nFull; k += 64) p.workItems[w0 + k] = make_int4(I, first + 8 * k, 8, 0);
+        const int nMasked = __popcll(anyBits);
+        int mi0 = 0;
+        if (nMasked > 0) {
+            if (lane == 0) mi0 = atomicAdd(&cnt[2], nMasked);
+            mi0 = __builtin_amdgcn_readfirstlane(mi0);
+            if (mi0 + nMasked > p.maskCapacity / NB_PARTS) { failed = true; return; }
+            mi0 += part * (p.maskCapacity / NB_PARTS);
+        }
+        for (int t2 = 0; t2 < nT; t2 += 2) {
+            const int t = t2 + half;
+            if (t < nT && ((anyBits >> t) & 1ull)) p.masks[(size_t)(mi0 + __popcll(anyBits & ((1ull << t) - 1ull))) * 32 + il] = mask[t][il];
+        }
+        for (int t = lane; t < nT; t += 64) p.tileInfo[first + t] = make_int4(tileSub[t], ((anyBits >> t) & 1ull) ? mi0 + __popcll(anyBits & ((1ull << t) - 1ull)) : -1, 0, 0);
+        for (int k = lane; k < nFull; k += 64) p.workItemsStage[w0 + k] = make_int4(I, first + 8 * k, 8, 0);
         if (nPart && lane == 0) p.workItemsPartial[wp] = make_int4(I, first + 8 * nFull, nT & 7, 0);
         __builtin_amdgcn_wave_barrier();
     };
 
+    const long long tProlog = p.dbgOut ? (long long)wall_clock64() : 0;
     // diagonal tile
     if (lane < 32) list[lane] = (uI >= 0) ? ((I * 32 + lane) | (13 << SNB_JSHIFT_BITS)) : -1;
     if (lane == 0) tileSub[0] = p.blockSubset[I];
@@ -231,55 +270,81 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     const int cx0 = (int)floorf((cxx - hx - R) / colW), cx1 = (int)floorf((cxx + hx + R) / colW);
     const int cy0 = (int)floorf((cyy - hy - R) / colH), cy1 = (int)floorf((cyy + hy + R) / colH);
     const float zlo = czz - hz - R, zhi = czz + hz + R;
+    const int nCombX = cx1 - cx0 + 1, nCombY = cy1 - cy0 + 1, nComb = nCombX * nCombY * 3;
+    const float eps = 2e-6f * Lz + 1e-6f;                 // quantised sort keys: widen by a hair
     for (int s = 0; s < p.nSubsets && !failed; s++) {
         int segStart = count;
         const int2* ranges = p.colRange + (size_t)s * p.ncx * p.ncy;
-        for (int gx = cx0; gx <= cx1 && !failed; gx++) {
-            const int kx = (gx < 0) ? -1 : (gx >= p.ncx ? 1 : 0);
-            const int ccx = gx - kx * p.ncx;
-            if (ccx < 0 || ccx >= p.ncx) continue;
-            for (int gy = cy0; gy <= cy1 && !failed; gy++) {
-                const int ky = (gy < 0) ? -1 : (gy >= p.ncy ? 1 : 0);
-                const int ccy = gy - ky * p.ncy;
-                if (ccy < 0 || ccy >= p.ncy) continue;
-                const int2 rg = ranges[ccx * p.ncy + ccy];
-                if (rg.y <= rg.x) continue;
-                const int serp = ccx * p.ncy + ((ccx & 1) ? (p.ncy - 1 - ccy) : ccy);
-                const bool asc = (serp & 1) == 0;
-                for (int kz = -1; kz <= 1 && !failed; kz++) {
-                    const float a = zlo - kz * Lz, b = zhi - kz * Lz;     // wanted z interval in the primary cell
-                    if (b < 0.f || a >= Lz) continue;
-                    const float eps = 2e-6f * Lz + 1e-6f;                 // quantised sort keys: widen by a hair
-                    int i0, i1;
-                    if (asc) { i0 = runLowerBound<Real>(p, rg.x, rg.y, a - eps, true, lane); i1 = runLowerBound<Real>(p, i0, rg.y, b + eps, true, lane); }
-                    else { i0 = runLowerBound<Real>(p, rg.x, rg.y, b + eps, false, lane); i1 = runLowerBound<Real>(p, i0, rg.y, a - eps, false, lane); }
-                    const float sx = kx * Lx, sy = ky * Ly, sz = kz * Lz;
-                    const int code = (kx + 1) * 9 + (ky + 1) * 3 + (kz + 1);
-                    for (int base = i0; base < i1 && !failed; base += 64) {
-                        const int j = base + lane;
-                        bool ok = j < i1;
-                        if (ok) { const int J = j >> 5; ok = (J != I) && ownsPair(I, J); }
-                        if (ok) {
-                            const auto v = p.posq[j];
-                            float dx = fabsf((float)v.x + sx - cxx) - hx, dy = fabsf((float)v.y + sy - cyy) - hy, dz = fabsf((float)v.z + sz - czz) - hz;
-                            dx = dx > 0 ? dx : 0; dy = dy > 0 ? dy : 0; dz = dz > 0 ? dz : 0;
-                            ok = dx * dx + dy * dy + dz * dz < R2;
-                        }
-                        const unsigned long long m = __ballot(ok);
-                        const int nNew = __popcll(m);
-                        if (count + nNew > NB_CAP - 32) {
-                            // list full: close the current segment, publish this chunk and start a fresh list
-                            const int padded = (count + 31) & ~31;
-                            for (int k = count + lane; k < padded; k += 64) list[k] = -1;
-                            for (int t = (segStart >> 5) + lane; t < (padded >> 5); t += 64) tileSub[t] = s;
-                            flush(padded, hasDiag);
-                            hasDiag = false; count = 0; segStart = 0;
-                        }
-                        if (ok) list[count + lanePrefix(m)] = j | (code << SNB_JSHIFT_BITS);
-                        count += nNew;
+        const int* zIndex = p.zIndex + (size_t)s * p.ncx * p.ncy * 65;
+        // One lane per (column, z image) combination: candidate run = the column's atoms whose z bucket overlaps the wanted interval
+        // (bucket offsets from k_nbZPrefix, no search).  The runs of up to 64 combinations are concatenated and walked 64 candidates
+        // at a time, so every pass has full lanes and independent loads.
+        for (int c0 = 0; c0 < nComb && !failed; c0 += 64) {
+            const int c = c0 + lane;
+            int cStart = 0, cLen = 0, cCode = 0;
+            if (c < nComb) {
+                const int kzI = c % 3, cxy = c / 3;
+                const int gx = cx0 + cxy / nCombY, gy = cy0 + cxy % nCombY, kz = kzI - 1;
+                const int kx = (gx < 0) ? -1 : (gx >= p.ncx ? 1 : 0), ky = (gy < 0) ? -1 : (gy >= p.ncy ? 1 : 0);
+                const int ccx = gx - kx * p.ncx, ccy = gy - ky * p.ncy;
+                const float a = zlo - kz * Lz, b = zhi - kz * Lz;     // wanted z interval in the primary cell
+                if (ccx >= 0 && ccx < p.ncx && ccy >= 0 && ccy < p.ncy && !(b < 0.f || a >= Lz)) {
+                    const int col = ccx * p.ncy + ccy;
+                    const int2 rg = ranges[col];
+                    if (rg.y > rg.x) {
+                        const int serp = ccx * p.ncy + ((ccx & 1) ? (p.ncy - 1 - ccy) : ccy);
+                        float fa = (a - eps) / Lz, fb = (b + eps) / Lz;
+                        fa = fa < 0.f ? 0.f : (fa > 1.f ? 1.f : fa); fb = fb < 0.f ? 0.f : (fb > 1.f ? 1.f : fb);
+                        if (serp & 1) { const float t = 1.f - fb; fb = 1.f - fa; fa = t; }
+                        int blo = ((int)(fa * 1048575.0f) >> 14) - 1, bhi = ((int)(fb * 1048575.0f) >> 14) + 1;   // one bucket of slack for float rounding
+                        blo = blo < 0 ? 0 : blo; bhi = bhi > 63 ? 63 : bhi;
+                        const int* zi = zIndex + (size_t)col * 65;
+                        cStart = rg.x + zi[blo]; cLen = zi[bhi + 1] - zi[blo];
+                        cCode = (kx + 1) * 9 + (ky + 1) * 3 + (kz + 1);
                     }
                 }
             }
+            int incl = cLen;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            const int total = __shfl(incl, 63, 64);
+            __builtin_amdgcn_wave_barrier();
+            cmbStart[lane] = cStart; cmbPrefix[lane] = incl - cLen; cmbCode[lane] = cCode;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int v0 = 0; v0 < ((p.dbg & 4) ? 0 : total) && !failed; v0 += 64) {
+                const int v = v0 + lane;
+                bool ok = v < total;
+                int j = 0, code = 13;
+                if (ok) {
+                    int k = 0;     // last combination whose exclusive prefix is <= v (empty combinations share a prefix: skip past them)
+#pragma unroll
+                    for (int st = 32; st > 0; st >>= 1) if (k + st < 64 && cmbPrefix[k + st] <= v) k += st;
+                    j = cmbStart[k] + (v - cmbPrefix[k]); code = cmbCode[k];
+                    const int J = j >> 5;
+                    ok = (J != I) && ownsPair(I, J);
+                }
+                if (ok) {
+                    const int kx = code / 9 - 1, ky = (code / 3) % 3 - 1, kz = code % 3 - 1;
+                    const auto q = p.posq[j];
+                    float dx = fabsf((float)q.x + kx * Lx - cxx) - hx, dy = fabsf((float)q.y + ky * Ly - cyy) - hy, dz = fabsf((float)q.z + kz * Lz - czz) - hz;
+                    dx = dx > 0 ? dx : 0; dy = dy > 0 ? dy : 0; dz = dz > 0 ? dz : 0;
+                    ok = dx * dx + dy * dy + dz * dz < R2;
+                }
+                const unsigned long long m = __ballot(ok);
+                const int nNew = __popcll(m);
+                if (count + nNew > NB_CAP - 32) {
+                    // list full: close the current segment, publish this chunk and start a fresh list
+                    const int padded = (count + 31) & ~31;
+                    for (int k = count + lane; k < padded; k += 64) list[k] = -1;
+                    for (int t = (segStart >> 5) + lane; t < (padded >> 5); t += 64) tileSub[t] = s;
+                    flush(padded, hasDiag);
+                    hasDiag = false; count = 0; segStart = 0;
+                }
+                if (ok) list[count + lanePrefix(m)] = j | (code << SNB_JSHIFT_BITS);
+                count += nNew;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         // close the subset segment: pad to a whole tile, record the tiles' subset
         const int padded = (count + 31) & ~31;
@@ -287,8 +352,35 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         for (int t = (segStart >> 5) + lane; t < (padded >> 5); t += 64) tileSub[t] = s;
         count = padded;
     }
+    const long long tGather = p.dbgOut ? (long long)wall_clock64() : 0;
     if (!failed && count > 0) flush(count, hasDiag);
     if (failed && lane == 0) atomicAdd(&p.counters[3], 1);
+    if (p.dbgOut && lane == 0) { p.dbgOut[2 * I] = tStart; p.dbgOut[2 * I + 1] = (long long)wall_clock64(); p.dbgOut[2 * p.nBlocks + 2 * I] = tProlog; p.dbgOut[2 * p.nBlocks + 2 * I + 1] = tGather; }
+}
+
+// ---- 5. work items of the 64 partitions -> one contiguous array, full (8-tile) items first; totals into counters[0..7] ------------
+template <typename Real> __global__ __launch_bounds__(256) void k_nbCompactWork(const NbParams<Real> p) {
+    __shared__ int s_off[2][NB_PARTS + 1];
+    if (threadIdx.x == 0) {
+        int accF = 0, accP = 0, tiles = 0, masksN = 0, maxTiles = 0, maxWork = 0;
+        for (int q = 0; q < NB_PARTS; q++) {
+            const int* c = p.counters + 32 * (1 + q);
+            s_off[0][q] = accF; s_off[1][q] = accP;
+            accF += c[1]; accP += c[4]; tiles += c[0]; masksN += c[2];
+            maxTiles = maxTiles > c[0] ? maxTiles : c[0]; maxTiles = maxTiles > c[2] ? maxTiles : c[2];
+            maxWork = maxWork > c[1] ? maxWork : c[1]; maxWork = maxWork > c[4] ? maxWork : c[4];
+        }
+        s_off[0][NB_PARTS] = accF; s_off[1][NB_PARTS] = accP;
+        if (blockIdx.x == 0) { p.counters[0] = tiles; p.counters[1] = accF; p.counters[2] = masksN; p.counters[4] = accP; p.counters[5] = maxTiles; p.counters[6] = maxWork; }
+    }
+    __syncthreads();
+    const int q = blockIdx.x % NB_PARTS, which = blockIdx.x / NB_PARTS;      // which = 0: full items, 1: partial items
+    const int workRegion = p.workCapacity / NB_PARTS;
+    const int n = s_off[which][q + 1] - s_off[which][q];
+    const int4* src = (which ? p.workItemsPartial : p.workItemsStage) + (size_t)q * workRegion;
+    int4* dst = p.workItems + (which ? s_off[0][NB_PARTS] : 0) + s_off[which][q];
+    if (n > workRegion) return;      // overflowed partition: the host retries with larger regions
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
 // ---- driver ---------------------------------------------------------------------------------------------------------
@@ -303,16 +395,19 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, const
     const int n = p.nAtoms;
     const int stride = stride4 ? 4 : 3;
     dim3 block(256), gridN((n + 255) / 256);
-    (void)hipMemsetAsync(p.counters, 0, sizeof(int) * 8, s);
+    (void)hipMemsetAsync(p.counters, 0, sizeof(int) * 32 * (1 + NB_PARTS), s);
     (void)hipMemsetAsync(p.colRange, 0, sizeof(int2) * (size_t)p.nSubsets * p.ncx * p.ncy, s);
+    (void)hipMemsetAsync(p.zIndex, 0, sizeof(int) * (size_t)p.nSubsets * p.ncx * p.ncy * 65, s);
     if (n > 0) {
         if (isDouble) hipLaunchKernelGGL((k_nbKeys<Real, double>), gridN, block, 0, s, p, (const double*)userPos, stride);
         else hipLaunchKernelGGL((k_nbKeys<Real, float>), gridN, block, 0, s, p, (const float*)userPos, stride);
         (void)rocprim::radix_sort_pairs(sortTemp, sortTempBytes, p.keysIn, p.keysOut, p.valsIn, p.valsOut, (size_t)n, 0, 44 + p.subsetBits, s);
         hipLaunchKernelGGL((k_nbPad<Real>), dim3((p.nPadded + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbScatter<Real>), gridN, block, 0, s, p);
+        hipLaunchKernelGGL((k_nbZPrefix<Real>), dim3((p.nSubsets * p.ncx * p.ncy + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbBounds<Real>), dim3((p.nBlocks + 7) / 8), block, 0, s, p);
         hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((p.nBlocks + 3) / 4), block, 0, s, p);
+        hipLaunchKernelGGL((k_nbCompactWork<Real>), dim3(2 * NB_PARTS), block, 0, s, p);
     }
 }
 

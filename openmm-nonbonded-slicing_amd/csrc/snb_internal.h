@@ -146,9 +146,13 @@ template <typename Real> struct NbParams {
     // outputs
     int* sortedToUser; int* userToSorted; typename Vec<Real>::T4* posq; typename Vec<Real>::T2* sigeps; Real* imageOffset;
     int* atomSubset; int* atomGrid; int2* colRange;
-    int* tileJ; int4* tileInfo; unsigned* masks; int4* workItems; int4* workItemsPartial;
-    int* counters;   // [0] tiles, [1] full work items, [2] masks, [3] overflow events, [4] partial work items
+    int* zIndex;     // [nSubsets * ncx * ncy][65] atoms of the (subset, column) run below each of 64 z buckets (scratch of the builder)
+    int* tileJ; int4* tileInfo; unsigned* masks; int4* workItems; int4* workItemsStage; int4* workItemsPartial;
+    int* counters;   // [32 * 65]: line 0 = totals ([0] tiles, [1] full work items, [2] masks, [3] overflow events, [4] partial items, [5] max tiles|masks and
+                     // [6] max work items of a partition), lines 1..64 = the partitions' allocation counters (same slots)
     int tileCapacity, workCapacity, maskCapacity;
+    int dbg;         // SNB_DBG experiment bits (timing decomposition only)
+    long long* dbgOut;   // SNB_NB_TRACE: per-block start/end wall_clock64 stamps (100 MHz) of the tile builder
 };
 template <typename Real> size_t nbSortTempBytes(int n);
 template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, const void* userPos, int isDouble, int stride4, void* sortTemp, size_t sortTempBytes, hipStream_t s);
