@@ -177,7 +177,7 @@ public:
     hipStream_t stream = nullptr; bool ownStream = false;
     // ring of per-execute event sets, harvested lazily into cumulative kernel times (no per-step host sync)
     static constexpr int RING = 32;
-    hipEvent_t evRebuild[2] = {nullptr, nullptr};
+    hipEvent_t evRebuild[3] = {nullptr, nullptr, nullptr};
     hipStream_t stream2 = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;
     // measured on c3: serial 0.80 ms/step, forked 0.87 (default priority) / 1.32 (high or low priority): the graph's cross-stream
     // dependencies cost more than the overlap returns, so the fork is opt-in
@@ -197,7 +197,7 @@ public:
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
-    DevBuf<int> pmeCells, dZIndex;
+    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB;
     DevBuf<long long> dNbTrace;
     bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
     double maxAbsQ = 0, maxAbsC6 = 0;
@@ -254,7 +254,7 @@ public:
         (void)hipStreamSynchronize(stream);
         dropGraph();
         for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
-        for (int k = 0; k < 2; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
+        for (int k = 0; k < 3; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
         if (stream2) { (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); (void)hipStreamDestroy(stream2); }
         if (ownStream) (void)hipStreamDestroy(stream);
     }
@@ -339,8 +339,8 @@ public:
         dropGraph();   // buffers may move and every kernel argument block changes
         if (staticDirty) uploadStatic();
         gpuBuilt = false;
-        if (!cfg.host_neighbor_build && gpuRebuild()) return;
-        hostRebuild();
+        if (cfg.host_neighbor_build || !gpuRebuild()) hostRebuild();
+        pmeCells.resize(Npad);   // per-slot scratch is sized here: nothing may allocate while a step is being captured into a graph
     }
 
     void hostRebuild() {
@@ -439,7 +439,7 @@ public:
             }
             colRange.upload(hRange, stream);
         }
-        if (Npad >= (1 << SNB_JSHIFT_BITS) - 1) throw HipError{"too many atoms for the 27-bit tile index"};
+        if (Npad >= (1 << SNB_JSHIFT_BITS) - 1) throw HipError{"too many atoms for the 25-bit tile index"};
         // 4. sorted parameter arrays
         std::vector<T4> hPosq(Npad); std::vector<T2> hSigeps(Npad); std::vector<Real> hOff((size_t)Npad * 3, Real(0));
         std::vector<int> hAtomSubset(Npad, -1), hAtomGrid(Npad, -1);
@@ -522,7 +522,7 @@ public:
                 if (allPairs) {
                     for (int J = 0; J < numBlocks; J++) {
                         if (J == I || !owns(I, J)) continue;
-                        for (int k = 0; k < 32; k++) if (sortedToUser[J * 32 + k] >= 0) cand.push_back({J * 32 + k, 13});
+                        for (int k = 0; k < 32; k++) if (sortedToUser[J * 32 + k] >= 0) cand.push_back({J * 32 + k, SNB_JCODE_CENTER});
                     }
                 } else {
                     int cmin[3], cmax[3];
@@ -536,7 +536,7 @@ public:
                         for (int d = 0; d < 3; d++) { img[d] = (int)std::floor((double)cc[d] / nc[d]); cc[d] -= img[d] * nc[d]; }
                         if (std::abs(img[0]) > 1 || std::abs(img[1]) > 1 || std::abs(img[2]) > 1) continue;
                         const double sh[3] = {img[0] * box[0], img[1] * box[4], img[2] * box[8]};
-                        const int code = (img[0] + 1) * 9 + (img[1] + 1) * 3 + (img[2] + 1);
+                        const int code = (img[0] + 2) * 25 + (img[1] + 2) * 5 + (img[2] + 2);
                         const int cell = (cc[0] * nc[1] + cc[1]) * nc[2] + cc[2];
                         for (int a = cellStart[cell]; a < cellStart[cell + 1]; a++) {
                             const int sj = cellAtoms[a]; const int J = sj >> 5;
@@ -558,7 +558,7 @@ public:
             // diagonal tile first
             tileMask.clear();
             {
-                for (int k = 0; k < 32; k++) hTileJ.push_back((sortedToUser[I * 32 + k] >= 0) ? ((I * 32 + k) | (13 << SNB_JSHIFT_BITS)) : -1);
+                for (int k = 0; k < 32; k++) hTileJ.push_back((sortedToUser[I * 32 + k] >= 0) ? ((I * 32 + k) | (SNB_JCODE_CENTER << SNB_JSHIFT_BITS)) : -1);
                 int mi = (int)(hMasks.size() / 32);
                 hMasks.resize(hMasks.size() + 32, 0u);
                 for (int i = 0; i < 32; i++) { unsigned m = 0; for (int j = 0; j <= i; j++) m |= 1u << j; hMasks[(size_t)mi * 32 + i] = m; }   // keep j > i only
@@ -706,30 +706,47 @@ public:
             const int px = pick(pme.d.nx, box[0]), py = pick(pme.d.ny, box[4]);
             if (px > 0 && py > 0 && sizeof(double) * (size_t)px * py * pme.d.nz <= 60 * 1024) { colCells[0] = px; colCells[1] = py; ncx = pme.d.nx / px; ncy = pme.d.ny / py; }
         }
-        Npad = staticNpad; numBlocks = Npad / 32;
-        // outputs / scratch
-        posq.resize(Npad); sigeps.resize(Npad); imageOffset.resize((size_t)3 * Npad);
-        dSortedToUser.resize(Npad); dUserToSorted.resize(N); atomSubset.resize(Npad); atomGrid.resize(Npad);
+        // phase A: sort and block segmentation (the padded atom count depends on where the sorted order jumps)
+        dUserToSorted.resize(N);
         colRange.resize((size_t)nsub * ncx * ncy); dZIndex.resize((size_t)nsub * ncx * ncy * 65);
-        forceBuf.resize((size_t)6 * Npad);
-        fx.p = forceBuf.p; fy.p = fx.p + Npad; fz.p = fy.p + Npad; fpx.p = fz.p + Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
-        blockSubset.upload(staticBlkSubset, stream);
         dWrapped.resize((size_t)3 * N); dOffsetU.resize((size_t)3 * N); dKeysIn.resize(N); dKeysOut.resize(N); dValsIn.resize(N); dValsOut.resize(N);
-        dBlockCenter.resize((size_t)3 * numBlocks); dBlockHalf.resize((size_t)3 * numBlocks); dCounters.resize(32 * 65);
+        dScanA.resize(N); dScanB.resize(N); dCounters.resize(32 * 65);
         const size_t tempBytes = nbSortTempBytes<Real>(N);
         dSortTemp.resize(tempBytes);
+        NbParams<Real> p;
+        std::memset(&p, 0, sizeof(p));
+        p.nAtoms = N; p.nSubsets = nsub; p.ncx = ncx; p.ncy = ncy;
+        p.subsetBits = 1; while ((1 << p.subsetBits) < nsub) p.subsetBits++;
+        p.boxd[0] = box[0]; p.boxd[1] = box[4]; p.boxd[2] = box[8]; p.listCutoff = (float)R;
+        p.jumpDist = (float)(2.0 * std::sqrt(2.0) * std::max(box[0] / ncx, box[4] / ncy));   // neighbours along the sort path of a dense region are closer than this
+        p.uSubset = dUSubset.p; p.uCharge = dUCharge.p; p.uSigEps = dUSigEps.p; p.uExclStart = exclStart.p; p.uExclList = exclList.p;
+        p.slotOfSubset = dSlotOfSubset.p;
+        p.wrapped = dWrapped.p; p.offsetU = dOffsetU.p; p.keysIn = dKeysIn.p; p.keysOut = dKeysOut.p; p.valsIn = dValsIn.p; p.valsOut = dValsOut.p;
+        p.segKey = dValsIn.p; p.segStart = dScanA.p; p.padExtra = dScanB.p; p.padBefore = dScanA.p;   // valsIn is dead once the sort has run
+        p.userToSorted = dUserToSorted.p; p.colRange = colRange.p; p.zIndex = dZIndex.p; p.counters = dCounters.p;
+        if (!evRebuild[0]) { HIPCHECK(hipEventCreate(&evRebuild[0])); HIPCHECK(hipEventCreate(&evRebuild[1])); HIPCHECK(hipEventCreate(&evRebuild[2])); }
+        HIPCHECK(hipEventRecord(evRebuild[0], stream));
+        launchNeighborSort<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream);
+        HIPCHECK(hipEventRecord(evRebuild[2], stream));
+        int npadDev = 0;
+        HIPCHECK(hipMemcpyAsync(&npadDev, dCounters.p + 7, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+        if (npadDev < N || (npadDev & 31)) throw HipError{"neighbour build: inconsistent padded atom count"};
+        Npad = npadDev; numBlocks = Npad / 32;
+        if (Npad >= (1 << SNB_JSHIFT_BITS) - 1) throw HipError{"too many atoms for the 25-bit tile index"};
+        // outputs / scratch sized by the padded count
+        posq.resize(Npad); sigeps.resize(Npad); imageOffset.resize((size_t)3 * Npad);
+        dSortedToUser.resize(Npad); atomSubset.resize(Npad); atomGrid.resize(Npad); blockSubset.resize(numBlocks);
+        forceBuf.resize((size_t)6 * Npad);
+        fx.p = forceBuf.p; fy.p = fx.p + Npad; fz.p = fy.p + Npad; fpx.p = fz.p + Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
+        dBlockCenter.resize((size_t)3 * numBlocks); dBlockHalf.resize((size_t)3 * numBlocks);
         if (tileCap < (size_t)numBlocks * 40) tileCap = (size_t)numBlocks * 40;
         if (tileCap < 64 * 128) tileCap = 64 * 128;      // 64 allocation partitions, each with room for a few blocks' worth of tiles
+        float sortMs = 0;
+        HIPCHECK(hipEventElapsedTime(&sortMs, evRebuild[0], evRebuild[2]));
         for (int attempt = 0; attempt < 3; attempt++) {
             tileJ.resize(tileCap * 32); tileInfo.resize(tileCap); masks.resize(tileCap * 32); workItems.resize(2 * (tileCap / 4 + 2 * numBlocks + 64)); workItemsStage.resize(tileCap / 4 + 2 * numBlocks + 64); workItemsPartial.resize(tileCap / 4 + 2 * numBlocks + 64);
-            NbParams<Real> p;
-            std::memset(&p, 0, sizeof(p));
-            p.nAtoms = N; p.nPadded = Npad; p.nBlocks = numBlocks; p.nSubsets = nsub; p.ncx = ncx; p.ncy = ncy;
-            p.subsetBits = 1; while ((1 << p.subsetBits) < nsub) p.subsetBits++;
-            p.boxd[0] = box[0]; p.boxd[1] = box[4]; p.boxd[2] = box[8]; p.listCutoff = (float)R;
-            p.uSubset = dUSubset.p; p.uCharge = dUCharge.p; p.uSigEps = dUSigEps.p; p.uExclStart = exclStart.p; p.uExclList = exclList.p;
-            p.subsetStart = dSubsetStart.p; p.subsetPaddedStart = dSubsetPaddedStart.p; p.slotOfSubset = dSlotOfSubset.p; p.padFlag = dPadFlag.p; p.blockSubset = blockSubset.p;
-            p.wrapped = dWrapped.p; p.offsetU = dOffsetU.p; p.keysIn = dKeysIn.p; p.keysOut = dKeysOut.p; p.valsIn = dValsIn.p; p.valsOut = dValsOut.p;
+            p.nPadded = Npad; p.nBlocks = numBlocks; p.blockSubset = blockSubset.p;
             p.blockCenter = dBlockCenter.p; p.blockHalf = dBlockHalf.p;
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;
@@ -738,9 +755,8 @@ public:
             if (nbTrace) { dNbTrace.resize((size_t)4 * numBlocks); p.dbgOut = dNbTrace.p; }
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.workItems = workItems.p; p.workItemsStage = workItemsStage.p; p.workItemsPartial = workItemsPartial.p; p.counters = dCounters.p;
             p.tileCapacity = (int)tileCap; p.workCapacity = (int)(tileCap / 4 + 2 * numBlocks + 64); p.maskCapacity = (int)tileCap;
-            if (!evRebuild[0]) { HIPCHECK(hipEventCreate(&evRebuild[0])); HIPCHECK(hipEventCreate(&evRebuild[1])); }
             HIPCHECK(hipEventRecord(evRebuild[0], stream));
-            launchNeighborBuild<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream);
+            launchNeighborBuild<Real>(p, stream);
             HIPCHECK(hipEventRecord(evRebuild[1], stream));
             int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(h), hipMemcpyDeviceToHost, stream));
@@ -769,11 +785,11 @@ public:
                 stats.n_rebuilds++;
                 float gpuMs = 0;   // device time of the build (the host clock would also count the queued steps this call waited for)
                 HIPCHECK(hipEventElapsedTime(&gpuMs, evRebuild[0], evRebuild[1]));
-                stats.last_rebuild_ms = gpuMs;
+                stats.last_rebuild_ms = gpuMs + sortMs;
                 (void)t0;
                 return true;
             }
-            if (getenv("SNB_VERBOSE")) fprintf(stderr, "[snb] gpu neighbour build attempt %d: tiles %d work %d masks %d overflow %d (cap %zu)\n", attempt, h[0], h[1], h[2], h[3], tileCap);
+            if (getenv("SNB_VERBOSE")) fprintf(stderr, "[snb] gpu neighbour build attempt %d: tiles %d work %d masks %d overflow %d partial %d maxPartTiles %d maxPartWork %d (cap %zu, region %zu / %zu)\n", attempt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], tileCap, tileCap / 64, (tileCap / 4 + 2 * numBlocks + 64) / 64);
             // capacity: a partition (1/64 of the arrays) ran out of tiles, masks or work items -> grow and retry
             if ((size_t)h[5] > tileCap / 64 || (size_t)h[6] > (tileCap / 4 + 2 * numBlocks + 64) / 64) { tileCap = std::max((size_t)h[5] * 64 * 5 / 4, tileCap * 3 / 2) + 4096; continue; }
             return false;   // a block gathered more than its LDS list holds, or a block is too extended for tile images: host path
@@ -784,7 +800,7 @@ public:
     // ------------------------------------------------------------------------------------------
     void fillPme(PmeParams<Real>& p, PmePlan<Real>& plan, bool wantEnergy) {
         p.d = plan.d; p.nsub = nGrids; p.natoms = Npad; p.posq = posq.p; p.sigeps = sigeps.p; p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p;
-        pmeCells.resize(Npad); p.cells = pmeCells.p;
+        p.cells = pmeCells.p;
         p.cellsReady = (!plan.dispersion && cellsFromGather) ? 1 : 0;
         {   // fixed point: 16 x the largest per-atom charge fits 31 bits (a grid point collects at most a few atoms' weights, each <= 1)
             const double m = std::max(plan.dispersion ? maxAbsC6 : maxAbsQ, 1e-30);
@@ -929,10 +945,7 @@ public:
             p.invSwitchWidth = (Real)(sw ? 1.0 / (cfg.cutoff - cfg.switch_distance) : 0.0);
             for (int i = 0; i < 9; i++) p.box[i] = (Real)box[i];
             if (isPeriodic()) { p.invBoxDiag[0] = (Real)(1.0 / box[0]); p.invBoxDiag[1] = (Real)(1.0 / box[4]); p.invBoxDiag[2] = (Real)(1.0 / box[8]); }
-            for (int a = -1; a <= 1; a++) for (int b = -1; b <= 1; b++) for (int cc = -1; cc <= 1; cc++) {
-                const int code = (a + 1) * 9 + (b + 1) * 3 + (cc + 1);
-                p.shifts[code * 3] = (Real)(a * box[0]); p.shifts[code * 3 + 1] = (Real)(b * box[4]); p.shifts[code * 3 + 2] = (Real)(cc * box[8]);
-            }
+            p.boxDiag[0] = (Real)box[0]; p.boxDiag[1] = (Real)box[4]; p.boxDiag[2] = (Real)box[8];
             int mc = MC_NOCUTOFF;
             if (cfg.method == SNB_CutoffNonPeriodic || cfg.method == SNB_CutoffPeriodic) mc = MC_RF;
             else if (cfg.method == SNB_Ewald || cfg.method == SNB_PME) mc = MC_EWALD;

@@ -8,6 +8,7 @@
 // tiles and work items with one atomic allocation each.
 #include "snb_internal.h"
 #include <cstring>
+#include <algorithm>
 #include <string.h>
 #include <rocprim/rocprim.hpp>
 
@@ -32,6 +33,44 @@ __global__ void k_nbKeys(const NbParams<Real> p, const In* __restrict__ userPos,
     p.valsIn[u] = u;
 }
 
+// ---- 1b. block segmentation ---------------------------------------------------------------------------------------
+// Blocks are 32 consecutive atoms of the sorted order, but never across a subset boundary and never across a JUMP: two consecutive
+// atoms further apart (minimum image) than `jumpDist` -- the hollow of a shell-shaped subset, scattered ions, a solute straddling the
+// periodic boundary.  Every such segment is padded to a multiple of 32, so a block's bounding box stays small however sparse its
+// subset is.  segKey[t] = t at segment starts (0 elsewhere) -> inclusive max scan = start of t's segment -> padding owed at segment
+// ends -> exclusive sum scan = padding slots before t; padded index of t = t + padBefore[t].
+template <typename Real> __global__ void k_nbJumpFlags(const NbParams<Real> p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.nAtoms) return;
+    bool start = t == 0;
+    if (!start) {
+        start = (p.keysOut[t] >> 44) != (p.keysOut[t - 1] >> 44);
+        if (!start) {
+            const int u = p.valsOut[t], v = p.valsOut[t - 1];
+            float d2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float L = (float)p.boxd[d];
+                float dl = fabsf((float)p.wrapped[3 * (size_t)u + d] - (float)p.wrapped[3 * (size_t)v + d]);
+                dl = dl > 0.5f * L ? L - dl : dl;
+                d2 += dl * dl;
+            }
+            start = d2 > p.jumpDist * p.jumpDist;
+        }
+    }
+    p.segKey[t] = start ? t : 0;
+}
+template <typename Real> __global__ void k_nbPadExtra(const NbParams<Real> p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.nAtoms) return;
+    const bool isEnd = (t == p.nAtoms - 1) || (p.segKey[t + 1] == t + 1);
+    const int len = t - p.segStart[t] + 1;
+    p.padExtra[t] = isEnd ? ((32 - (len & 31)) & 31) : 0;
+}
+template <typename Real> __global__ void k_nbPadTotal(const NbParams<Real> p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.counters[7] = p.nAtoms + p.padBefore[p.nAtoms - 1] + p.padExtra[p.nAtoms - 1];
+}
+
 // ---- 2. scatter into the padded sorted order ---------------------------------------------------------------------
 template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,12 +79,25 @@ template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     const int u = p.valsOut[t];
     const int s = (int)(key >> 44);
     const int serp = (int)((key >> 20) & 0xFFFFFF);
-    const int si = p.subsetPaddedStart[s] + (t - p.subsetStart[s]);
+    const int si = t + p.padBefore[t];
+    if ((si & 31) == 0) p.blockSubset[si >> 5] = s;
     p.sortedToUser[si] = u; p.userToSorted[u] = si;
     typename Vec<Real>::T4 v; v.x = p.wrapped[3 * (size_t)u]; v.y = p.wrapped[3 * (size_t)u + 1]; v.z = p.wrapped[3 * (size_t)u + 2]; v.w = p.uCharge[u];
+    // A 32-atom block of a sparse subset can straddle the periodic boundary (consecutive occupied columns 1 and ncy-2, say): its atoms
+    // are stored in the image nearest to the block's first atom, so that the block's bounding box stays compact.  Stored positions
+    // may therefore lie up to one box length outside [0, L); imageOffset absorbs the shift and tile image codes reach +-2.
+    Real sh[3] = {0, 0, 0};
+    {
+        const int u0 = p.valsOut[t - (si & 31)];           // the block's first atom: blocks never cross segments, so ranks t-(si&31)..t are its atoms
+        const Real L[3] = {(Real)p.boxd[0], (Real)p.boxd[1], (Real)p.boxd[2]};
+        const Real w[3] = {v.x, v.y, v.z};
+#pragma unroll
+        for (int d = 0; d < 3; d++) { const Real dl = w[d] - p.wrapped[3 * (size_t)u0 + d]; sh[d] = dl > Real(0.5) * L[d] ? -L[d] : (dl < Real(-0.5) * L[d] ? L[d] : Real(0)); }
+    }
+    v.x += sh[0]; v.y += sh[1]; v.z += sh[2];
     p.posq[si] = v;
     p.sigeps[si] = p.uSigEps[u];
-    p.imageOffset[3 * (size_t)si] = p.offsetU[3 * (size_t)u]; p.imageOffset[3 * (size_t)si + 1] = p.offsetU[3 * (size_t)u + 1]; p.imageOffset[3 * (size_t)si + 2] = p.offsetU[3 * (size_t)u + 2];
+    p.imageOffset[3 * (size_t)si] = p.offsetU[3 * (size_t)u] + sh[0]; p.imageOffset[3 * (size_t)si + 1] = p.offsetU[3 * (size_t)u + 1] + sh[1]; p.imageOffset[3 * (size_t)si + 2] = p.offsetU[3 * (size_t)u + 2] + sh[2];
     p.atomSubset[si] = s; p.atomGrid[si] = p.slotOfSubset[s];
     // column bookkeeping: linear (non-serpentine) column id, run boundaries of (subset, column)
     const int cx = serp / p.ncy, cyS = serp - cx * p.ncy;
@@ -53,9 +105,10 @@ template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     const int col = cx * p.ncy + cy;
     const bool first = (t == 0) || ((p.keysOut[t - 1] >> 20) != (key >> 20));
     const bool last = (t == p.nAtoms - 1) || ((p.keysOut[t + 1] >> 20) != (key >> 20));
-    // z-bucket histogram of the (subset, column) run: 64 buckets of the key's 20-bit z (already direction-flipped for odd columns,
-    // so every run ascends in it); k_nbZPrefix turns the counts into run offsets the tile builder looks candidates up with
-    atomicAdd(&p.zIndex[((size_t)s * p.ncx * p.ncy + col) * 65 + (int)((key & 0xFFFFF) >> 14) + 1], 1);
+    // z-bucket index of the (subset, column) run: 64 buckets of the key's 20-bit z (already direction-flipped for odd columns, so every
+    // run ascends in it).  zIndex[b] = first padded index of the run with bucket >= b (k_nbZPrefix fills the empty buckets); positions,
+    // not counts, because segment padding may sit inside a run
+    atomicMin(&p.zIndex[((size_t)s * p.ncx * p.ncy + col) * 65 + (int)((key & 0xFFFFF) >> 14)], si);
     if (first) p.colRange[(size_t)s * p.ncx * p.ncy + col].x = si;
     if (last) p.colRange[(size_t)s * p.ncx * p.ncy + col].y = si + 1;
 }
@@ -64,19 +117,21 @@ template <typename Real> __global__ void k_nbZPrefix(const NbParams<Real> p) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= p.nSubsets * p.ncx * p.ncy) return;
     int* h = p.zIndex + (size_t)c * 65;
-    int acc = 0;
-    for (int b = 0; b <= 64; b++) { acc += h[b]; h[b] = acc; }     // h[b] = atoms of the run with bucket < b
+    const int2 rg = p.colRange[c];
+    int nxt = rg.y;                                   // (empty runs have rg = (0, 0) and are never looked up)
+    h[64] = nxt;
+    for (int b = 63; b >= 0; b--) { const int v = h[b]; nxt = v < nxt ? v : nxt; h[b] = nxt; }
 }
 
 // padding slots: static far-away coordinates with zero parameters (they are also masked out of every tile)
 template <typename Real> __global__ void k_nbPad(const NbParams<Real> p) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= p.nPadded) return;
-    if (p.padFlag[s]) {
+    if (p.sortedToUser[s] < 0) {
         typename Vec<Real>::T4 v; v.x = (Real)(1e9 + 1e6 * (s & 4095)); v.y = (Real)2e9; v.z = (Real)-3e9; v.w = 0;
         p.posq[s] = v;
         typename Vec<Real>::T2 z; z.x = 0; z.y = 0; p.sigeps[s] = z;
-        p.sortedToUser[s] = -1; p.atomSubset[s] = -1; p.atomGrid[s] = -1;
+        p.atomSubset[s] = -1; p.atomGrid[s] = -1;
         p.imageOffset[3 * (size_t)s] = 0; p.imageOffset[3 * (size_t)s + 1] = 0; p.imageOffset[3 * (size_t)s + 2] = 0;
     }
 }
@@ -262,7 +317,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
 
     const long long tProlog = p.dbgOut ? (long long)wall_clock64() : 0;
     // diagonal tile
-    if (lane < 32) list[lane] = (uI >= 0) ? ((I * 32 + lane) | (13 << SNB_JSHIFT_BITS)) : -1;
+    if (lane < 32) list[lane] = (uI >= 0) ? ((I * 32 + lane) | (SNB_JCODE_CENTER << SNB_JSHIFT_BITS)) : -1;
     if (lane == 0) tileSub[0] = p.blockSubset[I];
     int count = 32;
     bool hasDiag = true;
@@ -299,7 +354,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
                         int blo = ((int)(fa * 1048575.0f) >> 14) - 1, bhi = ((int)(fb * 1048575.0f) >> 14) + 1;   // one bucket of slack for float rounding
                         blo = blo < 0 ? 0 : blo; bhi = bhi > 63 ? 63 : bhi;
                         const int* zi = zIndex + (size_t)col * 65;
-                        cStart = rg.x + zi[blo]; cLen = zi[bhi + 1] - zi[blo];
+                        cStart = zi[blo]; cLen = zi[bhi + 1] - zi[blo];
                         cCode = (kx + 1) * 9 + (ky + 1) * 3 + (kz + 1);
                     }
                 }
@@ -325,11 +380,15 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
                     ok = (J != I) && ownsPair(I, J);
                 }
                 if (ok) {
-                    const int kx = code / 9 - 1, ky = (code / 3) % 3 - 1, kz = code % 3 - 1;
+                    // `code` says which lattice image of the WRAPPED j position is wanted; the stored position may already sit one box
+                    // length off (compact blocks), so the shift applied to it -- and recorded in the tile -- is the difference
+                    int kx = code / 9 - 1, ky = (code / 3) % 3 - 1, kz = code % 3 - 1;
                     const auto q = p.posq[j];
+                    kx -= (int)floorf((float)q.x / Lx); ky -= (int)floorf((float)q.y / Ly); kz -= (int)floorf((float)q.z / Lz);
                     float dx = fabsf((float)q.x + kx * Lx - cxx) - hx, dy = fabsf((float)q.y + ky * Ly - cyy) - hy, dz = fabsf((float)q.z + kz * Lz - czz) - hz;
                     dx = dx > 0 ? dx : 0; dy = dy > 0 ? dy : 0; dz = dz > 0 ? dz : 0;
-                    ok = dx * dx + dy * dy + dz * dz < R2;
+                    ok = (dx * dx + dy * dy + dz * dz < R2) && ((float)q.y < 1e8f);      // padding slots (parked at y = 2e9) can sit inside a run
+                    code = (kx + 2) * 25 + (ky + 2) * 5 + (kz + 2);
                 }
                 const unsigned long long m = __ballot(ok);
                 const int nNew = __popcll(m);
@@ -385,25 +444,44 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbCompactWork(
 
 // ---- driver ---------------------------------------------------------------------------------------------------------
 template <typename Real> size_t nbSortTempBytes(int n) {
-    size_t bytes = 0;
+    size_t bytes = 0, b2 = 0, b3 = 0;
     unsigned long long* k = nullptr; int* v = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0, 64, (hipStream_t)0);
-    return bytes;
+    (void)rocprim::inclusive_scan(nullptr, b2, v, v, (size_t)n, rocprim::maximum<int>(), (hipStream_t)0);
+    (void)rocprim::exclusive_scan(nullptr, b3, v, v, 0, (size_t)n, rocprim::plus<int>(), (hipStream_t)0);
+    return std::max(bytes, std::max(b2, b3));
 }
 
-template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, const void* userPos, int isDouble, int stride4, void* sortTemp, size_t sortTempBytes, hipStream_t s) {
+// Phase A: wrapped coordinates, sort, block segmentation.  Afterwards counters[7] holds the padded atom count (read it back, size the
+// per-slot arrays, then run phase B).
+template <typename Real> void launchNeighborSort(const NbParams<Real>& p, const void* userPos, int isDouble, int stride4, void* sortTemp, size_t sortTempBytes, hipStream_t s) {
     const int n = p.nAtoms;
     const int stride = stride4 ? 4 : 3;
     dim3 block(256), gridN((n + 255) / 256);
     (void)hipMemsetAsync(p.counters, 0, sizeof(int) * 32 * (1 + NB_PARTS), s);
+    if (n <= 0) return;
+    if (isDouble) hipLaunchKernelGGL((k_nbKeys<Real, double>), gridN, block, 0, s, p, (const double*)userPos, stride);
+    else hipLaunchKernelGGL((k_nbKeys<Real, float>), gridN, block, 0, s, p, (const float*)userPos, stride);
+    (void)rocprim::radix_sort_pairs(sortTemp, sortTempBytes, p.keysIn, p.keysOut, p.valsIn, p.valsOut, (size_t)n, 0, 44 + p.subsetBits, s);
+    hipLaunchKernelGGL((k_nbJumpFlags<Real>), gridN, block, 0, s, p);
+    (void)rocprim::inclusive_scan(sortTemp, sortTempBytes, p.segKey, p.segStart, (size_t)n, rocprim::maximum<int>(), s);
+    hipLaunchKernelGGL((k_nbPadExtra<Real>), gridN, block, 0, s, p);
+    (void)rocprim::exclusive_scan(sortTemp, sortTempBytes, p.padExtra, p.padBefore, 0, (size_t)n, rocprim::plus<int>(), s);
+    hipLaunchKernelGGL((k_nbPadTotal<Real>), dim3(1), dim3(64), 0, s, p);
+}
+
+// Phase B: padded sorted arrays, column ranges and z index, block bounds, tiles, work items.
+template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipStream_t s) {
+    const int n = p.nAtoms;
+    dim3 block(256), gridN((n + 255) / 256);
+    (void)hipMemsetAsync(p.counters, 0, sizeof(int) * 7, s);
+    (void)hipMemsetAsync(p.counters + 32, 0, sizeof(int) * 32 * NB_PARTS, s);
     (void)hipMemsetAsync(p.colRange, 0, sizeof(int2) * (size_t)p.nSubsets * p.ncx * p.ncy, s);
-    (void)hipMemsetAsync(p.zIndex, 0, sizeof(int) * (size_t)p.nSubsets * p.ncx * p.ncy * 65, s);
+    (void)hipMemsetAsync(p.zIndex, 0x7F, sizeof(int) * (size_t)p.nSubsets * p.ncx * p.ncy * 65, s);
+    (void)hipMemsetAsync(p.sortedToUser, 0xFF, sizeof(int) * (size_t)p.nPadded, s);
     if (n > 0) {
-        if (isDouble) hipLaunchKernelGGL((k_nbKeys<Real, double>), gridN, block, 0, s, p, (const double*)userPos, stride);
-        else hipLaunchKernelGGL((k_nbKeys<Real, float>), gridN, block, 0, s, p, (const float*)userPos, stride);
-        (void)rocprim::radix_sort_pairs(sortTemp, sortTempBytes, p.keysIn, p.keysOut, p.valsIn, p.valsOut, (size_t)n, 0, 44 + p.subsetBits, s);
-        hipLaunchKernelGGL((k_nbPad<Real>), dim3((p.nPadded + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbScatter<Real>), gridN, block, 0, s, p);
+        hipLaunchKernelGGL((k_nbPad<Real>), dim3((p.nPadded + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbZPrefix<Real>), dim3((p.nSubsets * p.ncx * p.ncy + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbBounds<Real>), dim3((p.nBlocks + 7) / 8), block, 0, s, p);
         hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((p.nBlocks + 3) / 4), block, 0, s, p);
@@ -413,7 +491,9 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, const
 
 template size_t nbSortTempBytes<float>(int);
 template size_t nbSortTempBytes<double>(int);
-template void launchNeighborBuild<float>(const NbParams<float>&, const void*, int, int, void*, size_t, hipStream_t);
-template void launchNeighborBuild<double>(const NbParams<double>&, const void*, int, int, void*, size_t, hipStream_t);
+template void launchNeighborSort<float>(const NbParams<float>&, const void*, int, int, void*, size_t, hipStream_t);
+template void launchNeighborSort<double>(const NbParams<double>&, const void*, int, int, void*, size_t, hipStream_t);
+template void launchNeighborBuild<float>(const NbParams<float>&, hipStream_t);
+template void launchNeighborBuild<double>(const NbParams<double>&, hipStream_t);
 
 }  // namespace snb

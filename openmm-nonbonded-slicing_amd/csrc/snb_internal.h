@@ -20,8 +20,11 @@
 #define SNB_ONE_4PI_EPS0 138.93545764438198
 #define SNB_PI 3.14159265358979323846
 #define SNB_EPSILON0 (1.0 / (4.0 * SNB_PI * SNB_ONE_4PI_EPS0))
-#define SNB_JIDX_MASK 0x07FFFFFF
-#define SNB_JSHIFT_BITS 27
+// tile j entry = sorted atom index (25 bits) | periodic image code << 25; code = (kx+2)*25 + (ky+2)*5 + (kz+2), k in -2..2: the j atom is taken
+// at its stored position + k * box diagonal (stored positions of a block are re-imaged to be compact, so k reaches +-2); -1 = padding slot
+#define SNB_JIDX_MASK 0x01FFFFFF
+#define SNB_JSHIFT_BITS 25
+#define SNB_JCODE_CENTER 62
 #define SNB_PME_ORDER 5
 
 namespace snb {
@@ -53,7 +56,7 @@ template <typename Real> struct DirectParams {
     Real invCut6, multShift6;                              // LJPME potential shifts
     int useSwitch; Real switchDist, invSwitchWidth;
     Real box[9]; Real invBoxDiag[3];                       // for the per-pair wrap variant
-    Real shifts[27 * 3];                                   // periodic image vectors, code = (sx+1)*9+(sy+1)*3+(sz+1)
+    Real boxDiag[3];                                       // rectangular box edge lengths (image codes are decoded against them)
 };
 
 template <typename Real> struct PairListParams {  // 1-4 exceptions: one thread per pair; exclusion corrections: one thread per atom
@@ -135,11 +138,13 @@ template <typename Real> struct NbParams {
     int nAtoms, nPadded, nBlocks, nSubsets, subsetBits, ncx, ncy;
     double boxd[3];
     float listCutoff;
+    float jumpDist;  // consecutive sorted atoms further apart than this start a new (padded) block segment
     // static, user order
     const int* uSubset; const Real* uCharge; const typename Vec<Real>::T2* uSigEps;
     const int* uExclStart; const int* uExclList;
-    const int* subsetStart; const int* subsetPaddedStart; const int* slotOfSubset; const unsigned char* padFlag;
-    const int* blockSubset;
+    const int* slotOfSubset;
+    int* blockSubset;
+    int* segKey; int* segStart; int* padExtra; int* padBefore;   // block segmentation scratch (segStart and padBefore may alias)
     // scratch
     Real* wrapped; Real* offsetU; unsigned long long* keysIn; unsigned long long* keysOut; int* valsIn; int* valsOut;
     float* blockCenter; float* blockHalf;
@@ -155,7 +160,8 @@ template <typename Real> struct NbParams {
     long long* dbgOut;   // SNB_NB_TRACE: per-block start/end wall_clock64 stamps (100 MHz) of the tile builder
 };
 template <typename Real> size_t nbSortTempBytes(int n);
-template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, const void* userPos, int isDouble, int stride4, void* sortTemp, size_t sortTempBytes, hipStream_t s);
+template <typename Real> void launchNeighborSort(const NbParams<Real>& p, const void* userPos, int isDouble, int stride4, void* sortTemp, size_t sortTempBytes, hipStream_t s);
+template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipStream_t s);
 
 // ---- launchers implemented in the .hip translation units -------------------------------------
 template <typename Real> void launchDirect(const DirectParams<Real>& p, int methodClass, bool wrap, bool energy, hipStream_t s);
