@@ -206,7 +206,7 @@ class Engine:
     def __init__(self, pkg, w, method, grid, dgrid, precision, device, rank, world, padding, rebuild_interval, stream=None):
         self.capi = pkg.capi; self.L = pkg.capi.lib(); self.h = ctypes.c_void_p()
         cfg = self.capi.SnbConfig()
-        cfg.abi_version = 1; cfg.n_atoms = len(w["q"]); cfg.n_subsets = w["nsub"]; cfg.method = method
+        cfg.abi_version = self.capi.SNB_ABI_VERSION; cfg.n_atoms = len(w["q"]); cfg.n_subsets = w["nsub"]; cfg.method = method
         cfg.precision = 1 if precision == "double" else 0; cfg.device = device; cfg.cutoff = CUTOFF; cfg.rf_dielectric = 78.3
         cfg.alpha = ALPHA; cfg.grid[0] = cfg.grid[1] = cfg.grid[2] = grid
         cfg.alpha_d = ALPHA; cfg.dgrid[0] = cfg.dgrid[1] = cfg.dgrid[2] = max(dgrid, 1)
@@ -349,7 +349,7 @@ def main():
         "config": {"workload": "%s: %d-atom cubic box L=%.3f nm, %d subsets, %s %d^3%s, cutoff 1.0 nm, alpha 2.6283/nm, %d exclusions, list skin %.2f nm"
                    % (cfg_name, N, Lbox, nsub, "PME" if method == 4 else "LJPME", st.grid[0], (" + dispersion %d^3" % st.dgrid[0]) if method == 5 else "",
                       len(w["exc_qq"]), args.padding),
-                   "tiles_32x32": T, "blocks": int(st.n_blocks), "rebuild_interval": args.rebuild_interval, "rebuilds_in_timed_region": int(st.n_rebuilds) - rebuilds_before, "neighbor_rebuild_ms": round(st.last_rebuild_ms, 2),
+                   "tiles_32x32": T, "blocks": int(st.n_blocks), "rebuild_interval": args.rebuild_interval, "rebuilds_in_timed_region": int(st.n_rebuilds) - rebuilds_before, "host_rebuilds": int(st.n_host_rebuilds), "neighbor_rebuild_ms": round(st.last_rebuild_ms, 2),
                    "first_call_ms": round(first_ms, 1), "energy_step_ms": round(energy_ms, 3),
                    "gpu_ms_per_step": round(gpu_ms, 4), "direct_kernel_ms": round(direct_ms, 4), "reciprocal_ms": round(recip_ms, 4),
                    "parallelism": ("subset-grid + tile sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},

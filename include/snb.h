@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SNB_ABI_VERSION 1
+#define SNB_ABI_VERSION 2
 
 typedef struct snb_engine* snb_handle;
 
@@ -93,6 +93,7 @@ typedef struct {
     double  sum_recip_ms;       /*   no per-step host synchronisation)                                  */
     double  sum_total_ms;
     int64_t n_timed;            /* executes included in the sums                                        */
+    int64_t n_host_rebuilds;    /* rebuilds that fell back to the host builder (triclinic / non-periodic / tiny boxes) */
 } snb_stats;
 
 /* -- lifetime ---------------------------------------------------------------------------------- */

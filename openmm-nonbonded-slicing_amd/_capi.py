@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsnb_hip.so")
-SNB_ABI_VERSION = 1
+SNB_ABI_VERSION = 2
 
 # every symbol include/snb.h declares (tests check the library exports each one)
 SYMBOLS = [
@@ -42,7 +42,7 @@ class SnbStats(ctypes.Structure):
         ("n_exclusions", ctypes.c_int64), ("n_14", ctypes.c_int64), ("n_rebuilds", ctypes.c_int64), ("grid", ctypes.c_int32 * 3),
         ("dgrid", ctypes.c_int32 * 3), ("last_direct_ms", ctypes.c_double), ("last_recip_ms", ctypes.c_double),
         ("last_total_ms", ctypes.c_double), ("last_rebuild_ms", ctypes.c_double), ("sum_direct_ms", ctypes.c_double),
-        ("sum_recip_ms", ctypes.c_double), ("sum_total_ms", ctypes.c_double), ("n_timed", ctypes.c_int64),
+        ("sum_recip_ms", ctypes.c_double), ("sum_total_ms", ctypes.c_double), ("n_timed", ctypes.c_int64), ("n_host_rebuilds", ctypes.c_int64),
     ]
 
 

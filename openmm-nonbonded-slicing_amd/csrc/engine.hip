@@ -197,7 +197,7 @@ public:
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
-    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB;
+    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC;
     DevBuf<long long> dNbTrace;
     bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
     double maxAbsQ = 0, maxAbsC6 = 0;
@@ -616,12 +616,16 @@ public:
         // work items: runs of <= 8 tiles of one i-block (fine grain => several rounds of waves per CU, small tail)
         std::vector<int4> hWork;
         const int CH = 8;
-        for (int b = 0; b < numBlocks; b++)
+        // sharded engines keep the work items of the i-blocks they own (block index % shard_count == shard_rank): a rule every rank
+        // evaluates identically, whatever order its own builder emitted the items in
+        shardTiles = 0;
+        for (int b = 0; b < numBlocks; b++) {
+            if (b % cfg.shard_count != cfg.shard_rank) continue;
+            shardTiles += hBlockTiles[b].y;
             for (int o = 0; o < hBlockTiles[b].y; o += CH) hWork.push_back(make_int4(b, hBlockTiles[b].x + o, std::min(CH, hBlockTiles[b].y - o), 0));
+        }
         std::stable_sort(hWork.begin(), hWork.end(), [&](const int4& a, const int4& b) { return a.z > b.z; });
         numWorkItems = (int)hWork.size();
-        shardTiles = 0;
-        for (int w = cfg.shard_rank; w < numWorkItems; w += cfg.shard_count) shardTiles += hWork[w].z;
         // 7. upload
         posq.upload(hPosq, stream); sigeps.upload(hSigeps, stream); imageOffset.upload(hOff, stream);
         dSortedToUser.upload(sortedToUser, stream); dUserToSorted.upload(userToSorted, stream);
@@ -632,7 +636,7 @@ public:
         fx.p = forceBuf.p; fy.p = fx.p + Npad; fz.p = fy.p + Npad; fpx.p = fz.p + Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
         HIPCHECK(hipStreamSynchronize(stream));
         needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;
-        stats.n_rebuilds++;
+        stats.n_rebuilds++; stats.n_host_rebuilds++;
         stats.last_rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
@@ -723,6 +727,8 @@ public:
         p.slotOfSubset = dSlotOfSubset.p;
         p.wrapped = dWrapped.p; p.offsetU = dOffsetU.p; p.keysIn = dKeysIn.p; p.keysOut = dKeysOut.p; p.valsIn = dValsIn.p; p.valsOut = dValsOut.p;
         p.segKey = dValsIn.p; p.segStart = dScanA.p; p.padExtra = dScanB.p; p.padBefore = dScanA.p;   // valsIn is dead once the sort has run
+        dScanC.resize(N); p.blockWide = dScanC.p; p.blockWideOut = dScanC.p;
+        for (int d = 0; d < 3; d++) p.maxHalfExtent[d] = (float)(0.45 * (box[4 * d] - 2.0 * R));   // extent <= 0.9 (L - 2R)
         p.userToSorted = dUserToSorted.p; p.colRange = colRange.p; p.zIndex = dZIndex.p; p.counters = dCounters.p;
         if (!evRebuild[0]) { HIPCHECK(hipEventCreate(&evRebuild[0])); HIPCHECK(hipEventCreate(&evRebuild[1])); HIPCHECK(hipEventCreate(&evRebuild[2])); }
         HIPCHECK(hipEventRecord(evRebuild[0], stream));
@@ -747,6 +753,7 @@ public:
         for (int attempt = 0; attempt < 3; attempt++) {
             tileJ.resize(tileCap * 32); tileInfo.resize(tileCap); masks.resize(tileCap * 32); workItems.resize(2 * (tileCap / 4 + 2 * numBlocks + 64)); workItemsStage.resize(tileCap / 4 + 2 * numBlocks + 64); workItemsPartial.resize(tileCap / 4 + 2 * numBlocks + 64);
             p.nPadded = Npad; p.nBlocks = numBlocks; p.blockSubset = blockSubset.p;
+            p.shardRank = cfg.shard_rank; p.shardCount = cfg.shard_count;
             p.blockCenter = dBlockCenter.p; p.blockHalf = dBlockHalf.p;
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;
@@ -779,7 +786,7 @@ public:
             }
             if (h[3] == 0) {
                 numTiles = h[0]; numWorkItems = h[1] + h[4]; numMaskTiles = h[2]; wrapMode = false;
-                shardTiles = numTiles / cfg.shard_count;
+                shardTiles = numTiles;      // the builder only emitted the blocks this engine owns
                 gpuBuilt = true;
                 needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;
                 stats.n_rebuilds++;
@@ -928,7 +935,8 @@ public:
             p.posq = posq.p; p.sigeps = sigeps.p; p.blockSubset = blockSubset.p; p.workItems = workItems.p;
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.sliceE = sliceE.p; p.lambdas = dLambdas.p;
             const int r = cfg.shard_rank, c = cfg.shard_count;
-            p.workStart = r; p.workStride = c; p.numWork = numWorkItems > r ? (numWorkItems - r + c - 1) / c : 0;
+            (void)r; (void)c;
+            p.workStart = 0; p.workStride = 1; p.numWork = numWorkItems;      // the lists hold only the i-blocks this engine owns (block % shard_count == shard_rank)
             p.nsub = nsub;
             p.cutoff2 = (Real)(cfg.cutoff * cfg.cutoff);
             p.krf = (Real)(std::pow(cfg.cutoff, -3.0) * (cfg.rf_dielectric - 1.0) / (2.0 * cfg.rf_dielectric + 1.0));

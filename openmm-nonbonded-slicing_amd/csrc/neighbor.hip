@@ -57,8 +57,28 @@ template <typename Real> __global__ void k_nbJumpFlags(const NbParams<Real> p) {
             }
             start = d2 > p.jumpDist * p.jumpDist;
         }
+        // second pass: every atom of a block found too wide by k_nbWideDetect becomes a segment (= block) of its own
+        if (!start && p.blockWide) start = p.blockWide[(t + p.padBefore[t]) >> 5] || p.blockWide[(t - 1 + p.padBefore[t - 1]) >> 5];
     }
     p.segKey[t] = start ? t : 0;
+}
+// A chain of moderately spaced atoms (scattered ions, say) passes the jump test and can still make a 32-atom block too extended for
+// the one-image-per-j-atom tile scheme (extent + 2R < L).  Blocks with an atom further than maxHalfExtent from their first atom
+// (minimum image, any axis) are flagged; the second segmentation pass dissolves them into single-atom blocks.
+template <typename Real> __global__ void k_nbWideDetect(const NbParams<Real> p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.nAtoms) return;
+    const int si = t + p.padBefore[t];
+    const int u = p.valsOut[t], u0 = p.valsOut[t - (si & 31)];
+    bool far = false;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float L = (float)p.boxd[d];
+        float dl = fabsf((float)p.wrapped[3 * (size_t)u + d] - (float)p.wrapped[3 * (size_t)u0 + d]);
+        dl = dl > 0.5f * L ? L - dl : dl;
+        far = far || dl > p.maxHalfExtent[d];
+    }
+    if (far) p.blockWideOut[si >> 5] = 1;
 }
 template <typename Real> __global__ void k_nbPadExtra(const NbParams<Real> p) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,6 +220,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int I = blockIdx.x * 4 + wid;
     if (I >= p.nBlocks) return;
+    if (p.shardCount > 1 && (I % p.shardCount) != p.shardRank) return;      // another engine owns this i-block (deterministic rule, same on every rank)
     const long long tStart = p.dbgOut ? (long long)wall_clock64() : 0;
     int* list = s_list[wid];
     unsigned (*mask)[32] = s_mask[wid];
@@ -463,10 +484,16 @@ template <typename Real> void launchNeighborSort(const NbParams<Real>& p, const 
     if (isDouble) hipLaunchKernelGGL((k_nbKeys<Real, double>), gridN, block, 0, s, p, (const double*)userPos, stride);
     else hipLaunchKernelGGL((k_nbKeys<Real, float>), gridN, block, 0, s, p, (const float*)userPos, stride);
     (void)rocprim::radix_sort_pairs(sortTemp, sortTempBytes, p.keysIn, p.keysOut, p.valsIn, p.valsOut, (size_t)n, 0, 44 + p.subsetBits, s);
-    hipLaunchKernelGGL((k_nbJumpFlags<Real>), gridN, block, 0, s, p);
-    (void)rocprim::inclusive_scan(sortTemp, sortTempBytes, p.segKey, p.segStart, (size_t)n, rocprim::maximum<int>(), s);
-    hipLaunchKernelGGL((k_nbPadExtra<Real>), gridN, block, 0, s, p);
-    (void)rocprim::exclusive_scan(sortTemp, sortTempBytes, p.padExtra, p.padBefore, 0, (size_t)n, rocprim::plus<int>(), s);
+    (void)hipMemsetAsync(p.blockWideOut, 0, sizeof(int) * (size_t)n, s);
+    NbParams<Real> p0 = p;
+    p0.blockWide = nullptr;                                 // pass 1: subset boundaries and jumps
+    for (int pass = 0; pass < 2; pass++) {
+        hipLaunchKernelGGL((k_nbJumpFlags<Real>), gridN, block, 0, s, pass == 0 ? p0 : p);
+        (void)rocprim::inclusive_scan(sortTemp, sortTempBytes, p.segKey, p.segStart, (size_t)n, rocprim::maximum<int>(), s);
+        hipLaunchKernelGGL((k_nbPadExtra<Real>), gridN, block, 0, s, p);
+        (void)rocprim::exclusive_scan(sortTemp, sortTempBytes, p.padExtra, p.padBefore, 0, (size_t)n, rocprim::plus<int>(), s);
+        if (pass == 0) hipLaunchKernelGGL((k_nbWideDetect<Real>), gridN, block, 0, s, p);   // pass 2 dissolves the blocks it flags
+    }
     hipLaunchKernelGGL((k_nbPadTotal<Real>), dim3(1), dim3(64), 0, s, p);
 }
 

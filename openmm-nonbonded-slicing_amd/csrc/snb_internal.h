@@ -145,6 +145,8 @@ template <typename Real> struct NbParams {
     const int* slotOfSubset;
     int* blockSubset;
     int* segKey; int* segStart; int* padExtra; int* padBefore;   // block segmentation scratch (segStart and padBefore may alias)
+    const int* blockWide; int* blockWideOut;                     // [nAtoms] flags of over-extended blocks of the first segmentation pass
+    float maxHalfExtent[3];                                      // a block is over-extended when an atom is further than this from its first atom
     // scratch
     Real* wrapped; Real* offsetU; unsigned long long* keysIn; unsigned long long* keysOut; int* valsIn; int* valsOut;
     float* blockCenter; float* blockHalf;
@@ -156,6 +158,7 @@ template <typename Real> struct NbParams {
     int* counters;   // [32 * 65]: line 0 = totals ([0] tiles, [1] full work items, [2] masks, [3] overflow events, [4] partial items, [5] max tiles|masks and
                      // [6] max work items of a partition), lines 1..64 = the partitions' allocation counters (same slots)
     int tileCapacity, workCapacity, maskCapacity;
+    int shardRank, shardCount;   // tiles and work items are built only for i-blocks with block % shardCount == shardRank
     int dbg;         // SNB_DBG experiment bits (timing decomposition only)
     long long* dbgOut;   // SNB_NB_TRACE: per-block start/end wall_clock64 stamps (100 MHz) of the tile builder
 };

@@ -1,7 +1,8 @@
 """Multi-GPU sharding of ONE SlicedNonbondedForce evaluation.
 
-One process per GPU.  Rank g of G owns the PME charge grids of the subsets J with J % G == g and the direct-space work
-items w with w % G == g (the engine applies the same rule from snb_config.shard_rank/shard_count); every rank holds all
+One process per GPU.  Rank g of G owns the PME charge grids of the subsets J with J % G == g and the direct-space tiles of
+the 32-atom i-blocks I with I % G == g (the engine applies the same rules from snb_config.shard_rank/shard_count; block
+indices follow the sorted atom order, which every rank derives identically from the same positions); every rank holds all
 positions.  The only exchange on the path is a sum: one all-reduce of the N x 3 partial forces per step, plus -- on energy
 steps -- one all-reduce of the S x 2 raw slice energies.  RCCL ("nccl" backend) on MI355X, gloo in the CPU tests.
 """
@@ -14,7 +15,8 @@ def owned_subsets(n_subsets: int, rank: int, world: int):
 
 
 def owned_work_items(n_items: int, rank: int, world: int):
-    """Direct-space work items of `rank` (csrc/direct.hip: item -> workItems[rank + item*world])."""
+    """Direct-space i-blocks of `rank` (csrc/neighbor.hip k_nbBuildTiles: `block % shard_count == shard_rank`; the rule must not depend
+    on the order in which a rank's own builder emits its work items, which is not reproducible across GPUs)."""
     return list(range(rank, n_items, world))
 
 

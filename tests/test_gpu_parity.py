@@ -50,7 +50,7 @@ def prec(request):
 
 def test_native_library_loaded(snb):
     L = snb.capi.lib()
-    assert L.snb_abi_version() == 1
+    assert L.snb_abi_version() == snb.capi.SNB_ABI_VERSION
 
 
 @pytest.mark.parametrize("case", ["testCoulomb", "testLJ", "testExclusionsAnd14", "testCutoff", "testCutoff14", "testPeriodic",
@@ -138,6 +138,26 @@ def test_random_system_vs_oracle(case, snb, F, oev, prec):
     force, pos, box = systems.random_box(F, n, nsub, method, L, cutoff, pme=pme, ljpme=ljpme, switch=switch)
     r, o = _compare(make_ev(snb, prec), oev, force, pos, box, TOLS[prec])
     assert r["stats"].n_tiles > 0
+
+
+def test_sparse_subsets_stay_on_gpu_builder(snb, F, oev, prec):
+    """Subsets that are NOT compact -- scattered single atoms ('ions'), a hollow spherical shell, a sphere centred on the box corner
+    (it straddles the periodic boundary in all three directions) -- must neither lose pairs nor push the engine off its GPU
+    neighbour builder: blocks are segmented at jumps of the sorted order and re-imaged compactly (neighbor.hip, k_nbJumpFlags)."""
+    n, L = 13824, 6.0
+    force, pos, box = systems.random_box(F, n, 4, 4, L, 1.0, pme=(2.6283, 48, 48, 48))
+    sub = np.zeros(n, dtype=int)
+    d = pos - 0.5 * L
+    r = np.linalg.norm(d, axis=1)
+    sub[(r > 2.2) & (r < 2.6)] = 2                                  # hollow shell: a column crosses it twice, far apart in z
+    dc = pos - L * np.round(pos / L)                                # minimum image to the corner (0,0,0)
+    sub[np.linalg.norm(dc, axis=1) < 1.3] = 3                       # eight octants of one sphere, one per box corner
+    sub[np.arange(n) % 97 == 5] = 1                                 # scattered single atoms
+    for i in range(n):
+        force.setParticleSubset(i, int(sub[i]))
+    assert all((sub == k).sum() > 32 for k in range(4))
+    r, o = _compare(make_ev(snb, prec), oev, force, pos, box, TOLS[prec])
+    assert r["stats"].n_tiles > 0 and r["stats"].n_host_rebuilds == 0
 
 
 def test_padding_and_rebuild_interval(snb, F, oev):

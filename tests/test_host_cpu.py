@@ -25,7 +25,7 @@ def test_struct_layout_matches_header(snb):
     capi = snb.capi
     # sizes follow from the field lists in include/snb.h (natural alignment)
     assert ctypes.sizeof(capi.SnbConfig) == 8 * 4 + 4 * 8 + 6 * 4 + 8 + 3 * 4 + 4 + 8 + 3 * 4 + 2 * 4 + 4 + 8
-    assert ctypes.sizeof(capi.SnbStats) == 7 * 8 + 6 * 4 + 4 * 8 + 3 * 8 + 8
+    assert ctypes.sizeof(capi.SnbStats) == 7 * 8 + 6 * 4 + 4 * 8 + 3 * 8 + 8 + 8
 
 
 def test_struct_layout_matches_c_compiler(snb, tmp_path):
@@ -55,7 +55,7 @@ def test_create_without_gpu_fails_loudly(snb):
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     capi = snb.capi
-    cfg = capi.SnbConfig(); cfg.abi_version = 1; cfg.n_atoms = 2; cfg.n_subsets = 1; cfg.method = 0; cfg.precision = 0
+    cfg = capi.SnbConfig(); cfg.abi_version = capi.SNB_ABI_VERSION; cfg.n_atoms = 2; cfg.n_subsets = 1; cfg.method = 0; cfg.precision = 0
     h = ctypes.c_void_p()
     st = capi.lib().snb_create(ctypes.byref(cfg), ctypes.byref(h))
     assert st == capi.SNB_ERR_HIP and not h
