@@ -218,9 +218,10 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     __shared__ int s_cmb[4][3][64];      // candidate runs of the current batch of (column, z image) combinations: start, exclusive prefix, image code
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int I = blockIdx.x * 4 + wid;
+    // sharded engines build only the i-blocks they own, I % shardCount == shardRank (a deterministic rule, the same on every rank);
+    // the grid is sized for the owned blocks so that every wave of a work-group has work
+    const int I = (blockIdx.x * 4 + wid) * p.shardCount + p.shardRank;
     if (I >= p.nBlocks) return;
-    if (p.shardCount > 1 && (I % p.shardCount) != p.shardRank) return;      // another engine owns this i-block (deterministic rule, same on every rank)
     const long long tStart = p.dbgOut ? (long long)wall_clock64() : 0;
     int* list = s_list[wid];
     unsigned (*mask)[32] = s_mask[wid];
@@ -511,7 +512,8 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipSt
         hipLaunchKernelGGL((k_nbPad<Real>), dim3((p.nPadded + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbZPrefix<Real>), dim3((p.nSubsets * p.ncx * p.ncy + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbBounds<Real>), dim3((p.nBlocks + 7) / 8), block, 0, s, p);
-        hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((p.nBlocks + 3) / 4), block, 0, s, p);
+        const int nOwned = (p.nBlocks - p.shardRank + p.shardCount - 1) / p.shardCount;
+        hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((nOwned + 3) / 4), block, 0, s, p);
         hipLaunchKernelGGL((k_nbCompactWork<Real>), dim3(2 * NB_PARTS), block, 0, s, p);
     }
 }

@@ -1069,6 +1069,117 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
     }
 }
 
+// Sharded engines (mix == 0): a rank holds the UNMIXED potential grids of its own subsets and every atom needs
+// sum_J lambda[slice(s_i, J)] * (gradient of grid J).  One work-group per column brick loops over the held grids: stage the brick of
+// grid J, then one thread per atom of ANY subset in the brick's columns adds lambda * gradient into the atom's reciprocal force
+// (plain read-modify-write: the work-group is the only writer of its columns' atoms; the gather pass cleared the arrays), and --
+// on energy steps -- E[slice(s_i, J)] += 1/2 q_i psi_J(r_i).  Replaces the 32-lanes-per-atom gather kernel, which
+// cost ~80 us per held grid at 300k atoms.
+template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBrickSharded(const PmeParams<Real> p) {
+    extern __shared__ __align__(16) unsigned char s_brick_raw[];
+    constexpr int NT = 1024, HALO_LO = 1, EXTRA = 6;
+    const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
+    const int cx = p.groupX * (p.d.nx / ncx), cy = p.groupY * (p.d.ny / ncy);
+    const int nby = ncy / p.groupY;
+    const int ncol = ncx * ncy;
+    const int Bx = blockIdx.x / nby, By = blockIdx.x - Bx * nby;
+    const int x0 = Bx * cx, y0 = By * cy;
+    const int bx = cx + EXTRA, by = cy + EXTRA;
+    const int tid = threadIdx.x;
+    Real* brick = reinterpret_cast<Real*>(s_brick_raw);
+    double* sE = reinterpret_cast<double*>(s_brick_raw + ((sizeof(Real) * (size_t)bx * by * nz + 15) & ~(size_t)15));   // [2*S] on energy steps
+    const bool wantE = p.wantEnergy != 0;
+    const int nS2 = p.nsubTotal * (p.nsubTotal + 1);
+    const int term = p.dispersion ? 1 : 0;
+    if (wantE) for (int i = tid; i < nS2; i += NT) sE[i] = 0.0;
+    __shared__ int s_begin[256], s_pref[257];
+    const int nr = p.nsubTotal * p.groupX * p.groupY;          // launcher guarantees nr <= 256
+    if (tid < nr) {
+        const int si = tid / (p.groupX * p.groupY), gxy = tid - si * (p.groupX * p.groupY);
+        const int gx = gxy / p.groupY, gy = gxy - gx * p.groupY;
+        const int2 rg = p.colRange[(size_t)si * ncol + (Bx * p.groupX + gx) * ncy + By * p.groupY + gy];
+        s_begin[tid] = rg.x; s_pref[tid + 1] = rg.y > rg.x ? rg.y - rg.x : 0;
+    }
+    __syncthreads();
+    if (tid == 0) { int acc = 0; s_pref[0] = 0; for (int r = 0; r < nr; r++) { acc += s_pref[r + 1]; s_pref[r + 1] = acc; } }
+    __syncthreads();
+    const int total = s_pref[nr];
+    if (total == 0) return;
+    const FastDiv dnz(nz), dby(by);
+    for (int slot = 0; slot < p.nsub; slot++) {
+        const int gj = p.gridSubset[slot];
+        const Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
+        __syncthreads();                                       // previous grid's readers are done with the brick
+        for (int i = tid; i < bx * by * nz; i += NT) {
+            const int l = dnz.div(i), z = i - l * nz;
+            const int lx = dby.div(l), ly = l - lx * by;
+            int x = x0 + lx - HALO_LO; if (x < 0) x += p.d.nx; else if (x >= p.d.nx) x -= p.d.nx;
+            int y = y0 + ly - HALO_LO; if (y < 0) y += p.d.ny; else if (y >= p.d.ny) y -= p.d.ny;
+            brick[i] = g[((size_t)x * p.d.ny + y) * nz + z];
+        }
+        __syncthreads();
+        // the atoms of ALL subsets in the brick's columns, as one concatenated index space (their runs are short when there are many
+        // subsets: one pass per subset would leave most of the 1024 threads idle)
+        {
+            for (int v0 = 0; v0 < total; v0 += NT) {
+                const int v = v0 + tid;
+                if (v < total) {
+                    int r = 0;
+#pragma unroll
+                    for (int st = 128; st > 0; st >>= 1) if (r + st < nr && s_pref[r + st] <= v) r += st;
+                    const int a = s_begin[r] + (v - s_pref[r]);
+                    const int si = p.atomSubset[a];
+                    const Real q = si >= 0 ? pmeCharge(p, a) : Real(0);
+                    if (q == Real(0)) continue;                // padding slots inside a run, uncharged atoms
+                    const int slice = si > gj ? si * (si + 1) / 2 + gj : gj * (gj + 1) / 2 + si;
+                    const Real lam = p.lambdas[2 * slice + term];
+                    const auto pos = p.posq[a];
+                    int idx[3]; Real fr[3];
+                    gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
+                    int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
+                    int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
+                    Real tx[5], ty[5], tz[5], dx[5], dy[5], dz[5];
+                    bspline5<Real>(fr[0], tx, dx); bspline5<Real>(fr[1], ty, dy); bspline5<Real>(fr[2], tz, dz);
+                    int zi[5];
+#pragma unroll
+                    for (int iz = 0; iz < 5; iz++) { int z = idx[2] + iz; zi[iz] = z >= nz ? z - nz : z; }
+                    Real fx = 0, fy = 0, fz = 0, psi = 0;
+                    const bool inBrick = rx >= -HALO_LO && rx + 4 < bx - HALO_LO && ry >= -HALO_LO && ry + 4 < by - HALO_LO;
+#pragma unroll
+                    for (int ix = 0; ix < 5; ix++) {
+#pragma unroll
+                        for (int iy = 0; iy < 5; iy++) {
+                            Real sz = 0, sdz = 0;
+                            if (inBrick) {
+                                const Real* line = brick + (size_t)((rx + HALO_LO + ix) * by + (ry + HALO_LO + iy)) * nz;
+#pragma unroll
+                                for (int iz = 0; iz < 5; iz++) { const Real gv = line[zi[iz]]; sz += tz[iz] * gv; sdz += dz[iz] * gv; }
+                            } else {   // drifted further than the halo since the last re-sort: correct but slow path through global memory
+                                int x = idx[0] + ix; if (x >= p.d.nx) x -= p.d.nx;
+                                int y = idx[1] + iy; if (y >= p.d.ny) y -= p.d.ny;
+                                const Real* line = g + ((size_t)x * p.d.ny + y) * nz;
+#pragma unroll
+                                for (int iz = 0; iz < 5; iz++) { const Real gv = line[zi[iz]]; sz += tz[iz] * gv; sdz += dz[iz] * gv; }
+                            }
+                            fx += dx[ix] * ty[iy] * sz; fy += tx[ix] * dy[iy] * sz; fz += tx[ix] * ty[iy] * sdz; psi += tx[ix] * ty[iy] * sz;
+                        }
+                    }
+                    const Real nx = p.d.nx, ny = p.d.ny, nzr = p.d.nz;
+                    const Real ql = -q * lam;
+                    p.fpx[a] += ql * (fx * nx * p.recip[0]);
+                    p.fpy[a] += ql * (fx * nx * p.recip[3] + fy * ny * p.recip[4]);
+                    p.fpz[a] += ql * (fx * nx * p.recip[6] + fy * ny * p.recip[7] + fz * nzr * p.recip[8]);
+                    if (wantE) __hip_atomic_fetch_add(&sE[2 * slice + term], 0.5 * (double)q * (double)psi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+    if (wantE) {
+        __syncthreads();
+        for (int i = tid; i < nS2; i += NT) { const double v = sE[i]; if (v != 0.0) atomicAdd(&p.sliceE[i], v); }
+    }
+}
+
 template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s) {
     if (p.natoms <= 0) return;
     if (p.mix && p.sortNcx > 0 && p.colRange != nullptr) {
@@ -1079,6 +1190,17 @@ template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hip
             const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBrick<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((k_interpolateBrick<Real>), dim3(nblocks), dim3(1024), lds, s, p);
+            return;
+        }
+    }
+    if (!p.mix && p.sortNcx > 0 && p.colRange != nullptr) {
+        const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
+        const size_t lds = ((sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * p.d.nz + 15) & ~(size_t)15) + sizeof(double) * p.nsubTotal * (p.nsubTotal + 1);
+        static const bool noBrick = getenv("SNB_NO_SHARDED_BRICK") != nullptr;
+        if (lds <= 150 * 1024 && !noBrick && p.nsubTotal * p.groupX * p.groupY <= 256) {
+            const int nblocks = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBrickSharded<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_interpolateBrickSharded<Real>), dim3(nblocks), dim3(1024), lds, s, p);
             return;
         }
     }
