@@ -409,6 +409,31 @@ template <typename Real, int P> __device__ inline void butterflyP(Cx<Real>* v, i
         // outputs in order 0,2,1,3 -> reorder
         Cx<Real> o1 = v[2], o2 = v[1];
         v[1] = o1; v[2] = o2;
+    } else if (P == 3) {
+        // X1,2 = (v0 - (v1+v2)/2) -+ i (sqrt(3)/2)(v1 - v2)   (forward; signs swap for the inverse)
+        const Cx<Real> t1 = {v[1].x + v[2].x, v[1].y + v[2].y};
+        const Cx<Real> m1 = {v[0].x - Real(0.5) * t1.x, v[0].y - Real(0.5) * t1.y};
+        const Real h = Real(0.86602540378443864676);
+        Cx<Real> sx = {h * (v[1].x - v[2].x), h * (v[1].y - v[2].y)};
+        if (sign > 0) { sx.x = -sx.x; sx.y = -sx.y; }
+        v[0] = {v[0].x + t1.x, v[0].y + t1.y};
+        v[1] = {m1.x + sx.y, m1.y - sx.x};            // m1 - i s
+        v[2] = {m1.x - sx.y, m1.y + sx.x};            // m1 + i s
+    } else if (P == 5) {
+        const Real c1 = Real(0.30901699437494742410), c2 = Real(-0.80901699437494742410);
+        const Real s1 = Real(0.95105651629515357212), s2 = Real(0.58778525229247312917);
+        const Cx<Real> a1 = {v[1].x + v[4].x, v[1].y + v[4].y}, a2 = {v[2].x + v[3].x, v[2].y + v[3].y};
+        const Cx<Real> b1 = {v[1].x - v[4].x, v[1].y - v[4].y}, b2 = {v[2].x - v[3].x, v[2].y - v[3].y};
+        const Cx<Real> p1 = {v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y};
+        const Cx<Real> p2 = {v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y};
+        Cx<Real> q1 = {s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y};
+        Cx<Real> q2 = {s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y};
+        if (sign > 0) { q1.x = -q1.x; q1.y = -q1.y; q2.x = -q2.x; q2.y = -q2.y; }
+        v[0] = {v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y};
+        v[1] = {p1.x + q1.y, p1.y - q1.x};            // p1 - i q1
+        v[4] = {p1.x - q1.y, p1.y + q1.x};            // p1 + i q1
+        v[2] = {p2.x + q2.y, p2.y - q2.x};
+        v[3] = {p2.x - q2.y, p2.y + q2.x};
     } else {
         butterflyGeneric<Real, P>(v, sign);
     }
