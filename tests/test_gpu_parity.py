@@ -160,6 +160,23 @@ def test_sparse_subsets_stay_on_gpu_builder(snb, F, oev, prec):
     assert r["stats"].n_tiles > 0 and r["stats"].n_host_rebuilds == 0
 
 
+BIG_CASES = [
+    # boxes large enough for the GPU neighbour builder and the PME brick kernels (L >= ~5.5 nm at this density)
+    # name, n, nsub, method, L, pme, ljpme
+    ("pme_oddgrid45_13824_n3", 13824, 3, 4, 6.0, (2.6283, 45, 45, 45), None),                       # odd nz: f64 LDS accumulation, odd-length z pairs
+    ("ljpme_grids48_24_13824_n3", 13824, 3, 5, 6.0, (2.6283, 48, 48, 48), (2.6283, 24, 24, 24)),    # dispersion mesh: bricks of column groups
+    ("pme_grid54_13824_n4", 13824, 4, 4, 6.0, (2.6283, 54, 54, 54), None),                          # 54 = 6 x 9 two-pass FFT split
+]
+
+
+@pytest.mark.parametrize("case", BIG_CASES, ids=[c[0] for c in BIG_CASES])
+def test_gpu_builder_and_brick_kernels_vs_oracle(case, snb, F, oev, prec):
+    name, n, nsub, method, L, pme, ljpme = case
+    force, pos, box = systems.random_box(F, n, nsub, method, L, 1.0, pme=pme, ljpme=ljpme)
+    r, o = _compare(make_ev(snb, prec), oev, force, pos, box, TOLS[prec])
+    assert r["stats"].n_tiles > 0 and r["stats"].n_host_rebuilds == 0
+
+
 def test_padding_and_rebuild_interval(snb, F, oev):
     """Tiles built with a skin and reused across steps must give the same answer as a fresh list."""
     force, pos, box = systems.random_box(F, 4096, 2, 4, 3.5, 1.0, pme=(2.6283, 32, 32, 32))
