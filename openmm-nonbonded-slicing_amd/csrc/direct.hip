@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
 // j-force accumulator travels with its slot by a one-lane row rotation fused into the subtract (v_sub_f32_dpp); lanes c and
 // c+8 carry two partial sums of the same slot and are merged by an 8-lane rotation at the end of the tile.
 // Staging: entry e (0..15) of quarter r holds atom 8r + (e & 7), so the rotated read index (c & 7) + 8 - s needs no wrap.
-template <int MC, bool MASKED>
+template <int MC, bool MASKED, bool POLY>
 __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float4* rdPos, const float2* rdSe, const v2f pix, const v2f piy, const v2f piz,
                                                 const v2f sigi, const v2f qiS, const v2f epsiS, const unsigned maskA, const unsigned maskB, const int c,
                                                 v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz) {
@@ -323,7 +323,15 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
         v2f f = es6 * (s6 * 12.0f - 6.0f);
         // Coulomb
         const v2f qq = qiS * xj.w;
-        if (MC == MC_EWALD) {
+        const v2f invR2 = invR * invR;
+        if (MC == MC_EWALD && POLY) {
+            // [erfc(ar)/r + 2a/sqrt(pi) e^{-(ar)^2}] / r^2 = 1/r^3 - Bt(r^2), Bt a degree-11 polynomial in t = r^2 * ewScale - 1: no exp, no rcp
+            const v2f t = r2 * p.ewScale - 1.0f;
+            v2f bt = t * p.ewPoly[11] + p.ewPoly[10];
+#pragma unroll
+            for (int k = 9; k >= 0; k--) bt = bt * t + p.ewPoly[k];
+            f = f * invR2 + qq * (invR2 * invR - bt);
+        } else if (MC == MC_EWALD) {
             const v2f r = r2 * invR;
             const v2f ar = r * p.alpha;
             const v2f e2 = r2 * (-p.alpha2l2e);
@@ -335,13 +343,12 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
             poly = poly * tt + (-0.284496736f);
             poly = poly * tt + 0.254829592f;
             const v2f erfcv = poly * tt * ex;
-            f = f + (qq * invR) * (erfcv + (ar * ex) * 1.1283791670955126f);
+            f = (f + (qq * invR) * (erfcv + (ar * ex) * 1.1283791670955126f)) * invR2;
         } else if (MC == MC_RF) {
-            f = f + qq * (invR - r2 * (2.0f * p.krf));
+            f = (f + qq * (invR - r2 * (2.0f * p.krf))) * invR2;
         } else {
-            f = f + qq * invR;
+            f = (f + qq * invR) * invR2;
         }
-        f = f * (invR * invR);
         bool inA = MC == MC_NOCUTOFF ? true : (r2.x < p.cutoff2), inB = MC == MC_NOCUTOFF ? true : (r2.y < p.cutoff2);
         if (MASKED) { const int k = (c - s) & 7; inA = inA && !((maskA >> k) & 1u); inB = inB && !((maskB >> k) & 1u); }
         f.x = inA ? f.x : 0.0f; f.y = inB ? f.y : 0.0f;
@@ -351,7 +358,7 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
     }
 }
 
-template <int MC>
+template <int MC, bool POLY>
 __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<float> p) {
     __shared__ float4 s_pos[4][64];
     __shared__ float2 s_se[4][64];
@@ -421,8 +428,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         // lambda folded into the i-side parameters once per tile
         const v2f qiS = qi * lamC, epsiS = epsi * lamL;
         float fjx = 0, fjy = 0, fjz = 0;
-        if (hasMask) tileStepsPacked<MC, true>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz);
-        else tileStepsPacked<MC, false>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz);
+        if (hasMask) tileStepsPacked<MC, true, POLY>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz);
+        else tileStepsPacked<MC, false, POLY>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz);
         // rotate-then-subtract leaves lane c holding slot (c+1)&7: one more rotation brings every slot home, then the two
         // partial sums of a slot (lanes c and c+8) are merged
         fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
@@ -452,7 +459,11 @@ template <typename Real, int MC> static void launchDirectMC(const DirectParams<R
     { static const int cap = getenv("SNB_DIRECT_WGS") ? atoi(getenv("SNB_DIRECT_WGS")) : 0; if (cap > 0 && nwg > cap) nwg = cap; }
     dim3 grid(nwg), block(256);
     if constexpr (std::is_same<Real, float>::value && MC != MC_LJPME) {
-        if (!wrap && !energy && !p.useSwitch) { hipLaunchKernelGGL((k_directPacked<MC>), grid, block, 0, s, p); return; }
+        if (!wrap && !energy && !p.useSwitch) {
+            if (MC == MC_EWALD && p.ewUsePoly) hipLaunchKernelGGL((k_directPacked<MC, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((k_directPacked<MC, false>), grid, block, 0, s, p);
+            return;
+        }
     }
     if (wrap) {
         if (energy) hipLaunchKernelGGL((k_direct<Real, MC, true, true>), grid, block, 0, s, p);

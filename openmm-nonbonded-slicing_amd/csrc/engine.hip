@@ -214,7 +214,6 @@ public:
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
-    DevBuf<float2> ewaldTable; int ewaldTabN = 0; float ewaldTabScale = 0;
     std::vector<int3> hKvec; DevBuf<int3> dKvec; DevBuf<Real> dCosSin;
     struct GraphKey { const void* pos; int isDouble, stride4; bool direct, recip; bool operator==(const GraphKey& o) const { return pos == o.pos && isDouble == o.isDouble && stride4 == o.stride4 && direct == o.direct && recip == o.recip; } };
     hipGraphExec_t graphExec = nullptr; GraphKey graphKey{}; long long execCount = 0;
@@ -235,7 +234,7 @@ public:
         if (cfg.shard_count < 1) cfg.shard_count = 1;
         // tabulated Ewald force factor: opt-in.  Measured on MI355X it only trades 4 % of the VALU instructions for LDS gathers (the packed
         // analytic erfc is already cheap) and leaves the kernel time unchanged, so the analytic form stays the default.
-        if (std::is_same<Real, float>::value && cfg.method >= SNB_Ewald && getenv("SNB_EWALD_TABLE")) buildEwaldTable();
+        if (cfg.method >= SNB_Ewald) buildEwaldPoly();
         for (int s = 0; s < nsub; s++) if (s % cfg.shard_count == cfg.shard_rank) ownedSubsets.push_back(s);
         nGrids = cfg.shard_count == 1 ? nsub : (int)ownedSubsets.size();
         if (isPme()) {
@@ -260,22 +259,40 @@ public:
         if (stream2) { (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); (void)hipStreamDestroy(stream2); }
         if (ownStream) (void)hipStreamDestroy(stream);
     }
-    // Bt(r^2) = [erf(ar) - 2ar/sqrt(pi) exp(-(ar)^2)] / r^3  (bounded, smooth; Bt(0) = 4 a^3 / (3 sqrt(pi))): the real-space Ewald
-    // force factor is 1/r^3 - Bt.  2048 intervals over [0, (cutoff+skin)^2], linear interpolation.
-    void buildEwaldTable() {
-        const int n = 2048;
-        const double rmax = cfg.cutoff + std::max(cfg.neighbor_padding, 0.0) + 0.05;
-        const double h = rmax * rmax / n, a = cfg.alpha;
+    // Real-space Ewald force factor of the single-precision forces-only pair kernel:
+    //   [erfc(ar)/r + 2a/sqrt(pi) exp(-(ar)^2)] / r^2 = 1/r^3 - Bt(r^2),   Bt(r^2) = [erf(ar) - 2ar/sqrt(pi) exp(-(ar)^2)] / r^3,
+    // Bt is an entire function of r^2 (Bt(0) = 4a^3/(3 sqrt(pi))), so a degree-11 polynomial in t = 2 r^2/r2max - 1 (Chebyshev fit
+    // over [0, (cutoff+skin)^2], converted to monomials in t, |t| <= 1) reproduces it to 1e-7 of Bt(0): 12 packed FMAs replace
+    // v_exp + v_rcp + the A&S erfc polynomial.  Absolute force error per pair stays below that of the A&S path at short range and
+    // below 2e-6 * qq near the cutoff (tools/ewald_poly_check.py).
+    static constexpr int EW_DEG = 11;
+    double ewPoly[EW_DEG + 1] = {0}; double ewR2Max = 1;
+    void buildEwaldPoly() {
+        const double rmax = cfg.cutoff + std::max(cfg.neighbor_padding, 0.0) + 0.02, a = cfg.alpha;
+        ewR2Max = rmax * rmax;
         auto bt = [&](double r2) {
             const double r = std::sqrt(r2), z = a * r;
-            if (z < 1e-3) return a * a * a * (4.0 / (3.0 * std::sqrt(SNB_PI))) * (1.0 - 0.6 * z * z);
+            if (z < 1e-2) return a * a * a * (4.0 / (3.0 * std::sqrt(SNB_PI))) * (1.0 - 0.6 * z * z + (3.0 / 14.0) * z * z * z * z);
             return (std::erf(z) - 2.0 * z / std::sqrt(SNB_PI) * std::exp(-z * z)) / (r2 * r);
         };
-        std::vector<float2> t(n + 2);
-        for (int i = 0; i <= n + 1; i++) { const double v0 = bt(i * h), v1 = bt((i + 1) * h); t[i].x = (float)v0; t[i].y = (float)(v1 - v0); }
-        ewaldTable.upload(t, stream);
-        HIPCHECK(hipStreamSynchronize(stream));
-        ewaldTabN = n; ewaldTabScale = (float)(1.0 / h);
+        const int M = 64;
+        double c[EW_DEG + 1];
+        for (int k = 0; k <= EW_DEG; k++) {
+            double acc = 0;
+            for (int j = 0; j < M; j++) { const double x = std::cos(SNB_PI * (j + 0.5) / M); acc += bt(0.5 * (x + 1.0) * ewR2Max) * std::cos(SNB_PI * k * (j + 0.5) / M); }
+            c[k] = acc * 2.0 / M;
+        }
+        c[0] *= 0.5;
+        // Chebyshev -> monomial: T_0 = 1, T_1 = x, T_{k+1} = 2 x T_k - T_{k-1}
+        double Tm[EW_DEG + 1] = {0}, Tc[EW_DEG + 1] = {0}, Tn[EW_DEG + 1];
+        Tm[0] = 1; Tc[1] = 1;
+        for (int i = 0; i <= EW_DEG; i++) ewPoly[i] = 0;
+        ewPoly[0] += c[0];
+        for (int i = 0; i <= EW_DEG; i++) ewPoly[i] += c[1] * Tc[i];
+        for (int k = 2; k <= EW_DEG; k++) {
+            for (int i = 0; i <= EW_DEG; i++) Tn[i] = (i > 0 ? 2.0 * Tc[i - 1] : 0.0) - Tm[i];
+            for (int i = 0; i <= EW_DEG; i++) { ewPoly[i] += c[k] * Tn[i]; Tm[i] = Tc[i]; Tc[i] = Tn[i]; }
+        }
     }
     bool isPme() const { return cfg.method == SNB_PME || cfg.method == SNB_LJPME; }
     bool isPeriodic() const { return cfg.method >= SNB_CutoffPeriodic; }
@@ -945,7 +962,9 @@ public:
             p.crf = (Real)((1.0 / cfg.cutoff) * (3.0 * cfg.rf_dielectric) / (2.0 * cfg.rf_dielectric + 1.0));
             p.alpha = (Real)cfg.alpha; p.alphaD = (Real)cfg.alpha_d; p.k4pe = (Real)SNB_ONE_4PI_EPS0;
             p.alpha2l2e = (Real)(cfg.alpha * cfg.alpha * 1.4426950408889634);
-            p.ewaldTable = ewaldTable.p; p.tabN = ewaldTabN; p.tabScale = ewaldTabScale;
+            for (int i = 0; i <= EW_DEG; i++) p.ewPoly[i] = (Real)ewPoly[i];
+            p.ewScale = (Real)(2.0 / ewR2Max);
+            { static const bool noPoly = getenv("SNB_EWALD_ERFC") != nullptr; p.ewUsePoly = noPoly ? 0 : 1; }
             { static const int dbgBits = getenv("SNB_DBG") ? atoi(getenv("SNB_DBG")) : 0; p.dbg = dbgBits; }
             const double ic2 = 1.0 / (cfg.cutoff * cfg.cutoff), ic6 = ic2 * ic2 * ic2;
             const double dar2 = cfg.alpha_d * cfg.alpha_d * cfg.cutoff * cfg.cutoff;

@@ -52,7 +52,7 @@ template <typename Real> struct DirectParams {
     Real cutoff2, krf, crf, alpha, alphaD, k4pe;          // k4pe = ONE_4PI_EPS0
     Real alpha2l2e;                                        // alpha^2 * log2(e)
     int dbg;                   // SNB_DBG experiment bits (1: no j-force flush, 2: no pair arithmetic, 4: ignore masks) - timing decomposition only
-    const float2* ewaldTable; int tabN; float tabScale;    // single-precision forces-only path: Bt(r^2) table, tabN intervals over [0, (cutoff+skin)^2]
+    Real ewPoly[12]; Real ewScale; int ewUsePoly;         // single-precision forces-only path: Bt(r^2) ~ sum_k ewPoly[k] t^k, t = r^2 * ewScale - 1 (engine.hip buildEwaldPoly)
     Real invCut6, multShift6;                              // LJPME potential shifts
     int useSwitch; Real switchDist, invSwitchWidth;
     Real box[9]; Real invBoxDiag[3];                       // for the per-pair wrap variant

@@ -12,7 +12,7 @@ def jittered_lattice(n, L, rng, jitter=0.05):
     return (g + 0.5) * (L / m) + rng.uniform(-jitter, jitter, (n, 3))
 
 
-def random_box(F, n, nsub, method, L, cutoff, seed=SEED, pme=None, ljpme=None, exclusions=True, lambdas=True, switch=False, density_jitter=0.05):
+def random_box(F, n, nsub, method, L, cutoff, seed=SEED, pme=None, ljpme=None, exclusions=True, lambdas=True, switch=False, density_jitter=0.05, derivatives=True):
     """Charged LJ particles on a jittered lattice, bonded in triplets (2 exclusions + one scaled 1-4 per triplet chain),
     subsets assigned by slabs along x so that blocks are compact."""
     rng = np.random.default_rng(seed)
@@ -52,9 +52,11 @@ def random_box(F, n, nsub, method, L, cutoff, seed=SEED, pme=None, ljpme=None, e
             ne, nv = "lam_elec_0%d" % s, "lam_vdw_0%d" % s
             f.addGlobalParameter(ne, vals[k % 8]); f.addGlobalParameter(nv, vals[(k + 1) % 8]); k += 2
             f.addScalingParameter(ne, 0, s, True, False); f.addScalingParameter(nv, 0, s, False, True)
-            f.addEnergyParameterDerivative(ne); f.addEnergyParameterDerivative(nv)
+            if derivatives:
+                f.addEnergyParameterDerivative(ne); f.addEnergyParameterDerivative(nv)
         if nsub > 2:
             f.addGlobalParameter("lam_12", 0.45)
             f.addScalingParameter("lam_12", 1, 2, True, True)
-            f.addEnergyParameterDerivative("lam_12")
+            if derivatives:
+                f.addEnergyParameterDerivative("lam_12")
     return f, pos, np.diag([L, L, L]).astype(float)

@@ -177,6 +177,39 @@ def test_gpu_builder_and_brick_kernels_vs_oracle(case, snb, F, oev, prec):
     assert r["stats"].n_tiles > 0 and r["stats"].n_host_rebuilds == 0
 
 
+FORCE_ONLY_CASES = [
+    # name, n, nsub, method, L, pme, ljpme, switch
+    ("pme_13824_n4", 13824, 4, 4, 6.0, (2.6283, 48, 48, 48), None, False),        # packed pair kernel (polynomial Ewald), brick PME, graph replay
+    ("rf_13824_n3", 13824, 3, 2, 6.0, None, None, False),                         # packed pair kernel, reaction field
+    ("rf_switch_13824_n2", 13824, 2, 2, 6.0, None, None, True),                   # switching function: scalar forces-only kernel
+    ("ljpme_13824_n3", 13824, 3, 5, 6.0, (2.6283, 48, 48, 48), (2.6283, 24, 24, 24), False),
+    ("pme_smallbox_4096_n2", 4096, 2, 4, 3.5, (2.6283, 32, 32, 32), None, False),  # host-built lists, atomic spreader
+]
+
+
+@pytest.mark.parametrize("case", FORCE_ONLY_CASES, ids=[c[0] for c in FORCE_ONLY_CASES])
+def test_forces_only_steps_vs_oracle(case, snb, F, oev, prec):
+    """The production path: forces-only evaluations (no energy, no parameter derivatives) run the packed single-precision pair
+    kernel and replay a captured hipGraph from the second step on; every step's forces must match the oracle's."""
+    name, n, nsub, method, L, pme, ljpme, switch = case
+    force, pos, box = systems.random_box(F, n, nsub, method, L, 1.0, pme=pme, ljpme=ljpme, switch=switch, derivatives=False)
+    system = snb.System()
+    for _ in range(n):
+        system.addParticle(1.0)
+    system.setDefaultPeriodicBoxVectors(*box)
+    system.addForce(force)
+    ctx = snb.Context(system, precision=prec, neighbor_padding=0.1, rebuild_interval=10)
+    rng = np.random.default_rng(7)
+    tol = TOLS[prec]
+    for step in range(4):
+        ctx.setPositions(pos)
+        fr = ctx.getState(getForces=True).getForces()
+        fo = oev(force, pos, box)["forces"]
+        err = np.linalg.norm(fo - fr, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)
+        assert err.max() <= tol, "step %d: max force error %g at atom %d" % (step, err.max(), int(err.argmax()))
+        pos = pos + rng.normal(0.0, 0.004, pos.shape)      # the list (skin 0.1 nm) is reused, the graph replayed
+
+
 def test_padding_and_rebuild_interval(snb, F, oev):
     """Tiles built with a skin and reused across steps must give the same answer as a fresh list."""
     force, pos, box = systems.random_box(F, 4096, 2, 4, 3.5, 1.0, pme=(2.6283, 32, 32, 32))
