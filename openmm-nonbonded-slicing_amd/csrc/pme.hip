@@ -901,9 +901,11 @@ template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hip
     const int nCols = p.d.ny * p.d.nzc;
     const size_t perCol = (size_t)2 * nx * p.nsub * sizeof(Cx<Real>) + (size_t)nx * sizeof(Real);
     const size_t twBytes = (size_t)nx * sizeof(Cx<Real>);
-    int NB = (int)((40 * 1024) / perCol);     // ~40 KB per work-group: 3-4 work-groups of 512 threads per CU
-    if (NB > 16) NB = 16;
-    if (NB < 1) NB = 1;
+    // columns per work-group: 8 adjacent (ky,kz) columns are one 64-byte line per (subset, kx) row -- measured on c3 (4 subsets):
+    // NB = 4: 68 us, 5: 64, 7: 69, 8: 48.5, 16: 60.5 -- so 8 when that fits ~72 KB of LDS, else 4, 2, 1
+    static const int ldsKB = getenv("SNB_CONV_LDS_KB") ? atoi(getenv("SNB_CONV_LDS_KB")) : 72;
+    int NB = 8;
+    while (NB > 1 && perCol * NB > (size_t)ldsKB * 1024) NB >>= 1;
     const size_t lds = perCol * NB + twBytes;
     launchConvolveX<Real>(p.d.rx1, p.d.rx2, dim3((unsigned)((nCols + NB - 1) / NB)), lds, s, p, NB, nCols);
 }
