@@ -200,7 +200,7 @@ public:
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
     DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC;
-    DevBuf<long long> dNbTrace;
+    DevBuf<long long> dNbTrace, dPmeTrace;
     bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
     double maxAbsQ = 0, maxAbsC6 = 0;
     DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset, exclStart, exclList;
@@ -253,6 +253,7 @@ public:
     }
     ~Engine() override {
         (void)hipStreamSynchronize(stream);
+        if (dPmeTrace.p) { long long h[4] = {0, 0, 0, 0}; (void)hipMemcpy(h, dPmeTrace.p, 32, hipMemcpyDeviceToHost); if (h[2] > 0) fprintf(stderr, "[snb] interpolation bricks: mean load %.2f us, mean compute %.2f us per work-group (%lld work-groups)\n", h[0] / 100.0 / h[2], h[1] / 100.0 / h[2], h[2]); }
         dropGraph();
         for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
         for (int k = 0; k < 3; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
@@ -827,6 +828,7 @@ public:
     void fillPme(PmeParams<Real>& p, PmePlan<Real>& plan, bool wantEnergy) {
         p.d = plan.d; p.nsub = nGrids; p.natoms = Npad; p.posq = posq.p; p.sigeps = sigeps.p; p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p;
         p.cells = pmeCells.p;
+        { static const bool tr = getenv("SNB_PME_TRACE") != nullptr; if (tr) { if (!dPmeTrace.p) { dPmeTrace.resize(4); HIPCHECK(hipMemset(dPmeTrace.p, 0, 32)); } p.trace = dPmeTrace.p; } }
         p.cellsReady = (!plan.dispersion && cellsFromGather) ? 1 : 0;
         {   // fixed point: 16 x the largest per-atom charge fits 31 bits (a grid point collects at most a few atoms' weights, each <= 1)
             const double m = std::max(plan.dispersion ? maxAbsC6 : maxAbsQ, 1e-30);

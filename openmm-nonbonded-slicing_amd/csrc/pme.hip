@@ -889,7 +889,8 @@ template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipS
     }
     // y
     {
-        const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), 16);
+        static const int nbMax = getenv("SNB_FFTY_NB") ? atoi(getenv("SNB_FFTY_NB")) : 32;   // measured on c3: 8: 40 us, 16: 31, 21: 28.4, 32: 27.8
+        const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), nbMax);
         const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>) + (size_t)ny * sizeof(Cx<Real>);
         const int tilesPerA = (nzc + NB - 1) / NB;
         launchFftStrided<Real>(p.d.ry1, p.d.ry2, dim3((unsigned)(p.nsub * nx * tilesPerA)), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB, tilesPerA, -1, 1);
@@ -913,7 +914,8 @@ template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hip
 template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipStream_t s) {
     const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc;
     {
-        const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), 16);
+        static const int nbMax = getenv("SNB_FFTY_NB") ? atoi(getenv("SNB_FFTY_NB")) : 32;   // measured on c3: 8: 40 us, 16: 31, 21: 28.4, 32: 27.8
+        const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), nbMax);
         const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>) + (size_t)ny * sizeof(Cx<Real>);
         const int tilesPerA = (nzc + NB - 1) / NB;
         launchFftStrided<Real>(p.d.ry1, p.d.ry2, dim3((unsigned)(p.nsub * nx * tilesPerA)), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB, tilesPerA, +1, 1);
@@ -1102,20 +1104,26 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
 // (plain read-modify-write: the work-group is the only writer of its columns' atoms; the gather pass cleared the arrays), and --
 // on energy steps -- E[slice(s_i, J)] += 1/2 q_i psi_J(r_i).  Replaces the 32-lanes-per-atom gather kernel, which
 // cost ~80 us per held grid at 300k atoms.
-template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBrickSharded(const PmeParams<Real> p) {
+// (occupancy note: ~100 VGPRs => one 1024-thread work-group per CU, 400 bricks = two rounds of ~20 us on c3; forcing 64 VGPRs spills
+// and measures 71 us, 512-thread groups 56 us, z slabs 70 us -- this shape, 52 us, is the best of those)
+template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBrickSharded(const PmeParams<Real> p, const int zSlabs) {
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
     constexpr int NT = 1024, HALO_LO = 1, EXTRA = 6;
     const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
     const int cx = p.groupX * (p.d.nx / ncx), cy = p.groupY * (p.d.ny / ncy);
     const int nby = ncy / p.groupY;
     const int ncol = ncx * ncy;
-    const int Bx = blockIdx.x / nby, By = blockIdx.x - Bx * nby;
+    // the brick is cut into zSlabs slabs along z (more, smaller work-groups): a slab owns the atoms whose base cell lies in it and
+    // stages sz + 4 planes (the stencil reaches 4 cells up, with periodic wrap)
+    const int zs = blockIdx.x % zSlabs, brickId = blockIdx.x / zSlabs;
+    const int sz = nz / zSlabs, z0 = zs * sz, bz = zSlabs == 1 ? nz : sz + 4;
+    const int Bx = brickId / nby, By = brickId - Bx * nby;
     const int x0 = Bx * cx, y0 = By * cy;
     const int bx = cx + EXTRA, by = cy + EXTRA;
     const int tid = threadIdx.x;
     Real* brick = reinterpret_cast<Real*>(s_brick_raw);
-    double* sE = reinterpret_cast<double*>(s_brick_raw + ((sizeof(Real) * (size_t)bx * by * nz + 15) & ~(size_t)15));   // [2*S] on energy steps
-    const bool wantE = p.wantEnergy != 0;
+    double* sE = reinterpret_cast<double*>(s_brick_raw + ((sizeof(Real) * (size_t)bx * by * bz + 15) & ~(size_t)15));   // [2*S] on energy steps
+    const bool wantE = p.wantEnergy != 0 && !p.mix;            // unsharded energies come from the k-space Gram sums (k_convolveX)
     const int nS2 = p.nsubTotal * (p.nsubTotal + 1);
     const int term = p.dispersion ? 1 : 0;
     if (wantE) for (int i = tid; i < nS2; i += NT) sE[i] = 0.0;
@@ -1132,25 +1140,35 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
     __syncthreads();
     const int total = s_pref[nr];
     if (total == 0) return;
-    const FastDiv dnz(nz), dby(by);
+    long long tA = 0, tLoad = 0, tComp = 0;
+    const bool trace = p.trace != nullptr;
+    const FastDiv dnz(bz), dby(by);
+    const int g2 = p.groupX * p.groupY;
     for (int slot = 0; slot < p.nsub; slot++) {
         const int gj = p.gridSubset[slot];
+        // unsharded (mix == 1): grid `slot` is the lambda-mixed potential felt by subset gj, so only that subset's atoms read it (and a
+        // brick without such atoms is not even staged); sharded: every subset's atoms read every held grid, scaled by lambda
+        const int vBegin = p.mix ? s_pref[gj * g2] : 0, vEnd = p.mix ? s_pref[(gj + 1) * g2] : total;
+        if (vBegin == vEnd) continue;                          // uniform over the work-group
         const Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
         __syncthreads();                                       // previous grid's readers are done with the brick
-        for (int i = tid; i < bx * by * nz; i += NT) {
-            const int l = dnz.div(i), z = i - l * nz;
+        if (trace) tA = (long long)wall_clock64();
+        for (int i = tid; i < bx * by * bz; i += NT) {
+            const int l = dnz.div(i), z = i - l * bz;
             const int lx = dby.div(l), ly = l - lx * by;
             int x = x0 + lx - HALO_LO; if (x < 0) x += p.d.nx; else if (x >= p.d.nx) x -= p.d.nx;
             int y = y0 + ly - HALO_LO; if (y < 0) y += p.d.ny; else if (y >= p.d.ny) y -= p.d.ny;
-            brick[i] = g[((size_t)x * p.d.ny + y) * nz + z];
+            int zg = z0 + z; if (zg >= nz) zg -= nz;
+            brick[i] = g[((size_t)x * p.d.ny + y) * nz + zg];
         }
         __syncthreads();
+        if (trace) { const long long t = (long long)wall_clock64(); tLoad += t - tA; tA = t; }
         // the atoms of ALL subsets in the brick's columns, as one concatenated index space (their runs are short when there are many
         // subsets: one pass per subset would leave most of the 1024 threads idle)
         {
-            for (int v0 = 0; v0 < total; v0 += NT) {
+            for (int v0 = vBegin; v0 < vEnd; v0 += NT) {
                 const int v = v0 + tid;
-                if (v < total) {
+                if (v < vEnd) {
                     int r = 0;
 #pragma unroll
                     for (int st = 128; st > 0; st >>= 1) if (r + st < nr && s_pref[r + st] <= v) r += st;
@@ -1159,36 +1177,37 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
                     const Real q = si >= 0 ? pmeCharge(p, a) : Real(0);
                     if (q == Real(0)) continue;                // padding slots inside a run, uncharged atoms
                     const int slice = si > gj ? si * (si + 1) / 2 + gj : gj * (gj + 1) / 2 + si;
-                    const Real lam = p.lambdas[2 * slice + term];
+                    const Real lam = p.mix ? Real(1) : p.lambdas[2 * slice + term];
                     const auto pos = p.posq[a];
                     int idx[3]; Real fr[3];
                     gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
+                    if (idx[2] < z0 || idx[2] >= z0 + sz) continue;       // another slab's atom
                     int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
                     int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
                     Real tx[5], ty[5], tz[5], dx[5], dy[5], dz[5];
                     bspline5<Real>(fr[0], tx, dx); bspline5<Real>(fr[1], ty, dy); bspline5<Real>(fr[2], tz, dz);
-                    int zi[5];
+                    int zi[5], zl[5];                                    // global (wrapped) and slab-local z of the five stencil planes
 #pragma unroll
-                    for (int iz = 0; iz < 5; iz++) { int z = idx[2] + iz; zi[iz] = z >= nz ? z - nz : z; }
+                    for (int iz = 0; iz < 5; iz++) { int z = idx[2] + iz; zi[iz] = z >= nz ? z - nz : z; zl[iz] = zSlabs == 1 ? zi[iz] : idx[2] - z0 + iz; }
                     Real fx = 0, fy = 0, fz = 0, psi = 0;
                     const bool inBrick = rx >= -HALO_LO && rx + 4 < bx - HALO_LO && ry >= -HALO_LO && ry + 4 < by - HALO_LO;
 #pragma unroll
                     for (int ix = 0; ix < 5; ix++) {
 #pragma unroll
                         for (int iy = 0; iy < 5; iy++) {
-                            Real sz = 0, sdz = 0;
+                            Real sv = 0, sdz = 0;
                             if (inBrick) {
-                                const Real* line = brick + (size_t)((rx + HALO_LO + ix) * by + (ry + HALO_LO + iy)) * nz;
+                                const Real* line = brick + (size_t)((rx + HALO_LO + ix) * by + (ry + HALO_LO + iy)) * bz;
 #pragma unroll
-                                for (int iz = 0; iz < 5; iz++) { const Real gv = line[zi[iz]]; sz += tz[iz] * gv; sdz += dz[iz] * gv; }
+                                for (int iz = 0; iz < 5; iz++) { const Real gv = line[zl[iz]]; sv += tz[iz] * gv; sdz += dz[iz] * gv; }
                             } else {   // drifted further than the halo since the last re-sort: correct but slow path through global memory
                                 int x = idx[0] + ix; if (x >= p.d.nx) x -= p.d.nx;
                                 int y = idx[1] + iy; if (y >= p.d.ny) y -= p.d.ny;
                                 const Real* line = g + ((size_t)x * p.d.ny + y) * nz;
 #pragma unroll
-                                for (int iz = 0; iz < 5; iz++) { const Real gv = line[zi[iz]]; sz += tz[iz] * gv; sdz += dz[iz] * gv; }
+                                for (int iz = 0; iz < 5; iz++) { const Real gv = line[zi[iz]]; sv += tz[iz] * gv; sdz += dz[iz] * gv; }
                             }
-                            fx += dx[ix] * ty[iy] * sz; fy += tx[ix] * dy[iy] * sz; fz += tx[ix] * ty[iy] * sdz; psi += tx[ix] * ty[iy] * sz;
+                            fx += dx[ix] * ty[iy] * sv; fy += tx[ix] * dy[iy] * sv; fz += tx[ix] * ty[iy] * sdz; psi += tx[ix] * ty[iy] * sv;
                         }
                     }
                     const Real nx = p.d.nx, ny = p.d.ny, nzr = p.d.nz;
@@ -1200,7 +1219,9 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
                 }
             }
         }
+        if (trace) { __syncthreads(); tComp += (long long)wall_clock64() - tA; }
     }
+    if (trace && tid == 0) { atomicAdd((unsigned long long*)&p.trace[0], (unsigned long long)tLoad); atomicAdd((unsigned long long*)&p.trace[1], (unsigned long long)tComp); atomicAdd((unsigned long long*)&p.trace[2], 1ull); }
     if (wantE) {
         __syncthreads();
         for (int i = tid; i < nS2; i += NT) { const double v = sE[i]; if (v != 0.0) atomicAdd(&p.sliceE[i], v); }
@@ -1209,7 +1230,8 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
 
 template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s) {
     if (p.natoms <= 0) return;
-    if (p.mix && p.sortNcx > 0 && p.colRange != nullptr) {
+    static const bool oldMixBrick = getenv("SNB_OLD_INTERP_BRICK") != nullptr;
+    if (oldMixBrick && p.mix && p.sortNcx > 0 && p.colRange != nullptr) {
         const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
         const size_t lds = sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * p.d.nz;
         if (lds <= 150 * 1024) {
@@ -1220,14 +1242,18 @@ template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hip
             return;
         }
     }
-    if (!p.mix && p.sortNcx > 0 && p.colRange != nullptr) {
+    if (p.sortNcx > 0 && p.colRange != nullptr) {
         const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
-        const size_t lds = ((sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * p.d.nz + 15) & ~(size_t)15) + sizeof(double) * p.nsubTotal * (p.nsubTotal + 1);
+        static const int zsEnv = getenv("SNB_INTERP_ZSLABS") ? atoi(getenv("SNB_INTERP_ZSLABS")) : 0;
+        int zSlabs = 1;      // measured on c3: 1 slab 52 us, 2 slabs 70, 4 slabs 72 (every slab rescans the columns' atoms)
+        if (zsEnv > 0 && p.d.nz % zsEnv == 0 && p.d.nz / zsEnv >= 8) zSlabs = zsEnv;
+        const int bz = zSlabs == 1 ? p.d.nz : p.d.nz / zSlabs + 4;
+        const size_t lds = ((sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * bz + 15) & ~(size_t)15) + sizeof(double) * p.nsubTotal * (p.nsubTotal + 1);
         static const bool noBrick = getenv("SNB_NO_SHARDED_BRICK") != nullptr;
         if (lds <= 150 * 1024 && !noBrick && p.nsubTotal * p.groupX * p.groupY <= 256) {
-            const int nblocks = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
+            const int nblocks = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * zSlabs;
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBrickSharded<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_interpolateBrickSharded<Real>), dim3(nblocks), dim3(1024), lds, s, p);
+            hipLaunchKernelGGL((k_interpolateBrickSharded<Real>), dim3(nblocks), dim3(1024), lds, s, p, zSlabs);
             return;
         }
     }

@@ -97,6 +97,7 @@ template <typename Real> struct PmeParams {
     const int* atomSubset;    // [Npad] sorted
     const int* atomGrid;      // [Npad] grid slot of the atom's subset, or -1 (not owned / padding)
     Real fixScale, fixInv;    // single-precision brick spreader: LDS accumulation in 32-bit fixed point (value * fixScale)
+    long long* trace;         // SNB_PME_TRACE: [0] summed load ticks, [1] summed compute ticks, [2] work-groups (interpolation bricks; 100 MHz ticks)
     int cellsReady;           // cells[] already hold this mesh's cells (written by the position-gather pass)
     int* cells;               // [Npad] scratch: packed mesh cell per atom (k_pmeCells), brick spreader only
     Real* gridReal;           // [nsub][nx][ny][nz]
