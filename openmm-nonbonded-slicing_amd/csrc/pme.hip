@@ -1228,6 +1228,26 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
     }
 }
 
+template <typename Real> static void launchInterpolateBricks(const PmeParams<Real>& p, hipStream_t s) {
+    {
+        const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
+        static const int zsEnv = getenv("SNB_INTERP_ZSLABS") ? atoi(getenv("SNB_INTERP_ZSLABS")) : 0;
+        int zSlabs = 1;      // measured on c3: 1 slab 52 us, 2 slabs 70, 4 slabs 72 (every slab rescans the columns' atoms)
+        if (zsEnv > 0 && p.d.nz % zsEnv == 0 && p.d.nz / zsEnv >= 8) zSlabs = zsEnv;
+        const int bz = zSlabs == 1 ? p.d.nz : p.d.nz / zSlabs + 4;
+        const size_t lds = ((sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * bz + 15) & ~(size_t)15) + sizeof(double) * p.nsubTotal * (p.nsubTotal + 1);
+        static const bool noBrick = getenv("SNB_NO_SHARDED_BRICK") != nullptr;
+        if (lds <= 150 * 1024 && !noBrick && p.nsubTotal * p.groupX * p.groupY <= 256) {
+            const int nblocks = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * zSlabs;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBrickSharded<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_interpolateBrickSharded<Real>), dim3(nblocks), dim3(1024), lds, s, p, zSlabs);
+            return;
+        }
+    }
+    const size_t lds = (!p.mix && p.wantEnergy) ? sizeof(double) * p.nsubTotal * (p.nsubTotal + 1) : 0;
+    hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
+}
+
 template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s) {
     if (p.natoms <= 0) return;
     static const bool oldMixBrick = getenv("SNB_OLD_INTERP_BRICK") != nullptr;
@@ -1243,19 +1263,20 @@ template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hip
         }
     }
     if (p.sortNcx > 0 && p.colRange != nullptr) {
-        const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
-        static const int zsEnv = getenv("SNB_INTERP_ZSLABS") ? atoi(getenv("SNB_INTERP_ZSLABS")) : 0;
-        int zSlabs = 1;      // measured on c3: 1 slab 52 us, 2 slabs 70, 4 slabs 72 (every slab rescans the columns' atoms)
-        if (zsEnv > 0 && p.d.nz % zsEnv == 0 && p.d.nz / zsEnv >= 8) zSlabs = zsEnv;
-        const int bz = zSlabs == 1 ? p.d.nz : p.d.nz / zSlabs + 4;
-        const size_t lds = ((sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * bz + 15) & ~(size_t)15) + sizeof(double) * p.nsubTotal * (p.nsubTotal + 1);
-        static const bool noBrick = getenv("SNB_NO_SHARDED_BRICK") != nullptr;
-        if (lds <= 150 * 1024 && !noBrick && p.nsubTotal * p.groupX * p.groupY <= 256) {
-            const int nblocks = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * zSlabs;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBrickSharded<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_interpolateBrickSharded<Real>), dim3(nblocks), dim3(1024), lds, s, p, zSlabs);
-            return;
+        // The kernel needs ~100 VGPRs, so one 1024-thread work-group occupies a CU: with more bricks than CUs the launch runs in rounds.
+        // Wider bricks (2 x 1, 2 x 2 columns) cut the count below the CU count and the halo overhead with it, as long as LDS allows.
+        PmeParams<Real> q = p;
+        static const int gEnv = getenv("SNB_INTERP_GROUP") ? atoi(getenv("SNB_INTERP_GROUP")) : -1;
+        for (int step = 0; step < 2; step++) {
+            const int nb = (q.sortNcx / q.groupX) * (q.sortNcy / q.groupY);
+            if (gEnv >= 0 ? step >= gEnv : nb <= 256) break;
+            PmeParams<Real> t = q;
+            if (step == 0 && t.sortNcx % (2 * t.groupX) == 0) t.groupX *= 2; else if (t.sortNcy % (2 * t.groupY) == 0) t.groupY *= 2; else break;
+            const size_t need = sizeof(Real) * (size_t)(t.groupX * (t.d.nx / t.sortNcx) + 6) * (t.groupY * (t.d.ny / t.sortNcy) + 6) * t.d.nz + 1024;
+            if (need > 150 * 1024 || t.nsubTotal * t.groupX * t.groupY > 256) break;
+            q = t;
         }
+        return launchInterpolateBricks<Real>(q, s);
     }
     const size_t lds = (!p.mix && p.wantEnergy) ? sizeof(double) * p.nsubTotal * (p.nsubTotal + 1) : 0;
     hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
