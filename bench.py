@@ -243,6 +243,9 @@ class Engine:
         self.ok(self.L.snb_execute(self.h, 1, int(energy), 1, 1, ctypes.byref(e)))
         return e.value
 
+    def set_force_output(self, ptr, is_double, accumulate=0):
+        self.ok(self.L.snb_set_force_output(self.h, ctypes.c_void_p(ptr), int(is_double), int(accumulate)))
+
     def forces_to(self, ptr, is_double):
         self.ok(self.L.snb_get_forces(self.h, ctypes.c_void_p(ptr), 1, int(is_double), 0))
 
@@ -292,6 +295,7 @@ def main():
     pos0 = torch.tensor(w["pos"], dtype=tdtype, device=dev).contiguous()
     pos = pos0.clone()
     forces = torch.zeros((N, 3), dtype=tdtype, device=dev)
+    eng.set_force_output(forces.data_ptr(), is_double)      # the step graph ends with the user-order force write; forces_to() below is then free
     # deterministic tiny jitter direction so that every step sees new coordinates (stays far inside the list skin)
     jit = torch.tensor(np.random.default_rng(SEED + 1).uniform(-1, 1, (N, 3)), dtype=tdtype, device=dev) * 2e-4
 

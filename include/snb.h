@@ -133,6 +133,11 @@ snb_status snb_execute(snb_handle h, int32_t include_forces, int32_t include_ene
 /* out: [N][3] in the type selected by is_double; accumulate != 0 adds to what is there (the reference
  * accumulates into the platform's force buffer). */
 snb_status snb_get_forces(snb_handle h, void* out, int32_t is_device, int32_t is_double, int32_t accumulate);
+/* Optional: name the device buffer ([N][3], type by is_double) that every following snb_execute writes (accumulate == 0) or adds
+ * (accumulate != 0) the forces to as the last kernel of the step -- it then belongs to the replayed step graph and a later
+ * snb_get_forces on the same pointer is a no-op.  out == NULL switches this off.  (The reference's execute() adds into the
+ * platform's force buffer itself, NonbondedSlicingKernels.h:59; this is that behaviour without an extra launch per step.) */
+snb_status snb_set_force_output(snb_handle h, void* out, int32_t is_double, int32_t accumulate);
 /* Raw (unscaled) energies of the last execute with include_energy: out[S][2] = (Coulomb, vdW). */
 snb_status snb_get_slice_energies(snb_handle h, double* out);
 snb_status snb_synchronize(snb_handle h);

@@ -59,6 +59,7 @@ struct EngineBase {
     virtual void requestRebuild() = 0;
     virtual void execute(int, int, int, int, double*) = 0;
     virtual void getForces(void*, int, int, int) = 0;
+    virtual void setForceOutput(void*, int, int) = 0;
     virtual void getSliceEnergies(double*) = 0;
     virtual void sync() = 0;
     virtual void getStats(snb_stats*) = 0;
@@ -215,7 +216,11 @@ public:
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
     std::vector<int3> hKvec; DevBuf<int3> dKvec; DevBuf<Real> dCosSin;
-    struct GraphKey { const void* pos; int isDouble, stride4; bool direct, recip; bool operator==(const GraphKey& o) const { return pos == o.pos && isDouble == o.isDouble && stride4 == o.stride4 && direct == o.direct && recip == o.recip; } };
+    struct GraphKey {
+        const void* pos; int isDouble, stride4; bool direct, recip; void* out; int outDouble, outAcc;
+        bool operator==(const GraphKey& o) const { return pos == o.pos && isDouble == o.isDouble && stride4 == o.stride4 && direct == o.direct && recip == o.recip && out == o.out && outDouble == o.outDouble && outAcc == o.outAcc; }
+    };
+    void* outPtr = nullptr; int outIsDouble = 0, outAccumulate = 0; bool outputWritten = false;   // snb_set_force_output
     hipGraphExec_t graphExec = nullptr; GraphKey graphKey{}; long long execCount = 0;
     void dropGraph() { if (graphExec) { (void)hipGraphExecDestroy(graphExec); graphExec = nullptr; } }
     bool lastRecip = false;
@@ -879,6 +884,7 @@ public:
         if (dLambdas.p == nullptr) setLambdas(lambdas.data());
         if (needRebuild || paramsDirty || cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval || cfg.neighbor_padding <= 0) rebuild();
         stepsSinceRebuild++;
+        outputWritten = outPtr != nullptr;
         const bool energy = includeEnergy != 0;
         lastRecip = includeRecip && (isPme() || cfg.method == SNB_Ewald);
         // Forces-only steps replay a captured hipGraph (the ~14 small launches of a step are host-launch-bound otherwise:
@@ -891,7 +897,7 @@ public:
             enqueueStep(energy, includeDirect != 0, includeRecip != 0, &ev);
             ev.pending = true;
         } else {
-            GraphKey key{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0};
+            GraphKey key{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0, outPtr, outIsDouble, outAccumulate};
             if (!graphExec || !(key == graphKey)) {
                 dropGraph();
                 if (!stream2 && concurrentPme) {   // created outside the capture
@@ -1009,6 +1015,10 @@ public:
         }
         if (fork) { HIPCHECK(hipEventRecord(evJoin, stream2)); HIPCHECK(hipStreamWaitEvent(stream, evJoin, 0)); }
         if (includeRecip && cfg.method == SNB_Ewald && cfg.shard_rank == 0) runEwald(energy);
+        if (outPtr) {   // the step's last kernel: user-order forces into the caller's buffer (part of the graph)
+            const bool recipDone = includeRecip && (isPme() || cfg.method == SNB_Ewald);
+            launchFinishForces<Real>(fx.p, fy.p, fz.p, recipDone ? fpx.p : nullptr, fpy.p, fpz.p, dUserToSorted.p, N, outPtr, outIsDouble, outAccumulate, stream);
+        }
         if (ev) HIPCHECK(hipEventRecord(ev->e[4], stream));
     }
 
@@ -1075,7 +1085,9 @@ public:
             for (int s = 0; s < S; s++) hostSliceE[2 * s + 1] += dispCoef[s] / volume;
     }
 
+    void setForceOutput(void* out, int isDouble, int accumulate) override { outPtr = out; outIsDouble = isDouble; outAccumulate = accumulate; outputWritten = false; }
     void getForces(void* out, int isDevice, int isDouble, int accumulate) override {
+        if (isDevice && out == outPtr && isDouble == outIsDouble && outputWritten) return;   // the last execute already delivered them there
         const size_t bytes = (size_t)N * 3 * (isDouble ? 8 : 4);
         const Real* px = lastRecip ? fpx.p : nullptr;
         if (isDevice) { launchFinishForces<Real>(fx.p, fy.p, fz.p, px, fpy.p, fpz.p, dUserToSorted.p, N, out, isDouble, accumulate, stream); return; }
@@ -1203,6 +1215,7 @@ snb_status snb_get_forces(snb_handle h, void* out, int32_t isDevice, int32_t isD
     if (!out) return SNB_ERR_INVALID_ARGUMENT;
     return guard(h, [&] { h->impl->getForces(out, isDevice, isDouble, acc); });
 }
+snb_status snb_set_force_output(snb_handle h, void* out, int32_t isDouble, int32_t acc) { return guard(h, [&] { h->impl->setForceOutput(out, isDouble, acc); }); }
 snb_status snb_get_slice_energies(snb_handle h, double* out) { if (!out) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->getSliceEnergies(out); }); }
 snb_status snb_synchronize(snb_handle h) { return guard(h, [&] { h->impl->sync(); }); }
 snb_status snb_get_pme_parameters(snb_handle h, double* alpha, int32_t grid[3]) {

@@ -210,6 +210,31 @@ def test_forces_only_steps_vs_oracle(case, snb, F, oev, prec):
         pos = pos + rng.normal(0.0, 0.004, pos.shape)      # the list (skin 0.1 nm) is reused, the graph replayed
 
 
+def test_force_output_inside_the_step_graph(snb):
+    """snb_set_force_output: the user-order force write becomes the last kernel of the (graph-replayed) step; the buffer must hold
+    what snb_get_forces would have delivered, on eager and on replayed steps alike."""
+    import torch
+    import bench
+    w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+    n = len(w["q"])
+    pos = torch.tensor(w["pos"], dtype=torch.float32, device="cuda")
+    ref = bench.Engine(snb, w, 4, 54, 0, "single", 0, 0, 1, 0.1, 10)
+    eng = bench.Engine(snb, w, 4, 54, 0, "single", 0, 0, 1, 0.1, 10)
+    out = torch.full((n, 3), float("nan"), dtype=torch.float32, device="cuda")
+    eng.set_force_output(out.data_ptr(), False)
+    fr = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    for step in range(5):
+        ref.set_positions_device(pos.data_ptr(), False); ref.execute(False); ref.forces_to(fr.data_ptr(), False); ref.sync()
+        eng.set_positions_device(pos.data_ptr(), False); eng.execute(False); eng.forces_to(out.data_ptr(), False); eng.sync()
+        a, b = fr.double().cpu().numpy(), out.double().cpu().numpy()
+        assert np.isfinite(b).all()
+        err = np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(a, axis=1), 1.0)
+        assert err.max() < 2e-4, (step, err.max())      # same kernels; only the atomic summation order differs
+        pos = pos + torch.randn(pos.shape, generator=g, device="cuda") * 0.003
+    ref.close(); eng.close()
+
+
 def test_padding_and_rebuild_interval(snb, F, oev):
     """Tiles built with a skin and reused across steps must give the same answer as a fresh list."""
     force, pos, box = systems.random_box(F, 4096, 2, 4, 3.5, 1.0, pme=(2.6283, 32, 32, 32))
