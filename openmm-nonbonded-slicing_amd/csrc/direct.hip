@@ -15,6 +15,7 @@
 // per-pair slice arithmetic at all (the reference computes the slice index and loads LAMBDA[slice] per pair).
 #include "snb_internal.h"
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace snb {
@@ -358,13 +359,24 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
     }
 }
 
+template <typename Real, bool ENERGY> __device__ __forceinline__ void exceptionsBody(const PairListParams<Real>& p, const int blk);
+template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionAtomsBody(const PairListParams<Real>& p, const int blk);
+
+// The first nListBlocks work-groups of the launch run the O(N) pair lists (exclusion corrections, then 1-4 exceptions: latency-bound
+// work that overlaps the VALU-bound tile work instead of trailing it as a launch of its own); the others loop over tile work items.
 template <int MC, bool POLY>
-__global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<float> p) {
+__global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<float> p, const PairListParams<float> q, const int nExclBlocks, const int nListBlocks) {
+    if ((int)blockIdx.x < nListBlocks) {
+        if ((int)blockIdx.x < nExclBlocks) { PairListParams<float> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<float, false>(qe, blockIdx.x); }
+        else exceptionsBody<float, false>(q, blockIdx.x - nExclBlocks);
+        return;
+    }
+    const int tileBlock = blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
     __shared__ float4 s_pos[4][64];
     __shared__ float2 s_se[4][64];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int item = blockIdx.x * 4 + wid; item < p.numWork; item += gridDim.x * 4) {   // no block-level barrier inside the loop
+    for (int item = tileBlock * 4 + wid; item < p.numWork; item += nTileBlocks * 4) {   // no block-level barrier inside the loop
     const int4 wi = p.workItems[p.workStart + item * p.workStride];
     const int I = __builtin_amdgcn_readfirstlane(wi.x);
     const int tBegin = __builtin_amdgcn_readfirstlane(wi.y), tEnd = tBegin + __builtin_amdgcn_readfirstlane(wi.z);
@@ -452,17 +464,22 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
 }
 
 
-template <typename Real, int MC> static void launchDirectMC(const DirectParams<Real>& p, bool wrap, bool energy, hipStream_t s) {
+template <typename Real, int MC> static bool launchDirectMC(const DirectParams<Real>& p, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s) {
     const int myItems = p.numWork;
-    if (myItems <= 0) return;
+    if (myItems <= 0) return false;
     int nwg = (myItems + 3) / 4;
     { static const int cap = getenv("SNB_DIRECT_WGS") ? atoi(getenv("SNB_DIRECT_WGS")) : 0; if (cap > 0 && nwg > cap) nwg = cap; }
     dim3 grid(nwg), block(256);
     if constexpr (std::is_same<Real, float>::value && MC != MC_LJPME) {
         if (!wrap && !energy && !p.useSwitch) {
-            if (MC == MC_EWALD && p.ewUsePoly) hipLaunchKernelGGL((k_directPacked<MC, true>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((k_directPacked<MC, false>), grid, block, 0, s, p);
-            return;
+            PairListParams<float> q;
+            std::memset(&q, 0, sizeof(q));
+            int nExclBlocks = 0, nListBlocks = 0;
+            if (lists) { q = *lists; nExclBlocks = (q.nExclAtoms + 255) / 256; nListBlocks = nExclBlocks + (q.n + 255) / 256; }
+            dim3 gridAll(nwg + nListBlocks);
+            if (MC == MC_EWALD && p.ewUsePoly) hipLaunchKernelGGL((k_directPacked<MC, true>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
+            else hipLaunchKernelGGL((k_directPacked<MC, false>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
+            return lists != nullptr;
         }
     }
     if (wrap) {
@@ -472,19 +489,22 @@ template <typename Real, int MC> static void launchDirectMC(const DirectParams<R
         if (energy) hipLaunchKernelGGL((k_direct<Real, MC, false, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((k_direct<Real, MC, false, false>), grid, block, 0, s, p);
     }
+    return false;
 }
 
-template <typename Real> void launchDirect(const DirectParams<Real>& p0, int mc, bool wrap, bool energy, hipStream_t s) {
+// Returns true when the launch also ran the pair lists passed in `lists` (single-precision forces-only tile kernel); otherwise the
+// caller launches them itself.
+template <typename Real> bool launchDirect(const DirectParams<Real>& p0, int mc, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s) {
     const DirectParams<Real>& p = p0;
     switch (mc) {
-        case MC_NOCUTOFF: launchDirectMC<Real, MC_NOCUTOFF>(p, wrap, energy, s); break;
-        case MC_RF: launchDirectMC<Real, MC_RF>(p, wrap, energy, s); break;
-        case MC_EWALD: launchDirectMC<Real, MC_EWALD>(p, wrap, energy, s); break;
-        default: launchDirectMC<Real, MC_LJPME>(p, wrap, energy, s); break;
+        case MC_NOCUTOFF: return launchDirectMC<Real, MC_NOCUTOFF>(p, wrap, energy, lists, s);
+        case MC_RF: return launchDirectMC<Real, MC_RF>(p, wrap, energy, lists, s);
+        case MC_EWALD: return launchDirectMC<Real, MC_EWALD>(p, wrap, energy, lists, s);
+        default: return launchDirectMC<Real, MC_LJPME>(p, wrap, energy, lists, s);
     }
 }
-template void launchDirect<float>(const DirectParams<float>&, int, bool, bool, hipStream_t);
-template void launchDirect<double>(const DirectParams<double>&, int, bool, bool, hipStream_t);
+template bool launchDirect<float>(const DirectParams<float>&, int, bool, bool, const PairListParams<float>*, hipStream_t);
+template bool launchDirect<double>(const DirectParams<double>&, int, bool, bool, const PairListParams<double>*, hipStream_t);
 
 // ---- 1-4 exceptions: ReferenceSlicedLJCoulomb14.cpp:61-95 ----------------------------------------
 template <typename Real, bool ENERGY> __device__ __forceinline__ void exceptionsBody(const PairListParams<Real>& p, const int blk) {

@@ -955,6 +955,20 @@ public:
             HIPCHECK(hipStreamWaitEvent(stream2, evFork, 0));
             pmeStream = stream2;
         }
+        PairListParams<Real> q;
+        std::memset(&q, 0, sizeof(q));
+        const bool haveLists = includeDirect && cfg.shard_rank == 0;   // O(N) pair lists: rank 0 only when sharded
+        if (haveLists) {
+            q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.sliceE = sliceE.p; q.lambdas = dLambdas.p;
+            const bool exPeriodic = (cfg.method == SNB_NoCutoff || cfg.method == SNB_CutoffNonPeriodic) ? false : cfg.exceptions_periodic != 0;
+            q.periodic = exPeriodic ? 1 : 0; q.imageOffset = imageOffset.p;
+            q.sigeps = sigeps.p; q.blockSubset = blockSubset.p; q.exclStart = exclStart.p; q.exclList = exclList.p; q.nSlices = S; q.sortedToUser = dSortedToUser.p; q.userToSorted = dUserToSorted.p;
+            for (int i = 0; i < 9; i++) q.box[i] = (Real)box[i];
+            q.alpha = (Real)cfg.alpha; q.alphaD = (Real)cfg.alpha_d; q.ljpme = cfg.method == SNB_LJPME;
+            q.pairs = pairs14.p; q.params = params14.p; q.n = n14;
+            q.nExclAtoms = (ew && nExcl > 0) ? Npad : 0;
+        }
+        bool listsDone = !haveLists;
         if (ev) HIPCHECK(hipEventRecord(ev->e[1], stream));
         if (includeDirect) {
             DirectParams<Real> p;
@@ -987,22 +1001,11 @@ public:
             if (cfg.method == SNB_CutoffNonPeriodic || cfg.method == SNB_CutoffPeriodic) mc = MC_RF;
             else if (cfg.method == SNB_Ewald || cfg.method == SNB_PME) mc = MC_EWALD;
             else if (cfg.method == SNB_LJPME) mc = MC_LJPME;
-            launchDirect<Real>(p, mc, wrapMode, energy, stream);
+            static const bool noFuse = getenv("SNB_NO_FUSED_LISTS") != nullptr;
+            if (launchDirect<Real>(p, mc, wrapMode, energy, (haveLists && !noFuse) ? &q : nullptr, stream)) listsDone = true;
         }
+        if (!listsDone) launchPairLists<Real>(q, energy, stream);
         if (ev) HIPCHECK(hipEventRecord(ev->e[2], stream));
-        if (includeDirect && cfg.shard_rank == 0) {   // O(N) pair lists: rank 0 only when sharded
-            PairListParams<Real> q;
-            std::memset(&q, 0, sizeof(q));
-            q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.sliceE = sliceE.p; q.lambdas = dLambdas.p;
-            const bool exPeriodic = (cfg.method == SNB_NoCutoff || cfg.method == SNB_CutoffNonPeriodic) ? false : cfg.exceptions_periodic != 0;
-            q.periodic = exPeriodic ? 1 : 0; q.imageOffset = imageOffset.p;
-            q.sigeps = sigeps.p; q.blockSubset = blockSubset.p; q.exclStart = exclStart.p; q.exclList = exclList.p; q.nSlices = S; q.sortedToUser = dSortedToUser.p; q.userToSorted = dUserToSorted.p;
-            for (int i = 0; i < 9; i++) q.box[i] = (Real)box[i];
-            q.alpha = (Real)cfg.alpha; q.alphaD = (Real)cfg.alpha_d; q.ljpme = cfg.method == SNB_LJPME;
-            q.pairs = pairs14.p; q.params = params14.p; q.n = n14;
-            q.nExclAtoms = (ew && nExcl > 0) ? Npad : 0;
-            launchPairLists<Real>(q, energy, stream);
-        }
         if (ev) HIPCHECK(hipEventRecord(ev->e[3], stream));
         if (includeRecip && isPme()) {
             if (nGrids > 0) {
