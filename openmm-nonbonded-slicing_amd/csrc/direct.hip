@@ -310,7 +310,7 @@ template <int MC, bool MASKED, bool POLY>
 __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float4* rdPos, const float2* rdSe, const v2f pix, const v2f piy, const v2f piz,
                                                 const v2f sigi, const v2f qiS, const v2f epsiS, const unsigned maskA, const unsigned maskB, const int c,
                                                 v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz) {
-#pragma unroll
+#pragma unroll 4
     for (int s = 0; s < 8; s++) {
         const float4 xj = rdPos[-s];
         const float2 sj = rdSe[-s];
