@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
     };
     struct TileHead { int sj, maskIdx; };
     auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x, v.y}; };
-    auto loadMask = [&](const TileHead& h) { return (h.maskIdx >= 0 && !(p.dbg & 4)) ? p.masks[h.maskIdx * 32 + il] : 0u; };
+    auto loadMask = [&](const TileHead& h) { return (h.maskIdx >= 0) ? p.masks[h.maskIdx * 32 + il] : 0u; };
     int jcode = p.tileJ[tBegin * 32 + stageJ];
     TileHead head = loadHead(tBegin);
     int jcodeNext = -1; TileHead headNext = head;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
         __builtin_amdgcn_wave_barrier();
         myPos[lane] = pj; mySe[lane] = sej;
         const int curCode = jcode;
-        const bool hasMask = head.maskIdx >= 0 && !(p.dbg & 4);
+        const bool hasMask = head.maskIdx >= 0;
         unsigned maskWord = maskPre;
         const int slice = slicePre;
         const Real lamC = lamCPre, lamL = lamLPre;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
         fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
         // add the two i-halves (rows r and r^1) and flush
         fjx += __shfl_xor(fjx, 16, 64); fjy += __shfl_xor(fjy, 16, 64); fjz += __shfl_xor(fjz, 16, 64);
-        if ((row & 1) == 0 && curCode != -1 && !(p.dbg & 1)) {            // lanes 0-15 (j-half 0) and 32-47 (j-half 1): entry `lane` == j-slot
+        if ((row & 1) == 0 && curCode != -1) {            // lanes 0-15 (j-half 0) and 32-47 (j-half 1): entry `lane` == j-slot
             const int jidx = curCode & SNB_JIDX_MASK;
             gAdd(&p.fx[jidx], fjx); gAdd(&p.fy[jidx], fjy); gAdd(&p.fz[jidx], fjz);
         }

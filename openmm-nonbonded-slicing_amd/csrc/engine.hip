@@ -782,7 +782,6 @@ public:
             p.blockCenter = dBlockCenter.p; p.blockHalf = dBlockHalf.p;
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;
-            { static const int dbgBits = getenv("SNB_DBG") ? atoi(getenv("SNB_DBG")) : 0; p.dbg = dbgBits >> 8; }
             static const bool nbTrace = getenv("SNB_NB_TRACE") != nullptr;
             if (nbTrace) { dNbTrace.resize((size_t)4 * numBlocks); p.dbgOut = dNbTrace.p; }
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.workItems = workItems.p; p.workItemsStage = workItemsStage.p; p.workItemsPartial = workItemsPartial.p; p.counters = dCounters.p;
@@ -852,7 +851,6 @@ public:
         // with bricks of `group` columns when one column is narrower than 5 cells (stencil 4 + 1 cell of drift)
         p.sortNcx = p.sortNcy = 0; p.groupX = p.groupY = 1; p.colRange = nullptr;
         p.zSlabs = 1;
-        { static const int dbgBits = getenv("SNB_DBG") ? atoi(getenv("SNB_DBG")) : 0; p.dbg = dbgBits; }
         // measured on c3: f64 accumulation 1 slab 110 us, 2 slabs 105 us, 4 slabs 145 us; fixed-point (single precision, even nz) 1 slab 61 us, 2 slabs 67 us
         if (plan.d.nz % 2 == 0 && plan.d.nz >= 32 && !(sizeof(Real) == 4)) p.zSlabs = 2;
         if (const char* zs = getenv("SNB_ZSLABS")) { const int k = atoi(zs); if (k >= 1 && plan.d.nz % k == 0) p.zSlabs = k; }
@@ -987,7 +985,6 @@ public:
             for (int i = 0; i <= EW_DEG; i++) p.ewPoly[i] = (Real)ewPoly[i];
             p.ewScale = (Real)(2.0 / ewR2Max);
             { static const bool noPoly = getenv("SNB_EWALD_ERFC") != nullptr; p.ewUsePoly = noPoly ? 0 : 1; }
-            { static const int dbgBits = getenv("SNB_DBG") ? atoi(getenv("SNB_DBG")) : 0; p.dbg = dbgBits; }
             const double ic2 = 1.0 / (cfg.cutoff * cfg.cutoff), ic6 = ic2 * ic2 * ic2;
             const double dar2 = cfg.alpha_d * cfg.alpha_d * cfg.cutoff * cfg.cutoff;
             p.invCut6 = (Real)ic6; p.multShift6 = (Real)(ic6 * (1.0 - std::exp(-dar2) * (1.0 + dar2 + 0.5 * dar2 * dar2)));

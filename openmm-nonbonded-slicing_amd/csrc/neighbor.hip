@@ -278,7 +278,6 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         int maxLen = e1 - e0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(maxLen, o, 64); maxLen = maxLen > other ? maxLen : other; }
-        if (p.dbg & 1) maxLen = 0;
         for (int k = 0; k < maxLen; k++) {
             bool want = false; int sp = -1;
             if (half == 0 && e0 + k < e1) {
@@ -308,7 +307,6 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         first = __builtin_amdgcn_readfirstlane(first); w0 = __builtin_amdgcn_readfirstlane(w0); wp = __builtin_amdgcn_readfirstlane(wp);
         if (first + nT > tileRegion || w0 + nFull > workRegion || wp + nPart > workRegion) { failed = true; return; }   // the host grows the regions and retries
         first += part * tileRegion; w0 += part * workRegion; wp += part * workRegion;
-        if (p.dbg & 2) return;
         for (int k = lane; k < count; k += 64) p.tileJ[(size_t)first * 32 + k] = list[k];
         // mask words: lanes 0..31 handle the rows of even tiles, lanes 32..63 of odd tiles; one allocation for all masked tiles of the chunk
         unsigned long long anyBits = 0ull;      // bit t = tile t has a non-zero mask
@@ -389,7 +387,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
             cmbStart[lane] = cStart; cmbPrefix[lane] = incl - cLen; cmbCode[lane] = cCode;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (int v0 = 0; v0 < ((p.dbg & 4) ? 0 : total) && !failed; v0 += 64) {
+            for (int v0 = 0; v0 < total && !failed; v0 += 64) {
                 const int v = v0 + lane;
                 bool ok = v < total;
                 int j = 0, code = 13;

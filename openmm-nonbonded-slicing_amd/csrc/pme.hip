@@ -195,7 +195,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
         }
         return;
     }
-    for (int base = 0; base < ((p.dbg & 64) ? 0 : total); base += NT) {
+    for (int base = 0; base < total; base += NT) {
         // phase 1: one thread per candidate atom; every x-line (atom, ix) of its 5x5 footprint that falls inside the brick becomes a list entry
         const int v = base + tid;
         int nEnt = 0, ixLo = 0, aSel = 0;
@@ -230,7 +230,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
         __syncthreads();                                                    // everyone has read the count before anyone appends again
         if (count <= LISTCAP - 5 * NT && base + NT < total) continue;      // room for another round of candidates (uniform branch)
         // phase 2: one thread per (atom, x-line): weights, then the line's 5x5 (y,z) points that fall inside the brick into LDS
-        for (int k = tid; k < ((p.dbg & 16) ? 0 : count); k += NT) {
+        for (int k = tid; k < count; k += NT) {
             const int e = list[k];
             const int a = e >> 3, ix = e & 7;
             const Real q = pmeCharge(p, a);
@@ -277,7 +277,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
                         const unsigned long long packed = ((unsigned long long)(unsigned)(hi[j] + (lo[j] >> 31)) << 32) | (unsigned)lo[j];
-                        if (zp[j] >= 0 && !(p.dbg & 8)) __hip_atomic_fetch_add(&line[zp[j] >> 1], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (zp[j] >= 0) __hip_atomic_fetch_add(&line[zp[j] >> 1], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             } else {
@@ -289,7 +289,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
                     Acc* line = plane + ly * sz;
 #pragma unroll
                     for (int iz = 0; iz < 5; iz++)
-                        if (zi[iz] >= 0 && !(p.dbg & 8)) __hip_atomic_fetch_add(&line[zi[iz]], (double)(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (zi[iz] >= 0) __hip_atomic_fetch_add(&line[zi[iz]], (double)(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
@@ -329,7 +329,6 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
         return;
     }
     Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
-    if (p.dbg & 32) return;
     const FastDiv dsz(sz), dcy(cy);
     for (int i = tid; i < npts; i += NT) {
         const int l = dsz.div(i), z = i - l * sz;
@@ -1018,86 +1017,11 @@ template <typename Real> __global__ __launch_bounds__(256) void k_interpolate(co
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Brick interpolation (unsharded production path on rectangular boxes): the mirror image of k_spreadBrick.
-// One work-group stages the (c_x+6) x (c_y+6) x nz neighbourhood of one column of ONE pre-mixed potential grid in LDS
-// with coalesced loads (halo: 4 stencil cells + 1 cell of drift on either side), then ONE THREAD PER ATOM of that
-// (subset, column) range evaluates its 125-point stencil out of LDS.  ~14 wave-instructions per atom instead of ~180
-// for the 32-lanes-per-atom gather kernel (which recomputes the B-splines 32 times and reduces by shuffles).
-// ---------------------------------------------------------------------------------------------------
-template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBrick(const PmeParams<Real> p) {
-    extern __shared__ __align__(16) unsigned char s_brick_raw[];
-    constexpr int NT = 1024, HALO_LO = 1, EXTRA = 6;
-    Real* brick = reinterpret_cast<Real*>(s_brick_raw);
-    const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
-    const int cx = p.groupX * (p.d.nx / ncx), cy = p.groupY * (p.d.ny / ncy);
-    const int nbx = ncx / p.groupX, nby = ncy / p.groupY;
-    const int ncol = ncx * ncy;
-    const int slot = blockIdx.x / (nbx * nby), bcol = blockIdx.x - slot * (nbx * nby);
-    const int Bx = bcol / nby, By = bcol - Bx * nby;
-    const int2* ranges = p.colRange + (size_t)p.gridSubset[slot] * ncol;
-    bool any = false;
-    for (int gx = 0; gx < p.groupX; gx++) for (int gy = 0; gy < p.groupY; gy++) { const int2 r0 = ranges[(Bx * p.groupX + gx) * ncy + By * p.groupY + gy]; any = any || (r0.y > r0.x); }
-    if (!any) return;                                         // no atom of this subset in the brick's columns
-    const int x0 = Bx * cx, y0 = By * cy;
-    const int bx = cx + EXTRA, by = cy + EXTRA;
-    const int tid = threadIdx.x;
-    const Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
-    const FastDiv dnz(nz), dby(by);
-    for (int i = tid; i < ((p.dbg & 16) ? 0 : bx * by * nz); i += NT) {
-        const int l = dnz.div(i), z = i - l * nz;
-        const int lx = dby.div(l), ly = l - lx * by;
-        int x = x0 + lx - HALO_LO; if (x < 0) x += p.d.nx; else if (x >= p.d.nx) x -= p.d.nx;
-        int y = y0 + ly - HALO_LO; if (y < 0) y += p.d.ny; else if (y >= p.d.ny) y -= p.d.ny;
-        brick[i] = g[((size_t)x * p.d.ny + y) * nz + z];
-    }
-    __syncthreads();
-    for (int gx = 0; gx < p.groupX; gx++) for (int gy = 0; gy < p.groupY; gy++) {
-    const int2 rg = ranges[(Bx * p.groupX + gx) * ncy + By * p.groupY + gy];
-    for (int a = rg.x + tid; a < ((p.dbg & 8) ? 0 : rg.y); a += NT) {
-        const Real q = pmeCharge(p, a);
-        const auto pos = p.posq[a];
-        int idx[3]; Real fr[3];
-        gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
-        int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
-        int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
-        Real tx[5], ty[5], tz[5], dx[5], dy[5], dz[5];
-        bspline5<Real>(fr[0], tx, dx); bspline5<Real>(fr[1], ty, dy); bspline5<Real>(fr[2], tz, dz);
-        int zi[5];
-#pragma unroll
-        for (int iz = 0; iz < 5; iz++) { int z = idx[2] + iz; zi[iz] = z >= nz ? z - nz : z; }
-        Real fx = 0, fy = 0, fz = 0;
-        const bool inBrick = rx >= -HALO_LO && rx + 4 < bx - HALO_LO && ry >= -HALO_LO && ry + 4 < by - HALO_LO;
-        if (q != Real(0)) {
-#pragma unroll
-            for (int ix = 0; ix < 5; ix++) {
-#pragma unroll
-                for (int iy = 0; iy < 5; iy++) {
-                    Real sz = 0, sdz = 0;
-                    if (inBrick) {
-                        const Real* line = brick + (size_t)((rx + HALO_LO + ix) * by + (ry + HALO_LO + iy)) * nz;
-#pragma unroll
-                        for (int iz = 0; iz < 5; iz++) { const Real gv = line[zi[iz]]; sz += tz[iz] * gv; sdz += dz[iz] * gv; }
-                    } else {   // drifted further than the halo since the last re-sort: correct but slow path through global memory
-                        int x = idx[0] + ix; if (x >= p.d.nx) x -= p.d.nx;
-                        int y = idx[1] + iy; if (y >= p.d.ny) y -= p.d.ny;
-                        const Real* line = g + ((size_t)x * p.d.ny + y) * nz;
-#pragma unroll
-                        for (int iz = 0; iz < 5; iz++) { const Real gv = line[zi[iz]]; sz += tz[iz] * gv; sdz += dz[iz] * gv; }
-                    }
-                    fx += dx[ix] * ty[iy] * sz; fy += tx[ix] * dy[iy] * sz; fz += tx[ix] * ty[iy] * sdz;
-                }
-            }
-        }
-        const Real nx = p.d.nx, ny = p.d.ny, nzr = p.d.nz;
-        const Real gx_ = -q * (fx * nx * p.recip[0]);
-        const Real gy_ = -q * (fx * nx * p.recip[3] + fy * ny * p.recip[4]);
-        const Real gz_ = -q * (fx * nx * p.recip[6] + fy * ny * p.recip[7] + fz * nzr * p.recip[8]);
-        if (p.dispersion) { p.fpx[a] += gx_; p.fpy[a] += gy_; p.fpz[a] += gz_; }   // second (dispersion) pipeline of LJPME adds
-        else { p.fpx[a] = gx_; p.fpy[a] = gy_; p.fpz[a] = gz_; }
-    }
-    }
-}
-
+// Brick interpolation: the mirror image of k_spreadBrick.  One work-group stages the (c_x+6) x (c_y+6) x nz neighbourhood of one
+// column brick of a potential grid in LDS with coalesced loads (halo: 4 stencil cells + 1 cell of drift on either side), then ONE
+// THREAD PER ATOM evaluates its 125-point stencil out of LDS (~14 wave-instructions per atom instead of ~180 for the 32-lanes-per-atom
+// gather kernel k_interpolate, which recomputes the B-splines 32 times and reduces by shuffles).
+//
 // Sharded engines (mix == 0): a rank holds the UNMIXED potential grids of its own subsets and every atom needs
 // sum_J lambda[slice(s_i, J)] * (gradient of grid J).  One work-group per column brick loops over the held grids: stage the brick of
 // grid J, then one thread per atom of ANY subset in the brick's columns adds lambda * gradient into the atom's reciprocal force
@@ -1106,7 +1030,7 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
 // cost ~80 us per held grid at 300k atoms.
 // (occupancy note: ~100 VGPRs => one 1024-thread work-group per CU, 400 bricks = two rounds of ~20 us on c3; forcing 64 VGPRs spills
 // and measures 71 us, 512-thread groups 56 us, z slabs 70 us -- this shape, 52 us, is the best of those)
-template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBrickSharded(const PmeParams<Real> p, const int zSlabs) {
+template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBricks(const PmeParams<Real> p, const int zSlabs) {
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
     constexpr int NT = 1024, HALO_LO = 1, EXTRA = 6;
     const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
@@ -1236,11 +1160,11 @@ template <typename Real> static void launchInterpolateBricks(const PmeParams<Rea
         if (zsEnv > 0 && p.d.nz % zsEnv == 0 && p.d.nz / zsEnv >= 8) zSlabs = zsEnv;
         const int bz = zSlabs == 1 ? p.d.nz : p.d.nz / zSlabs + 4;
         const size_t lds = ((sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * bz + 15) & ~(size_t)15) + sizeof(double) * p.nsubTotal * (p.nsubTotal + 1);
-        static const bool noBrick = getenv("SNB_NO_SHARDED_BRICK") != nullptr;
+        static const bool noBrick = getenv("SNB_NO_INTERP_BRICKS") != nullptr;   // testing aid: force the 32-lanes-per-atom kernel
         if (lds <= 150 * 1024 && !noBrick && p.nsubTotal * p.groupX * p.groupY <= 256) {
             const int nblocks = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * zSlabs;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBrickSharded<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_interpolateBrickSharded<Real>), dim3(nblocks), dim3(1024), lds, s, p, zSlabs);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBricks<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_interpolateBricks<Real>), dim3(nblocks), dim3(1024), lds, s, p, zSlabs);
             return;
         }
     }
@@ -1250,18 +1174,6 @@ template <typename Real> static void launchInterpolateBricks(const PmeParams<Rea
 
 template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s) {
     if (p.natoms <= 0) return;
-    static const bool oldMixBrick = getenv("SNB_OLD_INTERP_BRICK") != nullptr;
-    if (oldMixBrick && p.mix && p.sortNcx > 0 && p.colRange != nullptr) {
-        const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
-        const size_t lds = sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * p.d.nz;
-        if (lds <= 150 * 1024) {
-            // padding atoms and atoms of empty columns are never visited: the engine clears all force views once per step
-            const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBrick<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_interpolateBrick<Real>), dim3(nblocks), dim3(1024), lds, s, p);
-            return;
-        }
-    }
     if (p.sortNcx > 0 && p.colRange != nullptr) {
         // The kernel needs ~100 VGPRs, so one 1024-thread work-group occupies a CU: with more bricks than CUs the launch runs in rounds.
         // Wider bricks (2 x 1, 2 x 2 columns) cut the count below the CU count and the halo overhead with it, as long as LDS allows.

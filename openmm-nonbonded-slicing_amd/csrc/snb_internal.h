@@ -51,7 +51,6 @@ template <typename Real> struct DirectParams {
     int nsub;
     Real cutoff2, krf, crf, alpha, alphaD, k4pe;          // k4pe = ONE_4PI_EPS0
     Real alpha2l2e;                                        // alpha^2 * log2(e)
-    int dbg;                   // SNB_DBG experiment bits (1: no j-force flush, 2: no pair arithmetic, 4: ignore masks) - timing decomposition only
     Real ewPoly[12]; Real ewScale; int ewUsePoly;         // single-precision forces-only path: Bt(r^2) ~ sum_k ewPoly[k] t^k, t = r^2 * ewScale - 1 (engine.hip buildEwaldPoly)
     Real invCut6, multShift6;                              // LJPME potential shifts
     int useSwitch; Real switchDist, invSwitchWidth;
@@ -116,7 +115,6 @@ template <typename Real> struct PmeParams {
     int wantEnergy;
     int sortNcx, sortNcy;      // brick kernels: number of sort columns (0 = use the atomic / gather fallbacks)
     int groupX, groupY;        // sort columns per brick (brick = group * nx/sortNcx cells, at least 5)
-    int dbg;                   // SNB_DBG experiment bits (timing decomposition only)
     int zSlabs;                // bricks are also cut into this many slabs along z (nz % zSlabs == 0)
     const int2* colRange;      // [nsubTotal][ncx*ncy] sorted-atom range of every (subset, xy column)
 };
@@ -160,7 +158,6 @@ template <typename Real> struct NbParams {
                      // [6] max work items of a partition), lines 1..64 = the partitions' allocation counters (same slots)
     int tileCapacity, workCapacity, maskCapacity;
     int shardRank, shardCount;   // tiles and work items are built only for i-blocks with block % shardCount == shardRank
-    int dbg;         // SNB_DBG experiment bits (timing decomposition only)
     long long* dbgOut;   // SNB_NB_TRACE: per-block start/end wall_clock64 stamps (100 MHz) of the tile builder
 };
 template <typename Real> size_t nbSortTempBytes(int n);
