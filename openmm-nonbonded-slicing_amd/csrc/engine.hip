@@ -215,6 +215,7 @@ public:
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
+    bool valuesDirty = false, excValuesDirty = false, haveExceptions = false;   // parameter values changed, structure did not
     std::vector<int3> hKvec; DevBuf<int3> dKvec; DevBuf<Real> dCosSin;
     struct GraphKey {
         const void* pos; int isDouble, stride4; bool direct, recip; void* out; int outDouble, outAcc;
@@ -304,9 +305,10 @@ public:
     bool isPeriodic() const { return cfg.method >= SNB_CutoffPeriodic; }
 
     void setParticles(const double* q, const double* sg, const double* ep, const int32_t* sub) override {
+        bool subsetsChanged = !haveParticles;
         for (int i = 0; i < N; i++) {
             if (sub[i] < 0 || sub[i] >= nsub) throw HipError{"subset out of range"};
-            if (subset[i] != sub[i] || sigma[i] != sg[i] || epsilon[i] != ep[i]) needRebuild = true;   // subsets change the sort; sigma/eps ride along
+            if (subset[i] != sub[i]) subsetsChanged = true;      // subsets decide the sorted order and the block layout
         }
         charge.assign(q, q + N); sigma.assign(sg, sg + N); epsilon.assign(ep, ep + N); subset.assign(sub, sub + N);
         maxAbsQ = 0; maxAbsC6 = 0;   // bounds for the fixed-point LDS accumulation of the single-precision brick spreader
@@ -315,16 +317,20 @@ public:
             const double hs = 0.5 * sg[i];
             maxAbsC6 = std::max(maxAbsC6, std::fabs(8.0 * hs * hs * hs * 2.0 * std::sqrt(ep[i])));
         }
-        haveParticles = true; paramsDirty = true; staticDirty = true;
+        haveParticles = true;
+        // new charges / sigmas / epsilons alone (parameter offsets, updateParametersInContext) do not touch the neighbour structure:
+        // they are refreshed in place (refreshValues) instead of going through a rebuild
+        if (subsetsChanged) { needRebuild = true; paramsDirty = true; staticDirty = true; } else valuesDirty = true;
     }
     void setExceptions(int32_t m, const int32_t* pairs, const double* qq, const double* sg, const double* ep, const int32_t* f14) override {
         for (int k = 0; k < m; k++)
             if (pairs[2 * k] < 0 || pairs[2 * k] >= N || pairs[2 * k + 1] < 0 || pairs[2 * k + 1] >= N || pairs[2 * k] == pairs[2 * k + 1]) throw HipError{"exception particle index out of range"};
         std::vector<int32_t> np(pairs, pairs + 2 * (size_t)m);
-        if (np != excPairs) needRebuild = true;   // the exclusion masks live in the tiles
+        const bool pairsChanged = !haveExceptions || np != excPairs;      // the exclusion masks live in the tiles
         excPairs.swap(np); excQQ.assign(qq, qq + m); excSigma.assign(sg, sg + m); excEps.assign(ep, ep + m);
         if (f14) excForce14.assign(f14, f14 + m); else excForce14.assign(m, 0);
-        paramsDirty = true; staticDirty = true;
+        haveExceptions = true;
+        if (pairsChanged) { needRebuild = true; paramsDirty = true; staticDirty = true; } else excValuesDirty = true;
     }
     void setLambdas(const double* l) override {
         lambdas.assign(l, l + (size_t)S * 2);
@@ -667,11 +673,11 @@ public:
 
     // Static (sort-independent) device data: 1-4 list and exclusion CSR in USER indices (Q6:
     // ReferenceNonbondedSlicingKernels.cpp:99-112, 129-131), per-atom parameters in user order, the padded subset layout.
-    void uploadStatic() {
+    // 1-4 list (exceptions with non-zero parameters, Q6) in user order: pairs + (sigma, 4 eps, k qq, slice)
+    void upload14() {
         const size_t m = excPairs.size() / 2;
         std::vector<int2> p14; std::vector<T4> q14;
         auto sl = [](int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
-        std::vector<int> hStart((size_t)N + 1, 0), hList(2 * m);
         for (size_t k = 0; k < m; k++) {
             const int a = excPairs[2 * k], b = excPairs[2 * k + 1];
             if (excQQ[k] != 0.0 || excEps[k] != 0.0 || excForce14[k]) {
@@ -679,18 +685,45 @@ public:
                 T4 v; v.x = (Real)excSigma[k]; v.y = (Real)(4.0 * excEps[k]); v.z = (Real)(SNB_ONE_4PI_EPS0 * excQQ[k]); v.w = (Real)sl(subset[a], subset[b]);
                 q14.push_back(v);
             }
-            hStart[a + 1]++; hStart[b + 1]++;
         }
-        for (int i = 0; i < N; i++) hStart[i + 1] += hStart[i];
-        { std::vector<int> fill(N, 0); for (size_t k = 0; k < m; k++) { const int a = excPairs[2 * k], b = excPairs[2 * k + 1]; hList[hStart[a] + fill[a]++] = b; hList[hStart[b] + fill[b]++] = a; } }
         n14 = (int)p14.size(); nExcl = (int)m;
         pairs14.upload(p14, stream); params14.upload(q14, stream);
-        exclStart.upload(hStart, stream); exclList.upload(hList, stream);
         stats.n_14 = n14; stats.n_exclusions = nExcl;
-        // user-order parameters
+    }
+    void uploadParticleValues() {
         std::vector<Real> hq(N); std::vector<T2> hse(N);
         for (int i = 0; i < N; i++) { hq[i] = (Real)charge[i]; hse[i].x = (Real)(0.5 * sigma[i]); hse[i].y = (Real)(2.0 * std::sqrt(epsilon[i])); }
-        dUCharge.upload(hq, stream); dUSigEps.upload(hse, stream); dUSubset.upload(std::vector<int>(subset.begin(), subset.end()), stream);
+        dUCharge.upload(hq, stream); dUSigEps.upload(hse, stream);
+    }
+    // New parameter VALUES with the same subsets / exception pairs (copyParametersToContext, parameter offsets: the reference recomputes
+    // them on the device per changed global parameter, nonbondedParameters.cc:4-179): the sorted per-atom arrays are rewritten in place
+    // from the user-order values -- no re-sort, no tile rebuild.  The captured step graph is dropped because kernel arguments derived
+    // from the values (number of 1-4 pairs, fixed-point scale of the spreader) are baked into it.
+    void refreshValues() {
+        if (excValuesDirty) upload14();
+        if (valuesDirty) {
+            uploadParticleValues();
+            launchRefreshParams<Real>(dSortedToUser.p, dUCharge.p, dUSigEps.p, posq.p, sigeps.p, Npad, stream);
+        }
+        HIPCHECK(hipStreamSynchronize(stream));      // the host staging vectors above go out of scope
+        dropGraph();
+        valuesDirty = excValuesDirty = false;
+    }
+
+    void uploadStatic() {
+        const size_t m = excPairs.size() / 2;
+        std::vector<int> hStart((size_t)N + 1, 0), hList(2 * m);
+        for (size_t k = 0; k < m; k++) {
+            const int a = excPairs[2 * k], b = excPairs[2 * k + 1];
+            hStart[a + 1]++; hStart[b + 1]++;
+        }
+        upload14();
+        for (int i = 0; i < N; i++) hStart[i + 1] += hStart[i];
+        { std::vector<int> fill(N, 0); for (size_t k = 0; k < m; k++) { const int a = excPairs[2 * k], b = excPairs[2 * k + 1]; hList[hStart[a] + fill[a]++] = b; hList[hStart[b] + fill[b]++] = a; } }
+        exclStart.upload(hStart, stream); exclList.upload(hList, stream);
+        // user-order parameters
+        uploadParticleValues();
+        dUSubset.upload(std::vector<int>(subset.begin(), subset.end()), stream);
         // padded subset layout (depends on subset populations only)
         std::vector<int> cnt(nsub, 0);
         for (int i = 0; i < N; i++) cnt[subset[i]]++;
@@ -880,7 +913,9 @@ public:
             if (box[3] != 0 || box[6] != 0 || box[7] != 0) { err = "SlicedNonbondedForce: Ewald is not supported with non-rectangular boxes.  Use PME instead."; throw (int)SNB_ERR_UNSUPPORTED; }
         }
         if (dLambdas.p == nullptr) setLambdas(lambdas.data());
-        if (needRebuild || paramsDirty || cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval || cfg.neighbor_padding <= 0) rebuild();
+        const bool rebuilding = needRebuild || paramsDirty || cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval || cfg.neighbor_padding <= 0;
+        if ((valuesDirty || excValuesDirty) && !staticDirty && !rebuilding) refreshValues();
+        if (rebuilding) { if (valuesDirty || excValuesDirty) { staticDirty = true; valuesDirty = excValuesDirty = false; } rebuild(); }
         stepsSinceRebuild++;
         outputWritten = outPtr != nullptr;
         const bool energy = includeEnergy != 0;

@@ -45,6 +45,26 @@ void launchGatherPositions(const void* userPos, int isDouble, int stride4, const
     else hipLaunchKernelGGL((k_gatherPositions<Real, float>), grid, block, 0, s, (const float*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, gc);
 }
 
+// In-place refresh of the sorted per-atom parameters from the user-order values (parameter offsets / updateParametersInContext)
+template <typename Real>
+__global__ void k_refreshParams(const int* __restrict__ sortedToUser, const Real* __restrict__ uCharge, const typename Vec<Real>::T2* __restrict__ uSigEps,
+                                typename Vec<Real>::T4* __restrict__ posq, typename Vec<Real>::T2* __restrict__ sigeps, int nPadded) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nPadded) return;
+    const int u = sortedToUser[s];
+    if (u < 0) return;
+    posq[s].w = uCharge[u];
+    sigeps[s] = uSigEps[u];
+}
+template <typename Real>
+void launchRefreshParams(const int* sortedToUser, const Real* uCharge, const typename Vec<Real>::T2* uSigEps, typename Vec<Real>::T4* posq,
+                         typename Vec<Real>::T2* sigeps, int nPadded, hipStream_t s) {
+    if (nPadded <= 0) return;
+    hipLaunchKernelGGL((k_refreshParams<Real>), dim3((nPadded + 255) / 256), dim3(256), 0, s, sortedToUser, uCharge, uSigEps, posq, sigeps, nPadded);
+}
+template void launchRefreshParams<float>(const int*, const float*, const Vec<float>::T2*, Vec<float>::T4*, Vec<float>::T2*, int, hipStream_t);
+template void launchRefreshParams<double>(const int*, const double*, const Vec<double>::T2*, Vec<double>::T4*, Vec<double>::T2*, int, hipStream_t);
+
 template <typename Real, typename Out>
 __global__ void k_finishForces(const Real* __restrict__ fx, const Real* __restrict__ fy, const Real* __restrict__ fz,
                                const Real* __restrict__ fpx, const Real* __restrict__ fpy, const Real* __restrict__ fpz,

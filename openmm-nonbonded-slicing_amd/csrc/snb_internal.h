@@ -193,6 +193,8 @@ template <typename Real> struct GatherCells { Real recip[9]; int nx, ny, nz; int
 
 template <typename Real> void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
                                                     typename Vec<Real>::T4* posq, int nPadded, Real* forces, const GatherCells<Real>& gc, hipStream_t s);
+template <typename Real> void launchRefreshParams(const int* sortedToUser, const Real* uCharge, const typename Vec<Real>::T2* uSigEps, typename Vec<Real>::T4* posq,
+                                                  typename Vec<Real>::T2* sigeps, int nPadded, hipStream_t s);
 template <typename Real> void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, const Real* fpx, const Real* fpy, const Real* fpz,
                                                  const int* userToSorted, int nAtoms, void* out, int isDouble, int accumulate, hipStream_t s);
 

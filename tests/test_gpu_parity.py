@@ -235,6 +235,43 @@ def test_force_output_inside_the_step_graph(snb):
     ref.close(); eng.close()
 
 
+def test_parameter_update_without_rebuild(snb, F, oev, prec):
+    """updateParametersInContext with new charges / sigmas / epsilons / exception parameters but the same subsets and exception
+    pairs (the alchemical use of the reference's copyParametersToContext, CommonNonbondedSlicingKernels.cpp:1404-1568) must give the
+    oracle's answer for the new parameters WITHOUT re-sorting atoms or rebuilding tiles."""
+    n, L = 13824, 6.0
+    force, pos, box = systems.random_box(F, n, 3, 4, L, 1.0, pme=(2.6283, 48, 48, 48))
+    system = snb.System()
+    for _ in range(n):
+        system.addParticle(1.0)
+    system.setDefaultPeriodicBoxVectors(*box)
+    system.addForce(force)
+    ctx = snb.Context(system, precision=prec, neighbor_padding=0.1, rebuild_interval=1000)
+    ctx.setPositions(pos)
+    ctx.getState(getEnergy=True, getForces=True)
+    kern = ctx._kernelFor(force)
+    rebuilds = kern.getStats().n_rebuilds
+    rng = np.random.default_rng(11)
+    for i in range(0, n, 3):
+        q, sg, ep = force.getParticleParameters(i)
+        force.setParticleParameters(i, q * 0.5 + 0.01, sg * 1.05, ep * 0.7)
+    for k in range(0, force.getNumExceptions(), 5):
+        a, b, qq, sg, ep = force.getExceptionParameters(k)
+        if qq != 0.0 or ep != 0.0:
+            force.setExceptionParameters(k, a, b, qq * 0.3, sg, ep * 1.5)
+    force.updateParametersInContext(ctx)
+    st = ctx.getState(getEnergy=True, getForces=True, getParameterDerivatives=True)
+    o = oev(force, pos, box)
+    tol = TOLS[prec]
+    K.assertEqualTo(o["energy"], st.getPotentialEnergy(), tol)
+    fo, fr = o["forces"], st.getForces()
+    err = np.linalg.norm(fo - fr, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)
+    assert err.max() <= tol, err.max()
+    for name, v in o["derivatives"].items():
+        K.assertEqualTo(v, st.getEnergyParameterDerivatives()[name], tol)
+    assert kern.getStats().n_rebuilds == rebuilds, "parameter values alone must not trigger a neighbour rebuild"
+
+
 def test_padding_and_rebuild_interval(snb, F, oev):
     """Tiles built with a skin and reused across steps must give the same answer as a fresh list."""
     force, pos, box = systems.random_box(F, 4096, 2, 4, 3.5, 1.0, pme=(2.6283, 32, 32, 32))
