@@ -39,11 +39,25 @@ class _ScalingParameterInfo:
             (self.includeCoulomb and info.includeCoulomb) or (self.includeLJ and info.includeLJ))
 
 
+def _value(x):
+    """Plain float of a number or of an openmm.unit.Quantity (md unit system: nm, kJ/mol, e)."""
+    if hasattr(x, "value_in_unit_system"):
+        import openmm.unit as _u   # only reached when the source force came from OpenMM itself
+        return float(x.value_in_unit_system(_u.md_unit_system))
+    return float(x)
+
+
 class SlicedNonbondedForce:
     # NonbondedSlicingKernels.h:29-36
     NoCutoff, CutoffNonPeriodic, CutoffPeriodic, Ewald, PME, LJPME = range(6)
 
-    def __init__(self, numSubsets: int):
+    def __init__(self, numSubsets, numSubsetsForCopy=None):
+        """SlicedNonbondedForce(numSubsets), or SlicedNonbondedForce(force, numSubsets): a copy of `force` -- any object with
+        OpenMM's NonbondedForce getters, e.g. an openmm.NonbondedForce or another SlicedNonbondedForce -- with every particle in
+        subset 0 (openmmapi/src/SlicedNonbondedForce.cpp:34-82)."""
+        source = None
+        if numSubsetsForCopy is not None:
+            source, numSubsets = numSubsets, numSubsetsForCopy
         self.numSubsets = int(numSubsets)
         self._particles = []          # [charge, sigma, epsilon]
         self._exceptions = []         # [p1, p2, chargeProd, sigma, epsilon]
@@ -68,8 +82,42 @@ class SlicedNonbondedForce:
         self._forceGroup = 0
         self._recipForceGroup = -1
         self.useCuFFT = True  # kept for surface compatibility; meaningless here
+        if source is not None:
+            self._copyFrom(source)
 
     # ---- NonbondedForce surface -------------------------------------------------------------
+    def _copyFrom(self, force):
+        # same order of calls as the reference's converting constructor (SlicedNonbondedForce.cpp:37-81)
+        self.setForceGroup(force.getForceGroup())
+        self.setNonbondedMethod(int(force.getNonbondedMethod()))
+        self.setCutoffDistance(_value(force.getCutoffDistance()))
+        self.setUseSwitchingFunction(force.getUseSwitchingFunction())
+        self.setSwitchingDistance(_value(force.getSwitchingDistance()))
+        self.setEwaldErrorTolerance(force.getEwaldErrorTolerance())
+        self.setReactionFieldDielectric(force.getReactionFieldDielectric())
+        self.setUseDispersionCorrection(force.getUseDispersionCorrection())
+        self.setIncludeDirectSpace(force.getIncludeDirectSpace())
+        a, nx, ny, nz = force.getPMEParameters()
+        self.setPMEParameters(_value(a), nx, ny, nz)
+        a, nx, ny, nz = force.getLJPMEParameters()
+        self.setLJPMEParameters(_value(a), nx, ny, nz)
+        self.setReciprocalSpaceForceGroup(force.getReciprocalSpaceForceGroup())
+        for i in range(force.getNumParticles()):
+            q, sg, ep = force.getParticleParameters(i)
+            self.addParticle(_value(q), _value(sg), _value(ep))
+        for i in range(force.getNumExceptions()):
+            p1, p2, qq, sg, ep = force.getExceptionParameters(i)
+            self.addException(p1, p2, _value(qq), _value(sg), _value(ep))
+        self.setExceptionsUsePeriodicBoundaryConditions(force.getExceptionsUsePeriodicBoundaryConditions())
+        for i in range(force.getNumGlobalParameters()):
+            self.addGlobalParameter(force.getGlobalParameterName(i), force.getGlobalParameterDefaultValue(i))
+        for i in range(force.getNumParticleParameterOffsets()):
+            name, idx, dq, dsg, dep = force.getParticleParameterOffset(i)
+            self.addParticleParameterOffset(name, idx, dq, dsg, dep)
+        for i in range(force.getNumExceptionParameterOffsets()):
+            name, idx, dqq, dsg, dep = force.getExceptionParameterOffset(i)
+            self.addExceptionParameterOffset(name, idx, dqq, dsg, dep)
+
     def getNumParticles(self): return len(self._particles)
     def getNumExceptions(self): return len(self._exceptions)
     def getNumGlobalParameters(self): return len(self._globalParams)

@@ -111,8 +111,8 @@ def evaluate(force, positions, box=None, parameters=None, include_direct=True, i
     ``pme`` = (alpha, nx, ny, nz) overrides the force's own PME parameters (which must be explicit:
     auto-selection belongs to OpenMM's NonbondedForceImpl::calcPMEParameters, third-party, a13)."""
     L = lib()
-    if parameters is None:
-        parameters = default_parameters(force)
+    # a Context starts from the force's default parameter values; `parameters` overrides some of them (Context::setParameter)
+    parameters = dict(default_parameters(force), **(parameters or {}))
     r = resolve(force, parameters)
     pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
     assert pos.shape[0] == r["n"]
@@ -163,8 +163,8 @@ def evaluate(force, positions, box=None, parameters=None, include_direct=True, i
 
 
 def dispersion_coefficients(force, parameters=None):
-    if parameters is None:
-        parameters = default_parameters(force)
+    # a Context starts from the force's default parameter values; `parameters` overrides some of them (Context::setParameter)
+    parameters = dict(default_parameters(force), **(parameters or {}))
     r = resolve(force, parameters)
     out = np.zeros(r["S"])
     lib().orc_dispersion_coefficients(r["n"], r["ns"], _dp(r["sigma"]), _dp(r["epsilon"]), _ip(r["subset"]), force.getCutoffDistance(),

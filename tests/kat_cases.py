@@ -529,3 +529,148 @@ def testNonbondedSlicing(ev, F, method, exceptions, lj, tol=TOL, pme=None, ljpme
     assertEqualTo(r["energy"], total, tol)
     # sum of all slices at lambda=1 equals the unsliced energy
     assertEqualTo(results[1.0][0]["energy"], float(results[1.0][1]["slice_energies"].sum()), tol)
+
+
+# --- :29-85  testInstantiateFromNonbondedForce ----------------------------------------------------------------------------------
+# The reference builds an OpenMM NonbondedForce, converts it with SlicedNonbondedForce(force, 1) and requires both to agree
+# (direct and reciprocal groups, before and after context.setParameter("p1", 1)).  OpenMM's NonbondedForce is not available here,
+# so the source object is a plain 1-subset force filled through the same setters (the converting constructor only uses
+# NonbondedForce's getters), and `ev` evaluates source and copy.
+def testInstantiateFromNonbondedForce(ev, F, method, pme=None, tol=TOL):
+    force = F(1)
+    force.setCutoffDistance(2.0)
+    force.setNonbondedMethod(method)
+    force.addParticle(0.0, 1.0, 0.5)
+    force.addParticle(1.0, 0.5, 0.6)
+    force.addParticle(-1.0, 2.0, 0.7)
+    force.addParticle(0.5, 2.0, 0.8)
+    force.addParticle(-0.5, 2.0, 0.8)
+    force.addException(0, 3, 0.0, 1.0, 0.0)
+    force.addException(2, 3, 0.5, 1.0, 1.5)
+    force.addException(0, 1, 1.0, 1.5, 1.0)
+    force.addGlobalParameter("p1", 0.5)
+    force.addGlobalParameter("p2", 1.0)
+    force.addParticleParameterOffset("p1", 0, -2.0, 0.5, 0.5)
+    force.addParticleParameterOffset("p2", 1, 1.0, 1.0, 2.0)
+    force.addExceptionParameterOffset("p1", 1, 0.5, 0.5, 1.5)
+    if pme is not None:
+        force.setPMEParameters(*pme)
+        force.setLJPMEParameters(*pme)
+    sliced = F(force, 1)
+    assert sliced.getNumSubsets() == 1 and sliced.getNumParticles() == 5 and sliced.getNumExceptions() == 3
+    assert sliced.getNumParticleParameterOffsets() == 2 and sliced.getNumExceptionParameterOffsets() == 1
+    assert sliced.getNonbondedMethod() == method and sliced.getCutoffDistance() == 2.0
+    N = 5
+    box = cubic(float(N))
+    positions = [[i, 0, 0] for i in range(N)]
+    periodic = method >= 2
+    for params in (None, {"p1": 1.0}):
+        for dirflag, recflag in ((True, False), (False, True)) if method >= 3 else ((True, True),):
+            r1 = ev(force, positions, box if periodic else None, params, dirflag, recflag)
+            r2 = ev(sliced, positions, box if periodic else None, params, dirflag, recflag)
+            assertEqualTo(r1["energy"], r2["energy"], tol)
+            assertForces(r1["forces"], r2["forces"], tol)
+
+
+# --- :494-555 testLargeSystem: geometry generator (the comparison partner is the oracle, see the test files) -------------------------
+def largeSystem(F, method, seed=0):
+    numMolecules = 600; cutoff = 2.0; boxSize = 20.0
+    rng = np.random.default_rng(seed)
+    f = F(1)
+    positions = np.zeros((2 * numMolecules, 3))
+    for i in range(numMolecules):
+        eps = 0.1 if i < numMolecules // 2 else 0.2
+        f.addParticle(-1.0, 0.2, eps); f.addParticle(1.0, 0.1, eps)
+        positions[2 * i] = boxSize * rng.random(3)
+        positions[2 * i + 1] = positions[2 * i] + [1.0, 0.0, 0.0]
+        f.addException(2 * i, 2 * i + 1, 0.0, 0.15, 0.0)
+    f.setNonbondedMethod(method)
+    f.setCutoffDistance(cutoff)
+    return f, positions, cubic(boxSize)
+
+
+# --- :557-612 testHugeSystem: energy change along the force direction (size-independent property; gridSize 150 = 3.4 M particles) -------
+def testHugeSystem(evEnergy, evForces, F, gridSize=150, tol=1e-4, seed=0, scaledDown=False):
+    spacing = 0.3; boxSize = gridSize * spacing
+    force = F(1)
+    force.setNonbondedMethod(F.CutoffPeriodic)
+    force.setCutoffDistance(1.0)
+    force.setUseSwitchingFunction(True)
+    force.setSwitchingDistance(0.9)
+    rng = np.random.default_rng(seed)
+    g = np.stack(np.meshgrid(np.arange(gridSize), np.arange(gridSize), np.arange(gridSize), indexing="ij"), -1).reshape(-1, 3)
+    positions = g * spacing + rng.random(g.shape) * 0.1
+    force.addParticles(np.zeros(len(g)), np.full(len(g), 0.1), np.ones(len(g))) if hasattr(force, "addParticles") else [force.addParticle(0.0, 0.1, 1.0) for _ in range(len(g))]
+    box = cubic(boxSize)
+    f = np.asarray(evForces(force, positions, box))
+    norm = math.sqrt(float((f * f).sum()))
+    delta = 0.3
+    if scaledDown:      # smaller grids: keep the per-atom displacement of the 150^3 original (|F| grows like sqrt(N)) ...
+        delta *= math.sqrt(len(g) / 150.0 ** 3)
+    step = 0.5 * delta / norm
+    e2 = evEnergy(force, positions - f * step, box)
+    e3 = evEnergy(force, positions + f * step, box)
+    if scaledDown:      # ... and test the energy DIFFERENCE itself, which is then small against |E|
+        assert abs((e2 - e3) - norm * delta) <= 20 * tol * norm * delta, (e2 - e3, norm * delta)
+    else:
+        assertEqualTo(e2, e3 + norm * delta, tol)
+
+
+# --- :1320-1457 testScalingParameterSeparation -------------------------------------------------------------------------------------
+def testScalingParameterSeparation(ev, F, method, exceptions, pme=None, ljpme=None, tol=1e-4, seed=0):
+    numMolecules = 100; numParticles = 200; cutoff = 3.5
+    L = 7.0 if exceptions else 10.0
+    box = cubic(L)
+    positions = dimer_lattice(numMolecules, L)
+    q = lambda k: 1 - 2 * (k % 2)
+
+    def base(n):
+        f = F(n)
+        f.setNonbondedMethod(method); f.setCutoffDistance(cutoff); f.setUseDispersionCorrection(True)
+        if pme is not None:
+            f.setPMEParameters(*pme)
+        if ljpme is not None:
+            f.setLJPMEParameters(*ljpme)
+        for k in range(numMolecules):
+            i, j = 2 * k, 2 * k + 1
+            f.addParticle(q(i), 1, 1); f.addParticle(q(j), 1, 1)
+            if exceptions:
+                f.addException(i, j, q(i) * q(j), 1, 1)
+        return f
+
+    sliced1, sliced2 = base(2), base(2)
+    rng = np.random.default_rng(seed)
+    for k in range(numParticles):
+        if rng.random() < 0.5:
+            sliced1.setParticleSubset(k, 1); sliced2.setParticleSubset(k, 1)
+    lam, value = 0.5, 0.3
+    sliced1.addGlobalParameter("lambda", lam)
+    sliced1.addScalingParameter("lambda", 0, 1, True, True)
+    sliced1.addEnergyParameterDerivative("lambda")
+    sliced2.addGlobalParameter("lambdaCoulomb", lam)
+    sliced2.addGlobalParameter("lambdaLJ", lam)
+    sliced2.addScalingParameter("lambdaCoulomb", 0, 1, True, False)
+    sliced2.addScalingParameter("lambdaLJ", 0, 1, False, True)
+    sliced2.addEnergyParameterDerivative("lambdaCoulomb")
+    sliced2.addEnergyParameterDerivative("lambdaLJ")
+    sliced1.addGlobalParameter("alpha", value)
+    sliced1.addScalingParameter("alpha", 0, 0, True, True)
+    sliced1.addEnergyParameterDerivative("alpha")
+    sliced1.addGlobalParameter("beta", value)
+    sliced1.addScalingParameter("beta", 1, 1, True, True)
+    sliced1.addEnergyParameterDerivative("beta")
+    sliced2.addGlobalParameter("gamma", value)
+    sliced2.addScalingParameter("gamma", 0, 0, True, True)
+    sliced2.addScalingParameter("gamma", 1, 1, True, True)
+    sliced2.addEnergyParameterDerivative("gamma")
+    periodic = method >= 2
+    groups = ((True, True), (True, False), (False, True)) if method >= 3 else ((True, True),)
+    for dirflag, recflag in groups:       # overall, direct space, reciprocal space
+        r1 = ev(sliced1, positions, box if periodic else None, None, dirflag, recflag)
+        r2 = ev(sliced2, positions, box if periodic else None, None, dirflag, recflag)
+        d1, d2 = r1["derivatives"], r2["derivatives"]
+        assertEqualTo(r1["energy"], r2["energy"], tol)
+        assertForces(r1["forces"], r2["forces"], tol)
+        assertEqualTo(d1["lambda"], d2["lambdaCoulomb"] + d2["lambdaLJ"], tol)
+        assertEqualTo(r1["energy"], lam * d1["lambda"] + value * (d1["alpha"] + d1["beta"]), tol)
+        assertEqualTo(d1["alpha"] + d1["beta"], d2["gamma"], tol)

@@ -235,6 +235,53 @@ def test_force_output_inside_the_step_graph(snb):
     ref.close(); eng.close()
 
 
+@pytest.mark.parametrize("method", [0, 1, 2, 4, 5])
+def test_instantiate_from_nonbonded_force(method, snb, F, prec):
+    K.testInstantiateFromNonbondedForce(make_ev(snb, prec), F, method, pme=(1.0, 20, 20, 20) if method >= 4 else None, tol=1e-3 if prec == "single" else K.TOL)
+
+
+@pytest.mark.parametrize("method", [2, 4, 5])
+@pytest.mark.parametrize("exceptions", [False, True])
+def test_scaling_parameter_separation(method, exceptions, snb, F, prec):
+    n = 28 if exceptions else 40
+    K.testScalingParameterSeparation(make_ev(snb, prec), F, method, exceptions, pme=(1.0, n, n, n) if method >= 4 else None,
+                                     ljpme=(1.0, n, n, n) if method == 5 else None, tol=1e-3 if prec == "single" else 1e-4)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_large_system_vs_oracle(method, snb, F, oev, prec):
+    """testLargeSystem (TestSlicedNonbondedForce.h:494-555): 600 bonded dimers at random positions in a 20 nm box, cutoff 2 nm; the
+    reference compares its platform with OpenMM's NonbondedForce, here the comparison partner is the oracle."""
+    force, pos, box = K.largeSystem(F, method)
+    _compare(make_ev(snb, prec), oev, force, pos, box if method == 2 else None, TOLS[prec])
+
+
+def test_huge_system_energy_follows_forces(snb, F, prec):
+    """testHugeSystem (TestSlicedNonbondedForce.h:557-612) at its full size: 150^3 = 3 375 000 particles, CutoffPeriodic with a
+    switching function; stepping along the force direction must change the energy by |F| * delta."""
+    import torch
+    state = {}
+
+    def ctx_for(force, positions, box):
+        if "ctx" not in state:
+            system = snb.System()
+            system.addParticles(force.getNumParticles()) if hasattr(system, "addParticles") else [system.addParticle(1.0) for _ in range(force.getNumParticles())]
+            system.setDefaultPeriodicBoxVectors(*box)
+            system.addForce(force)
+            state["ctx"] = snb.Context(system, precision=prec)
+        state["ctx"].setPositions(positions)
+        return state["ctx"]
+
+    def energy(force, positions, box):
+        return ctx_for(force, positions, box).getState(getEnergy=True).getPotentialEnergy()
+
+    def forces(force, positions, box):
+        return ctx_for(force, positions, box).getState(getForces=True).getForces()
+
+    K.testHugeSystem(energy, forces, F, gridSize=150, tol=1e-4)
+    torch.cuda.empty_cache()
+
+
 def test_parameter_update_without_rebuild(snb, F, oev, prec):
     """updateParametersInContext with new charges / sigmas / epsilons / exception parameters but the same subsets and exception
     pairs (the alchemical use of the reference's copyParametersToContext, CommonNonbondedSlicingKernels.cpp:1404-1568) must give the

@@ -50,6 +50,23 @@ def test_nonbonded_slicing(method, exceptions, lj, ev, F):
                            ljpme=(1.0, n, n, n) if method == 5 else None)
 
 
+@pytest.mark.parametrize("method", [0, 1, 2, 4, 5])
+def test_instantiate_from_nonbonded_force(method, ev, F):
+    K.testInstantiateFromNonbondedForce(ev, F, method, pme=(1.0, 20, 20, 20) if method >= 4 else None)
+
+
+@pytest.mark.parametrize("method", [2, 4, 5])
+@pytest.mark.parametrize("exceptions", [False, True])
+def test_scaling_parameter_separation(method, exceptions, ev, F):
+    n = 28 if exceptions else 40
+    K.testScalingParameterSeparation(ev, F, method, exceptions, pme=(1.0, n, n, n) if method >= 4 else None, ljpme=(1.0, n, n, n) if method == 5 else None)
+
+
+def test_huge_system_property_small(ev, F):
+    """testHugeSystem's finite-difference property on a 12^3 grid (the 150^3 original runs on the GPU)."""
+    K.testHugeSystem(lambda f, x, b: ev(f, x, b)["energy"], lambda f, x, b: ev(f, x, b)["forces"], F, gridSize=12, scaledDown=True)
+
+
 def test_fft_against_numpy(oracle):
     rng = np.random.default_rng(1)
     for shape in [(28, 25, 30), (21, 25, 27), (8, 6, 10), (7, 11, 13)]:
