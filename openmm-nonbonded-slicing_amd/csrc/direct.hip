@@ -140,7 +140,14 @@ __device__ __forceinline__ void tileSteps(const DirectParams<Real>& p, const typ
             }
             // Coulomb
             const Real qq = (ENERGY ? qi : qiS) * xj.w;
-            if (MC == MC_EWALD || MC == MC_LJPME) {
+            if ((MC == MC_EWALD || MC == MC_LJPME) && !ENERGY && std::is_same<Real, double>::value) {
+                // forces only: [erfc(ar)/r + 2a/sqrt(pi) e^{-(ar)^2}] = 1/r - r^2 Bt(r^2), Bt a degree-20 polynomial (~1e-13): no libm erfc / exp
+                const Real t = r2 * p.ewScale - Real(1);
+                Real bt = p.ewPoly[20];
+#pragma unroll
+                for (int k = 19; k >= 0; k--) bt = bt * t + p.ewPoly[k];
+                fC = qq * (invR - r2 * bt);
+            } else if (MC == MC_EWALD || MC == MC_LJPME) {
                 const Real ar = p.alpha * r;
                 const Real ex = expNegAlpha2R2(p.alpha2l2e, p.alpha, r2);
                 const Real erfcv = erfcFromExp(ar, ex);

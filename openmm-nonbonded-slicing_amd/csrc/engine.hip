@@ -268,21 +268,21 @@ public:
     }
     // Real-space Ewald force factor of the single-precision forces-only pair kernel:
     //   [erfc(ar)/r + 2a/sqrt(pi) exp(-(ar)^2)] / r^2 = 1/r^3 - Bt(r^2),   Bt(r^2) = [erf(ar) - 2ar/sqrt(pi) exp(-(ar)^2)] / r^3,
-    // Bt is an entire function of r^2 (Bt(0) = 4a^3/(3 sqrt(pi))), so a degree-11 polynomial in t = 2 r^2/r2max - 1 (Chebyshev fit
-    // over [0, (cutoff+skin)^2], converted to monomials in t, |t| <= 1) reproduces it to 1e-7 of Bt(0): 12 packed FMAs replace
-    // v_exp + v_rcp + the A&S erfc polynomial.  Absolute force error per pair stays below that of the A&S path at short range and
+    // Bt is an entire function of r^2 (Bt(0) = 4a^3/(3 sqrt(pi))), so a polynomial in t = 2 r^2/r2max - 1 (Chebyshev fit over
+    // [0, (cutoff+skin)^2], converted to monomials in t, |t| <= 1) reproduces it: degree 11 to 1e-7 of Bt(0) in single precision
+    // (12 packed FMAs replace v_exp + v_rcp + the A&S erfc polynomial), degree 20 to ~1e-13 in double (replaces libm erfc + exp).  Absolute force error per pair stays below that of the A&S path at short range and
     // below 2e-6 * qq near the cutoff (tools/ewald_poly_check.py).
-    static constexpr int EW_DEG = 11;
+    static constexpr int EW_DEG = sizeof(Real) == 4 ? 11 : 20;      // 1e-7 resp. ~1e-13 of Bt(0)
     double ewPoly[EW_DEG + 1] = {0}; double ewR2Max = 1;
     void buildEwaldPoly() {
         const double rmax = cfg.cutoff + std::max(cfg.neighbor_padding, 0.0) + 0.02, a = cfg.alpha;
         ewR2Max = rmax * rmax;
         auto bt = [&](double r2) {
             const double r = std::sqrt(r2), z = a * r;
-            if (z < 1e-2) return a * a * a * (4.0 / (3.0 * std::sqrt(SNB_PI))) * (1.0 - 0.6 * z * z + (3.0 / 14.0) * z * z * z * z);
+            if (z < 2e-2) return a * a * a * (4.0 / (3.0 * std::sqrt(SNB_PI))) * (1.0 - 0.6 * z * z + (3.0 / 14.0) * z * z * z * z - (1.0 / 18.0) * z * z * z * z * z * z);
             return (std::erf(z) - 2.0 * z / std::sqrt(SNB_PI) * std::exp(-z * z)) / (r2 * r);
         };
-        const int M = 64;
+        const int M = 96;
         double c[EW_DEG + 1];
         for (int k = 0; k <= EW_DEG; k++) {
             double acc = 0;

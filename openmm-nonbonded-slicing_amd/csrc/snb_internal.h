@@ -51,7 +51,7 @@ template <typename Real> struct DirectParams {
     int nsub;
     Real cutoff2, krf, crf, alpha, alphaD, k4pe;          // k4pe = ONE_4PI_EPS0
     Real alpha2l2e;                                        // alpha^2 * log2(e)
-    Real ewPoly[12]; Real ewScale; int ewUsePoly;         // single-precision forces-only path: Bt(r^2) ~ sum_k ewPoly[k] t^k, t = r^2 * ewScale - 1 (engine.hip buildEwaldPoly)
+    Real ewPoly[21]; Real ewScale; int ewUsePoly;         // forces-only paths: Bt(r^2) ~ sum_k ewPoly[k] t^k, t = r^2 * ewScale - 1; degree 11 (float) / 20 (double), engine.hip buildEwaldPoly
     Real invCut6, multShift6;                              // LJPME potential shifts
     int useSwitch; Real switchDist, invSwitchWidth;
     Real box[9]; Real invBoxDiag[3];                       // for the per-pair wrap variant
