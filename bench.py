@@ -145,6 +145,8 @@ CONFIGS = {
     "c4": (300000, 14.42, 8, 4, 120, 0, "single"),
     "c5": (1000000, 21.54, 4, 5, 180, 90, "double"),
 }
+# 1-GPU rates of this build on MI355X (bench.py --config <name>, round 1), quoted beside N > 1 results of the same workload
+ONE_GPU_NS_DAY = {"c4": 201.1, "c3": 284.0, "c2": 617.1}
 ALPHA = 2.6283
 CUTOFF = 1.0
 
@@ -356,7 +358,7 @@ def main():
                    "tiles_32x32": T, "blocks": int(st.n_blocks), "rebuild_interval": args.rebuild_interval, "rebuilds_in_timed_region": int(st.n_rebuilds) - rebuilds_before, "host_rebuilds": int(st.n_host_rebuilds), "neighbor_rebuild_ms": round(st.last_rebuild_ms, 2),
                    "first_call_ms": round(first_ms, 1), "energy_step_ms": round(energy_ms, 3),
                    "gpu_ms_per_step": round(gpu_ms, 4), "direct_kernel_ms": round(direct_ms, 4), "reciprocal_ms": round(recip_ms, 4),
-                   "parallelism": ("subset-grid + tile sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},
+                   "parallelism": ("subset-grid + i-block sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_direct (direct-space sliced tile kernel)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(bytes_direct), "avg_launch_ms": round(direct_ms, 4)},
     }
@@ -370,6 +372,9 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_file) + ": " + rec["formula"]
         except Exception as exc:   # a malformed summary must not hide the measurement
             out["roofline"]["traffic_source"] = "unreadable %s (%s)" % (pmc_file, exc)
+    if world > 1 and cfg_name in ONE_GPU_NS_DAY:
+        # the N > 1 line runs the 8-subset box of BASELINE.json's multi-GPU config; its own 1-GPU rate (not the 4-subset headline's) is the fair yardstick
+        out["config"]["one_gpu_value_same_workload"] = ONE_GPU_NS_DAY[cfg_name]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: the same workload generator at 24k atoms (same density, cutoff, alpha, grid spacing), a few evaluations
         ws = build_workload(24000, 6.2145, min(nsub, 4), np.random.default_rng(SEED))
