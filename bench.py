@@ -347,7 +347,9 @@ def main():
     # one energy evaluation for the record (per-slice energies)
     eng.set_positions_device(pos0.data_ptr(), is_double)
     torch.cuda.synchronize()
-    t1 = time.perf_counter(); e_total = eng.execute(True); eng.sync(); energy_ms = (time.perf_counter() - t1) * 1e3
+    energy_ms = 1e30
+    for _ in range(4):      # best of four: the first may coincide with a scheduled list rebuild
+        t1 = time.perf_counter(); e_total = eng.execute(True); eng.sync(); energy_ms = min(energy_ms, (time.perf_counter() - t1) * 1e3)
     out = {
         "metric": "ns/day (force evaluation only, dt = 2 fs)", "value": round(ns_day, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -356,7 +358,7 @@ def main():
                    % (cfg_name, N, Lbox, nsub, "PME" if method == 4 else "LJPME", st.grid[0], (" + dispersion %d^3" % st.dgrid[0]) if method == 5 else "",
                       len(w["exc_qq"]), args.padding),
                    "tiles_32x32": T, "blocks": int(st.n_blocks), "rebuild_interval": args.rebuild_interval, "rebuilds_in_timed_region": int(st.n_rebuilds) - rebuilds_before, "host_rebuilds": int(st.n_host_rebuilds), "neighbor_rebuild_ms": round(st.last_rebuild_ms, 2),
-                   "first_call_ms": round(first_ms, 1), "energy_step_ms": round(energy_ms, 3),
+                   "first_call_ms": round(first_ms, 1), "energy_step_ms": round(energy_ms, 3), "energy_step_gpu_ms": round(eng.stats().last_total_ms, 3),
                    "gpu_ms_per_step": round(gpu_ms, 4), "direct_kernel_ms": round(direct_ms, 4), "reciprocal_ms": round(recip_ms, 4),
                    "parallelism": ("subset-grid + i-block sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_direct (direct-space sliced tile kernel)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -188,6 +188,7 @@ __device__ inline float rowRor8(float v) { return __builtin_bit_cast(float, __bu
 // 16-atom half stored twice so the rotated index c+16-s needs no wrap).
 template <typename Real, int MC, bool WRAP, bool ENERGY>
 __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
+    double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
     using T4 = typename Vec<Real>::T4;
     using T2 = typename Vec<Real>::T2;
     __shared__ T4 s_pos[4][64];
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
         if (ENERGY && slice != curSlice) {
             if (curSlice >= 0) {
                 double a = waveSum((double)ecl), b = waveSum((double)elj);
-                if (lane == 0) { atomicAdd(&p.sliceE[2 * curSlice], a); atomicAdd(&p.sliceE[2 * curSlice + 1], b); }
+                if (lane == 0) { atomicAdd(&sliceE[2 * curSlice], a); atomicAdd(&sliceE[2 * curSlice + 1], b); }
             }
             ecl = 0; elj = 0; curSlice = slice;
         }
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
     if (row < 2) { gAdd(&p.fx[I * 32 + il], fix); gAdd(&p.fy[I * 32 + il], fiy); gAdd(&p.fz[I * 32 + il], fiz); }
     if (ENERGY && curSlice >= 0) {
         double a = waveSum((double)ecl), b = waveSum((double)elj);
-        if (lane == 0) { atomicAdd(&p.sliceE[2 * curSlice], a); atomicAdd(&p.sliceE[2 * curSlice + 1], b); }
+        if (lane == 0) { atomicAdd(&sliceE[2 * curSlice], a); atomicAdd(&sliceE[2 * curSlice + 1], b); }
     }
     __builtin_amdgcn_wave_barrier();
     }   // work-item loop
@@ -313,10 +314,14 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
 // j-force accumulator travels with its slot by a one-lane row rotation fused into the subtract (v_sub_f32_dpp); lanes c and
 // c+8 carry two partial sums of the same slot and are merged by an 8-lane rotation at the end of the tile.
 // Staging: entry e (0..15) of quarter r holds atom 8r + (e & 7), so the rotated read index (c & 7) + 8 - s needs no wrap.
-template <int MC, bool MASKED, bool POLY>
+// ENERGY: the raw (unscaled) pair energies of the tile's slice are accumulated as well -- eLJ = eps_ij s6 (s6 - 1) and the Coulomb
+// energy of the method (Ewald: qq erfc(ar)/r with the A&S erfc) -- from the
+// RAW i-parameters qiRaw / epsiRaw, while the forces keep using the lambda-scaled ones.  This is the kernel of every step of a force
+// that asks for energy-parameter derivatives (the reference accumulates them whether or not the energy is requested, Q4).
+template <int MC, bool MASKED, bool POLY, bool ENERGY>
 __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float4* rdPos, const float2* rdSe, const v2f pix, const v2f piy, const v2f piz,
-                                                const v2f sigi, const v2f qiS, const v2f epsiS, const unsigned maskA, const unsigned maskB, const int c,
-                                                v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz) {
+                                                const v2f sigi, const v2f qiS, const v2f epsiS, const v2f qiRaw, const v2f epsiRaw, const unsigned maskA, const unsigned maskB, const int c,
+                                                v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz, v2f& ecl, v2f& elj) {
 #pragma unroll 4
     for (int s = 0; s < 8; s++) {
         const float4 xj = rdPos[-s];
@@ -329,9 +334,13 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
         const v2f s6 = s2 * s2 * s2;
         const v2f es6 = (epsiS * sj.y) * s6;
         v2f f = es6 * (s6 * 12.0f - 6.0f);
+        v2f eLJ = {0.f, 0.f}, eC = {0.f, 0.f};
+        if (ENERGY) eLJ = ((epsiRaw * sj.y) * s6) * (s6 - 1.0f);
         // Coulomb
         const v2f qq = qiS * xj.w;
         const v2f invR2 = invR * invR;
+        v2f qqRaw = {0.f, 0.f};
+        if (ENERGY) qqRaw = qiRaw * xj.w;
         if (MC == MC_EWALD && POLY) {
             // [erfc(ar)/r + 2a/sqrt(pi) e^{-(ar)^2}] / r^2 = 1/r^3 - Bt(r^2), Bt a degree-11 polynomial in t = r^2 * ewScale - 1: no exp, no rcp
             const v2f t = r2 * p.ewScale - 1.0f;
@@ -339,6 +348,20 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
 #pragma unroll
             for (int k = 9; k >= 0; k--) bt = bt * t + p.ewPoly[k];
             f = f * invR2 + qq * (invR2 * invR - bt);
+            if (ENERGY) {
+                // the pair ENERGY keeps the A&S erfc (relative accuracy near the cutoff, where erfc ~ 4e-5 and most pairs sit): a polynomial
+                // for erf(ar)/r leaves a one-signed 1e-7 residue there that adds up over 6e7 pairs (measured: slice-energy error 9e-4 vs 4e-4)
+                const v2f ar = (r2 * invR) * p.alpha;
+                const v2f e2 = r2 * (-p.alpha2l2e);
+                const v2f ex = {__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
+                const v2f den = ar * 0.3275911f + 1.0f;
+                const v2f tt = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                v2f poly = tt * 1.061405429f + (-1.453152027f);
+                poly = poly * tt + 1.421413741f;
+                poly = poly * tt + (-0.284496736f);
+                poly = poly * tt + 0.254829592f;
+                eC = (qqRaw * invR) * (poly * tt * ex);
+            }
         } else if (MC == MC_EWALD) {
             const v2f r = r2 * invR;
             const v2f ar = r * p.alpha;
@@ -352,14 +375,21 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
             poly = poly * tt + 0.254829592f;
             const v2f erfcv = poly * tt * ex;
             f = (f + (qq * invR) * (erfcv + (ar * ex) * 1.1283791670955126f)) * invR2;
+            if (ENERGY) eC = (qqRaw * invR) * erfcv;
         } else if (MC == MC_RF) {
             f = (f + qq * (invR - r2 * (2.0f * p.krf))) * invR2;
+            if (ENERGY) eC = qqRaw * (invR + r2 * p.krf - p.crf);
         } else {
             f = (f + qq * invR) * invR2;
+            if (ENERGY) eC = qqRaw * invR;
         }
         bool inA = MC == MC_NOCUTOFF ? true : (r2.x < p.cutoff2), inB = MC == MC_NOCUTOFF ? true : (r2.y < p.cutoff2);
         if (MASKED) { const int k = (c - s) & 7; inA = inA && !((maskA >> k) & 1u); inB = inB && !((maskB >> k) & 1u); }
         f.x = inA ? f.x : 0.0f; f.y = inB ? f.y : 0.0f;
+        if (ENERGY) {
+            eC.x = inA ? eC.x : 0.0f; eC.y = inB ? eC.y : 0.0f; eLJ.x = inA ? eLJ.x : 0.0f; eLJ.y = inB ? eLJ.y : 0.0f;
+            ecl = ecl + eC; elj = elj + eLJ;
+        }
         const v2f gx = f * dx, gy = f * dy, gz = f * dz;
         fix = fix + gx; fiy = fiy + gy; fiz = fiz + gz;
         fjx = rowRor1(fjx) - (gx.x + gx.y); fjy = rowRor1(fjy) - (gy.x + gy.y); fjz = rowRor1(fjz) - (gz.x + gz.y);
@@ -371,7 +401,7 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
 
 // The first nListBlocks work-groups of the launch run the O(N) pair lists (exclusion corrections, then 1-4 exceptions: latency-bound
 // work that overlaps the VALU-bound tile work instead of trailing it as a launch of its own); the others loop over tile work items.
-template <int MC, bool POLY>
+template <int MC, bool POLY, bool ENERGY>
 __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<float> p, const PairListParams<float> q, const int nExclBlocks, const int nListBlocks) {
     if ((int)blockIdx.x < nListBlocks) {
         if ((int)blockIdx.x < nExclBlocks) { PairListParams<float> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<float, false>(qe, blockIdx.x); }
@@ -379,6 +409,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         return;
     }
     const int tileBlock = blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
+    double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
     __shared__ float4 s_pos[4][64];
     __shared__ float2 s_se[4][64];
     const int lane = threadIdx.x & 63;
@@ -396,6 +427,15 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     const v2f pix = {pa.x, pb.x}, piy = {pa.y, pb.y}, piz = {pa.z, pb.z};
     const v2f qi = {pa.w * p.k4pe, pb.w * p.k4pe}, sigi = {sa.x, sb.x}, epsi = {sa.y, sb.y};
     v2f fix = {0.f, 0.f}, fiy = {0.f, 0.f}, fiz = {0.f, 0.f};
+    v2f ecl = {0.f, 0.f}, elj = {0.f, 0.f};
+    int curSlice = -1;
+    auto flushEnergy = [&]() {   // raw energies of the slice just finished: wave sum in double, one atomic per term
+        if (curSlice >= 0) {
+            const double a = waveSum((double)ecl.x + (double)ecl.y), b = waveSum((double)elj.x + (double)elj.y);
+            if (lane == 0) { atomicAdd(&sliceE[2 * curSlice], a); atomicAdd(&sliceE[2 * curSlice + 1], b); }
+        }
+        ecl = {0.f, 0.f}; elj = {0.f, 0.f};
+    };
 
     float4* myPos = s_pos[wid];
     float2* mySe = s_se[wid];
@@ -432,6 +472,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         const bool hasMask = head.maskIdx >= 0;
         const unsigned maskA = maskAPre >> (8 * row), maskB = maskBPre >> (8 * row);   // my j-quarter's 8 bits
         const float lamC = lamCPre, lamL = lamLPre;
+        if (ENERGY && slicePre != curSlice) { flushEnergy(); curSlice = slicePre; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         jcode = jcodeNext; head = headNext;
@@ -447,8 +488,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         // lambda folded into the i-side parameters once per tile
         const v2f qiS = qi * lamC, epsiS = epsi * lamL;
         float fjx = 0, fjy = 0, fjz = 0;
-        if (hasMask) tileStepsPacked<MC, true, POLY>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz);
-        else tileStepsPacked<MC, false, POLY>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz);
+        if (hasMask) tileStepsPacked<MC, true, POLY, ENERGY>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+        else tileStepsPacked<MC, false, POLY, ENERGY>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
         // rotate-then-subtract leaves lane c holding slot (c+1)&7: one more rotation brings every slot home, then the two
         // partial sums of a slot (lanes c and c+8) are merged
         fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
@@ -466,6 +507,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     ux += __shfl_xor(ux, 32, 64); uy += __shfl_xor(uy, 32, 64); uz += __shfl_xor(uz, 32, 64);
     if (row == 0) { gAdd(&p.fx[I * 32 + c], ox); gAdd(&p.fy[I * 32 + c], oy); gAdd(&p.fz[I * 32 + c], oz); }
     if (row == 1) { gAdd(&p.fx[I * 32 + 16 + c], ux); gAdd(&p.fy[I * 32 + 16 + c], uy); gAdd(&p.fz[I * 32 + 16 + c], uz); }
+    if (ENERGY) { flushEnergy(); curSlice = -1; }
     __builtin_amdgcn_wave_barrier();
     }   // work-item loop
 }
@@ -478,15 +520,22 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
     { static const int cap = getenv("SNB_DIRECT_WGS") ? atoi(getenv("SNB_DIRECT_WGS")) : 0; if (cap > 0 && nwg > cap) nwg = cap; }
     dim3 grid(nwg), block(256);
     if constexpr (std::is_same<Real, float>::value && MC != MC_LJPME) {
-        if (!wrap && !energy && !p.useSwitch) {
+        static const bool scalarEnergy = getenv("SNB_SCALAR_ENERGY_KERNEL") != nullptr;
+        if (!wrap && !p.useSwitch && !(energy && scalarEnergy)) {
             PairListParams<float> q;
             std::memset(&q, 0, sizeof(q));
             int nExclBlocks = 0, nListBlocks = 0;
-            if (lists) { q = *lists; nExclBlocks = (q.nExclAtoms + 255) / 256; nListBlocks = nExclBlocks + (q.n + 255) / 256; }
+            if (lists && !energy) { q = *lists; nExclBlocks = (q.nExclAtoms + 255) / 256; nListBlocks = nExclBlocks + (q.n + 255) / 256; }   // the energy pair lists need their LDS reduction: own launch
             dim3 gridAll(nwg + nListBlocks);
-            if (MC == MC_EWALD && p.ewUsePoly) hipLaunchKernelGGL((k_directPacked<MC, true>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
-            else hipLaunchKernelGGL((k_directPacked<MC, false>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
-            return lists != nullptr;
+            const bool poly = MC == MC_EWALD && p.ewUsePoly;
+            if (energy) {
+                if (poly) hipLaunchKernelGGL((k_directPacked<MC, true, true>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
+                else hipLaunchKernelGGL((k_directPacked<MC, false, true>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
+            } else {
+                if (poly) hipLaunchKernelGGL((k_directPacked<MC, true, false>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
+                else hipLaunchKernelGGL((k_directPacked<MC, false, false>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
+            }
+            return lists != nullptr && !energy;
         }
     }
     if (wrap) {
@@ -545,7 +594,7 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exceptions
             __hip_atomic_fetch_add(&s_sliceE[2 * slice + 1], e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nS2; i += 256) { const double v = s_sliceE[i]; if (v != 0.0) atomicAdd(&p.sliceE[i], v); }
+        for (int i = threadIdx.x; i < nS2; i += 256) { const double v = s_sliceE[i]; if (v != 0.0) atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, 2 * p.nSlices)[i], v); }
     }
 }
 
@@ -610,7 +659,7 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
     }
     if (ENERGY) {
         __syncthreads();
-        for (int i = threadIdx.x; i < nS2; i += 256) { const double v = s_sliceE[i]; if (v != 0.0) atomicAdd(&p.sliceE[i], v); }
+        for (int i = threadIdx.x; i < nS2; i += 256) { const double v = s_sliceE[i]; if (v != 0.0) atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, 2 * p.nSlices)[i], v); }
     }
 }
 

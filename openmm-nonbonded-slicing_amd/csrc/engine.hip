@@ -216,6 +216,7 @@ public:
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
     bool valuesDirty = false, excValuesDirty = false, haveExceptions = false;   // parameter values changed, structure did not
+    bool hostSumsValid = false; std::vector<double> subsetCharge, selfCoulomb, selfDispersion;   // per-subset sums behind the closed-form energy terms
     std::vector<int3> hKvec; DevBuf<int3> dKvec; DevBuf<Real> dCosSin;
     struct GraphKey {
         const void* pos; int isDouble, stride4; bool direct, recip; void* out; int outDouble, outAcc;
@@ -236,7 +237,7 @@ public:
         for (auto& r : ring) for (int k = 0; k < 5; k++) HIPCHECK(hipEventCreate(&r.e[k]));
         charge.assign(N, 0.0); sigma.assign(N, 1.0); epsilon.assign(N, 0.0); subset.assign(N, 0);
         lambdas.assign((size_t)S * 2, 1.0); dispCoef.assign(S, 0.0); hostSliceE.assign((size_t)S * 2, 0.0);
-        sliceE.resize((size_t)S * 2);
+        sliceE.resize((size_t)S * 2 * SNB_SLICE_E_PARTS);
         if (cfg.shard_count < 1) cfg.shard_count = 1;
         // tabulated Ewald force factor: opt-in.  Measured on MI355X it only trades 4 % of the VALU instructions for LDS gathers (the packed
         // analytic erfc is already cheap) and leaves the kernel time unchanged, so the analytic form stays the default.
@@ -282,23 +283,27 @@ public:
             if (z < 2e-2) return a * a * a * (4.0 / (3.0 * std::sqrt(SNB_PI))) * (1.0 - 0.6 * z * z + (3.0 / 14.0) * z * z * z * z - (1.0 / 18.0) * z * z * z * z * z * z);
             return (std::erf(z) - 2.0 * z / std::sqrt(SNB_PI) * std::exp(-z * z)) / (r2 * r);
         };
+        chebyshevToMonomial(bt, EW_DEG, ewPoly);
+    }
+    // Chebyshev interpolant of f(r^2) over [0, ewR2Max] at 96 nodes, truncated at `deg`, as monomial coefficients in t = 2 r^2/ewR2Max - 1
+    template <typename Fn> void chebyshevToMonomial(Fn f, int deg, double* out) {
         const int M = 96;
-        double c[EW_DEG + 1];
-        for (int k = 0; k <= EW_DEG; k++) {
+        std::vector<double> c(deg + 1);
+        for (int k = 0; k <= deg; k++) {
             double acc = 0;
-            for (int j = 0; j < M; j++) { const double x = std::cos(SNB_PI * (j + 0.5) / M); acc += bt(0.5 * (x + 1.0) * ewR2Max) * std::cos(SNB_PI * k * (j + 0.5) / M); }
+            for (int j = 0; j < M; j++) { const double x = std::cos(SNB_PI * (j + 0.5) / M); acc += f(0.5 * (x + 1.0) * ewR2Max) * std::cos(SNB_PI * k * (j + 0.5) / M); }
             c[k] = acc * 2.0 / M;
         }
         c[0] *= 0.5;
-        // Chebyshev -> monomial: T_0 = 1, T_1 = x, T_{k+1} = 2 x T_k - T_{k-1}
-        double Tm[EW_DEG + 1] = {0}, Tc[EW_DEG + 1] = {0}, Tn[EW_DEG + 1];
-        Tm[0] = 1; Tc[1] = 1;
-        for (int i = 0; i <= EW_DEG; i++) ewPoly[i] = 0;
-        ewPoly[0] += c[0];
-        for (int i = 0; i <= EW_DEG; i++) ewPoly[i] += c[1] * Tc[i];
-        for (int k = 2; k <= EW_DEG; k++) {
-            for (int i = 0; i <= EW_DEG; i++) Tn[i] = (i > 0 ? 2.0 * Tc[i - 1] : 0.0) - Tm[i];
-            for (int i = 0; i <= EW_DEG; i++) { ewPoly[i] += c[k] * Tn[i]; Tm[i] = Tc[i]; Tc[i] = Tn[i]; }
+        // T_0 = 1, T_1 = x, T_{k+1} = 2 x T_k - T_{k-1}
+        std::vector<double> Tm(deg + 1, 0.0), Tc(deg + 1, 0.0), Tn(deg + 1, 0.0);
+        Tm[0] = 1; if (deg >= 1) Tc[1] = 1;
+        for (int i = 0; i <= deg; i++) out[i] = 0;
+        out[0] += c[0];
+        if (deg >= 1) for (int i = 0; i <= deg; i++) out[i] += c[1] * Tc[i];
+        for (int k = 2; k <= deg; k++) {
+            for (int i = 0; i <= deg; i++) Tn[i] = (i > 0 ? 2.0 * Tc[i - 1] : 0.0) - Tm[i];
+            for (int i = 0; i <= deg; i++) { out[i] += c[k] * Tn[i]; Tm[i] = Tc[i]; Tc[i] = Tn[i]; }
         }
     }
     bool isPme() const { return cfg.method == SNB_PME || cfg.method == SNB_LJPME; }
@@ -317,7 +322,7 @@ public:
             const double hs = 0.5 * sg[i];
             maxAbsC6 = std::max(maxAbsC6, std::fabs(8.0 * hs * hs * hs * 2.0 * std::sqrt(ep[i])));
         }
-        haveParticles = true;
+        haveParticles = true; hostSumsValid = false;
         // new charges / sigmas / epsilons alone (parameter offsets, updateParametersInContext) do not touch the neighbour structure:
         // they are refreshed in place (refreshValues) instead of going through a rebuild
         if (subsetsChanged) { needRebuild = true; paramsDirty = true; staticDirty = true; } else valuesDirty = true;
@@ -951,10 +956,11 @@ public:
             HIPCHECK(hipGraphLaunch(graphExec, stream));
         }
         if (energy) {
-            std::vector<double> dev((size_t)S * 2);
-            HIPCHECK(hipMemcpyAsync(dev.data(), sliceE.p, sizeof(double) * S * 2, hipMemcpyDeviceToHost, stream));
+            std::vector<double> dev((size_t)S * 2 * SNB_SLICE_E_PARTS);
+            HIPCHECK(hipMemcpyAsync(dev.data(), sliceE.p, sizeof(double) * dev.size(), hipMemcpyDeviceToHost, stream));
             HIPCHECK(hipStreamSynchronize(stream));
-            hostSliceE = dev;
+            hostSliceE.assign((size_t)S * 2, 0.0);
+            for (int part = 0; part < SNB_SLICE_E_PARTS; part++) for (int i = 0; i < 2 * S; i++) hostSliceE[i] += dev[(size_t)part * 2 * S + i];
             addHostTerms(includeDirect != 0, includeRecip != 0);
             if (energyOut) { double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }
         } else if (energyOut) *energyOut = 0.0;
@@ -977,7 +983,7 @@ public:
             }
         }
         launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, forceBuf.p, gc, stream);
-        if (energy) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2, stream));
+        if (energy) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2 * SNB_SLICE_E_PARTS, stream));
         const bool ew = cfg.method >= SNB_Ewald;
         // Opt-in (SNB_CONCURRENT_PME=1): forces-only graph steps run the reciprocal pipeline on a second stream beside the pair
         // kernel (disjoint force arrays fx.. / fpx..).  Timed (eager) steps stay serial so the per-kernel event timers stay clean.
@@ -1106,13 +1112,18 @@ public:
         if (cfg.shard_rank != 0) return;
         const double volume = box[0] * box[4] * box[8];
         if (recip && cfg.method >= SNB_Ewald) {
-            std::vector<double> Q(nsub, 0.0);
-            for (int i = 0; i < N; i++) {
-                const int s = subset[i]; Q[s] += charge[i];
-                const int slice = s * (s + 3) / 2;
-                hostSliceE[2 * slice] -= SNB_ONE_4PI_EPS0 * charge[i] * charge[i] * cfg.alpha / std::sqrt(SNB_PI);
-                if (cfg.method == SNB_LJPME) hostSliceE[2 * slice + 1] += std::pow(cfg.alpha_d, 6.0) * 64.0 * std::pow(0.5 * sigma[i], 6.0) * std::pow(2.0 * std::sqrt(epsilon[i]), 2.0) / 12.0;
+            if (!hostSumsValid) {      // O(N) sums over the particle parameters: recomputed only when the parameters change
+                subsetCharge.assign(nsub, 0.0); selfCoulomb.assign(nsub, 0.0); selfDispersion.assign(nsub, 0.0);
+                for (int i = 0; i < N; i++) {
+                    const int s = subset[i];
+                    subsetCharge[s] += charge[i];
+                    selfCoulomb[s] -= SNB_ONE_4PI_EPS0 * charge[i] * charge[i] * cfg.alpha / std::sqrt(SNB_PI);
+                    if (cfg.method == SNB_LJPME) selfDispersion[s] += std::pow(cfg.alpha_d, 6.0) * 64.0 * std::pow(0.5 * sigma[i], 6.0) * std::pow(2.0 * std::sqrt(epsilon[i]), 2.0) / 12.0;
+                }
+                hostSumsValid = true;
             }
+            for (int s = 0; s < nsub; s++) { hostSliceE[2 * (s * (s + 3) / 2)] += selfCoulomb[s]; hostSliceE[2 * (s * (s + 3) / 2) + 1] += selfDispersion[s]; }
+            const std::vector<double>& Q = subsetCharge;
             const double factor = (-1.0 / (4 * cfg.alpha * cfg.alpha)) / (2 * SNB_EPSILON0 * volume);
             for (int i = 0; i < nsub; i++) for (int j = i; j < nsub; j++) hostSliceE[2 * (j * (j + 1) / 2 + i)] += (i == j ? 1 : 2) * Q[i] * Q[j] * factor;
         }

@@ -35,8 +35,8 @@ template <typename Real> __global__ __launch_bounds__(256) void k_ewaldSums(cons
         const double ak = exp(k2 * p.factorEwald) / k2;
         for (int j = 0; j < p.nsub; j++) {
             for (int i = 0; i < j; i++)
-                atomicAdd(&p.sliceE[2 * (j * (j + 1) / 2 + i)], 2 * p.recipCoeff * ak * (s_sum[i] * s_sum[j] + s_sum[p.nsub + i] * s_sum[p.nsub + j]));
-            atomicAdd(&p.sliceE[2 * (j * (j + 3) / 2)], p.recipCoeff * ak * (s_sum[j] * s_sum[j] + s_sum[p.nsub + j] * s_sum[p.nsub + j]));
+                atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1))[2 * (j * (j + 1) / 2 + i)], 2 * p.recipCoeff * ak * (s_sum[i] * s_sum[j] + s_sum[p.nsub + i] * s_sum[p.nsub + j]));
+            atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1))[2 * (j * (j + 3) / 2)], p.recipCoeff * ak * (s_sum[j] * s_sum[j] + s_sum[p.nsub + j] * s_sum[p.nsub + j]));
         }
     }
 }

@@ -759,7 +759,7 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
                     const int gi = p.gridSubset[I], gj = p.gridSubset[J];
                     const int slice = gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi;
                     double tot = 0; for (int w = 0; w < NT / 64; w++) tot += s_red[w];
-                    atomicAdd(&p.sliceE[2 * slice + term], tot);
+                    atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, p.nsubTotal * (p.nsubTotal + 1))[2 * slice + term], tot);
                 }
             }
     }
@@ -1012,7 +1012,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_interpolate(co
     }
     if (shardE) {
         __syncthreads();
-        for (int i = threadIdx.x; i < nS2; i += 256) { const double v = s_sliceE[i]; if (v != 0.0) atomicAdd(&p.sliceE[i], v); }
+        for (int i = threadIdx.x; i < nS2; i += 256) { const double v = s_sliceE[i]; if (v != 0.0) atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, p.nsubTotal * (p.nsubTotal + 1))[i], v); }
     }
 }
 
@@ -1148,7 +1148,7 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
     if (trace && tid == 0) { atomicAdd((unsigned long long*)&p.trace[0], (unsigned long long)tLoad); atomicAdd((unsigned long long*)&p.trace[1], (unsigned long long)tComp); atomicAdd((unsigned long long*)&p.trace[2], 1ull); }
     if (wantE) {
         __syncthreads();
-        for (int i = tid; i < nS2; i += NT) { const double v = sE[i]; if (v != 0.0) atomicAdd(&p.sliceE[i], v); }
+        for (int i = tid; i < nS2; i += NT) { const double v = sE[i]; if (v != 0.0) atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, p.nsubTotal * (p.nsubTotal + 1))[i], v); }
     }
 }
 

@@ -25,6 +25,11 @@
 #define SNB_JIDX_MASK 0x01FFFFFF
 #define SNB_JSHIFT_BITS 25
 #define SNB_JCODE_CENTER 62
+// Per-slice energies are accumulated into one of 64 copies of the [S][2] table, chosen by work-group index, and summed by the host
+// after the copy back: tens of thousands of wavefronts adding into the same ~20 doubles were serialised in L2 (0.7 ms of a 0.95 ms
+// energy-step pair kernel).
+#define SNB_SLICE_E_PARTS 64
+#define SNB_SLICE_E_PARTITION(base, stride) ((base) + (size_t)(blockIdx.x & (SNB_SLICE_E_PARTS - 1)) * (size_t)(stride))
 #define SNB_PME_ORDER 5
 
 namespace snb {
