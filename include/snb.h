@@ -66,7 +66,8 @@ typedef struct {
     double  alpha_d;            /* LJPME dispersion separation parameter                                */
     int32_t dgrid[3];           /* LJPME dispersion mesh                                                */
     double  neighbor_padding;   /* nm added to the cutoff when building tiles (0 = rebuild every call)  */
-    int32_t rebuild_interval;   /* rebuild tiles every this many executes (<=1: every execute)          */
+    int32_t rebuild_interval;   /* rebuild tiles every this many executes (0, 1: every execute); < 0: automatic -- when an atom has
+                                 * moved 0.8 * neighbor_padding / 2 since the last rebuild, and after -rebuild_interval executes at the latest */
     int32_t shard_rank;         /* multi-GPU: this engine owns PME subsets J with J % shard_count == shard_rank */
     int32_t shard_count;        /*            and direct-space work items w with w % shard_count == shard_rank; 1 = unsharded */
     int32_t disable_graph;      /* 1 = enqueue every step eagerly (default 0: forces-only steps replay a captured hipGraph)  */
@@ -94,6 +95,8 @@ typedef struct {
     double  sum_total_ms;
     int64_t n_timed;            /* executes included in the sums                                        */
     int64_t n_host_rebuilds;    /* rebuilds that fell back to the host builder (triclinic / non-periodic / tiny boxes) */
+    int64_t n_list_overruns;    /* list lifetimes in which an atom moved more than neighbor_padding / 2 (pairs may have been missed:
+                                 * shorten rebuild_interval, widen the padding, or use the automatic mode)                */
 } snb_stats;
 
 /* -- lifetime ---------------------------------------------------------------------------------- */

@@ -42,7 +42,7 @@ class SnbStats(ctypes.Structure):
         ("n_exclusions", ctypes.c_int64), ("n_14", ctypes.c_int64), ("n_rebuilds", ctypes.c_int64), ("grid", ctypes.c_int32 * 3),
         ("dgrid", ctypes.c_int32 * 3), ("last_direct_ms", ctypes.c_double), ("last_recip_ms", ctypes.c_double),
         ("last_total_ms", ctypes.c_double), ("last_rebuild_ms", ctypes.c_double), ("sum_direct_ms", ctypes.c_double),
-        ("sum_recip_ms", ctypes.c_double), ("sum_total_ms", ctypes.c_double), ("n_timed", ctypes.c_int64), ("n_host_rebuilds", ctypes.c_int64),
+        ("sum_recip_ms", ctypes.c_double), ("sum_total_ms", ctypes.c_double), ("n_timed", ctypes.c_int64), ("n_host_rebuilds", ctypes.c_int64), ("n_list_overruns", ctypes.c_int64),
     ]
 
 

@@ -216,6 +216,8 @@ public:
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
     bool valuesDirty = false, excValuesDirty = false, haveExceptions = false;   // parameter values changed, structure did not
+    // displacement watch: reference positions of the last rebuild and two flags in mapped host memory (read without synchronising)
+    DevBuf<T4> posRef; int* hDispFlags = nullptr; int* dDispFlags = nullptr; int64_t listOverruns = 0;
     bool hostSumsValid = false; std::vector<double> subsetCharge, selfCoulomb, selfDispersion;   // per-subset sums behind the closed-form energy terms
     std::vector<int3> hKvec; DevBuf<int3> dKvec; DevBuf<Real> dCosSin;
     struct GraphKey {
@@ -242,6 +244,9 @@ public:
         // tabulated Ewald force factor: opt-in.  Measured on MI355X it only trades 4 % of the VALU instructions for LDS gathers (the packed
         // analytic erfc is already cheap) and leaves the kernel time unchanged, so the analytic form stays the default.
         if (cfg.method >= SNB_Ewald) buildEwaldPoly();
+        HIPCHECK(hipHostMalloc((void**)&hDispFlags, 64, hipHostMallocMapped));
+        hDispFlags[0] = hDispFlags[1] = 0;
+        HIPCHECK(hipHostGetDevicePointer((void**)&dDispFlags, hDispFlags, 0));
         for (int s = 0; s < nsub; s++) if (s % cfg.shard_count == cfg.shard_rank) ownedSubsets.push_back(s);
         nGrids = cfg.shard_count == 1 ? nsub : (int)ownedSubsets.size();
         if (isPme()) {
@@ -264,6 +269,7 @@ public:
         dropGraph();
         for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
         for (int k = 0; k < 3; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
+        if (hDispFlags) (void)hipHostFree(hDispFlags);
         if (stream2) { (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); (void)hipStreamDestroy(stream2); }
         if (ownStream) (void)hipStreamDestroy(stream);
     }
@@ -377,6 +383,10 @@ public:
         gpuBuilt = false;
         if (cfg.host_neighbor_build || !gpuRebuild()) hostRebuild();
         pmeCells.resize(Npad);   // per-slot scratch is sized here: nothing may allocate while a step is being captured into a graph
+        posRef.resize(Npad);
+        HIPCHECK(hipMemcpyAsync(posRef.p, posq.p, sizeof(T4) * (size_t)Npad, hipMemcpyDeviceToDevice, stream));
+        if (hDispFlags[1]) listOverruns++;      // an atom had moved more than skin/2 before this rebuild came
+        hDispFlags[0] = hDispFlags[1] = 0;
     }
 
     void hostRebuild() {
@@ -918,7 +928,12 @@ public:
             if (box[3] != 0 || box[6] != 0 || box[7] != 0) { err = "SlicedNonbondedForce: Ewald is not supported with non-rectangular boxes.  Use PME instead."; throw (int)SNB_ERR_UNSUPPORTED; }
         }
         if (dLambdas.p == nullptr) setLambdas(lambdas.data());
-        const bool rebuilding = needRebuild || paramsDirty || cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval || cfg.neighbor_padding <= 0;
+        // rebuild_interval < 0: automatic -- rebuild when the displacement watch of the position-gather pass has seen an atom move
+        // 0.8 * skin/2 since the last rebuild (the flag lives in mapped host memory: no synchronisation; it is read one execute late,
+        // hence the margin), and after -rebuild_interval executes at the latest
+        const bool autoMode = cfg.rebuild_interval < 0;
+        const bool due = autoMode ? (hDispFlags[0] != 0 || stepsSinceRebuild >= -cfg.rebuild_interval) : (cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval);
+        const bool rebuilding = needRebuild || paramsDirty || due || cfg.neighbor_padding <= 0;
         if ((valuesDirty || excValuesDirty) && !staticDirty && !rebuilding) refreshValues();
         if (rebuilding) { if (valuesDirty || excValuesDirty) { staticDirty = true; valuesDirty = excValuesDirty = false; } rebuild(); }
         stepsSinceRebuild++;
@@ -981,6 +996,11 @@ public:
                 gc.nx = pp.d.nx; gc.ny = pp.d.ny; gc.nz = pp.d.nz; gc.cells = pp.cells; gc.atomGrid = pp.atomGrid;
                 cellsFromGather = true;
             }
+        }
+        if (cfg.neighbor_padding > 0 && posRef.p) {
+            gc.posRef = posRef.p; gc.flags = dDispFlags;
+            const double half = 0.5 * cfg.neighbor_padding;
+            gc.fail2 = (Real)(half * half); gc.warn2 = (Real)(0.64 * half * half);      // rebuild request at 80 % of skin/2: the flag is read one step late
         }
         launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, forceBuf.p, gc, stream);
         if (energy) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2 * SNB_SLICE_E_PARTS, stream));
@@ -1148,6 +1168,7 @@ public:
         HIPCHECK(hipStreamSynchronize(stream));
         stats.n_tiles = 0;
         // tiles processed by this shard
+        stats.n_list_overruns = listOverruns + (hDispFlags && hDispFlags[1] ? 1 : 0);
         stats.n_tiles = shardTiles; stats.n_blocks = numBlocks; stats.n_padded_atoms = Npad; stats.n_exclusion_tiles = numMaskTiles;
         for (int d = 0; d < 3; d++) { stats.grid[d] = isPme() ? pme.d.nx * (d == 0) + pme.d.ny * (d == 1) + pme.d.nz * (d == 2) : 0; stats.dgrid[d] = cfg.method == SNB_LJPME ? dpme.d.nx * (d == 0) + dpme.d.ny * (d == 1) + dpme.d.nz * (d == 2) : 0; }
         for (int k = 0; k < RING; k++) { EvSet& r = ring[(ringPos + k) % RING]; if (r.pending) harvest(r); }

@@ -24,6 +24,12 @@ __global__ void k_gatherPositions(const In* __restrict__ userPos, int stride, co
     v.y = (Real)userPos[(size_t)u * stride + 1] + imageOffset[3 * s + 1];
     v.z = (Real)userPos[(size_t)u * stride + 2] + imageOffset[3 * s + 2];
     posq[s] = v;
+    if (gc.posRef) {
+        const auto r0 = gc.posRef[s];
+        const Real ddx = v.x - r0.x, ddy = v.y - r0.y, ddz = v.z - r0.z;
+        const Real d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+        if (d2 > gc.warn2) { gc.flags[0] = 1; if (d2 > gc.fail2) gc.flags[1] = 1; }      // plain stores of the same value: no atomics needed
+    }
     if (gc.cells) {
         int cell = -1;
         if (gc.atomGrid[s] >= 0 && v.w != Real(0)) {

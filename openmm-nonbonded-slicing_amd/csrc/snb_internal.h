@@ -194,7 +194,12 @@ template <typename Real> __device__ inline void gridCoord(const Real* recip, Rea
 
 
 // Coulomb-mesh geometry handed to the position-gather pass (cells == nullptr: no mesh / brick spreader not in use)
-template <typename Real> struct GatherCells { Real recip[9]; int nx, ny, nz; int* cells; const int* atomGrid; };
+template <typename Real> struct GatherCells {
+    Real recip[9]; int nx, ny, nz; int* cells; const int* atomGrid;
+    // displacement watch (posRef == nullptr: off): positions at the last rebuild; flags[0] |= 1 when an atom has moved further than
+    // sqrt(warn2) (time to rebuild), flags[1] |= 1 beyond sqrt(fail2) = skin/2 (the list may already have missed a pair)
+    const typename Vec<Real>::T4* posRef; int* flags; Real warn2, fail2;
+};
 
 template <typename Real> void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
                                                     typename Vec<Real>::T4* posq, int nPadded, Real* forces, const GatherCells<Real>& gc, hipStream_t s);

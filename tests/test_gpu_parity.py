@@ -319,6 +319,36 @@ def test_parameter_update_without_rebuild(snb, F, oev, prec):
     assert kern.getStats().n_rebuilds == rebuilds, "parameter values alone must not trigger a neighbour rebuild"
 
 
+def test_automatic_rebuild_follows_displacements(snb):
+    """rebuild_interval < 0: the position-gather pass watches displacements since the last rebuild and the engine rebuilds when an
+    atom has moved 0.8 * skin/2 (the reference relies on OpenMM's padded neighbour list doing the same).  A random walk must trigger
+    rebuilds by itself, keep matching a rebuild-every-step engine, and never overrun the list; a fixed interval that is too long for
+    the same walk must be reported through snb_stats.n_list_overruns."""
+    import torch
+    import bench
+    w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+    n = len(w["q"])
+    pos = torch.tensor(w["pos"], dtype=torch.float32, device="cuda")
+    auto = bench.Engine(snb, w, 4, 54, 0, "single", 0, 0, 1, 0.1, -200)
+    fixed = bench.Engine(snb, w, 4, 54, 0, "single", 0, 0, 1, 0.1, 1000)
+    ref = bench.Engine(snb, w, 4, 54, 0, "single", 0, 0, 1, 0.1, 1)
+    fa = torch.zeros((n, 3), dtype=torch.float32, device="cuda"); fr = torch.zeros_like(fa); ff = torch.zeros_like(fa)
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    worst = 0.0
+    for step in range(60):
+        for eng, out in ((auto, fa), (fixed, ff), (ref, fr)):
+            eng.set_positions_device(pos.data_ptr(), False); eng.execute(False); eng.forces_to(out.data_ptr(), False); eng.sync()
+        a, b = fr.double().cpu().numpy(), fa.double().cpu().numpy()
+        worst = max(worst, float((np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(a, axis=1), 1.0)).max()))
+        pos = pos + torch.randn(pos.shape, generator=g, device="cuda") * 0.004          # ~0.03 nm rms after 60 steps, tails beyond skin/2
+    sa, sf = auto.stats(), fixed.stats()
+    assert worst < 2e-3, worst      # summation-order noise of two different tile lists; a missed pair shows up as O(0.1-1)
+    assert 2 <= sa.n_rebuilds < 30 and sa.n_list_overruns == 0, (sa.n_rebuilds, sa.n_list_overruns)
+    assert sf.n_rebuilds == 1 and sf.n_list_overruns >= 1, (sf.n_rebuilds, sf.n_list_overruns)
+    for e in (auto, fixed, ref):
+        e.close()
+
+
 def test_padding_and_rebuild_interval(snb, F, oev):
     """Tiles built with a skin and reused across steps must give the same answer as a fresh list."""
     force, pos, box = systems.random_box(F, 4096, 2, 4, 3.5, 1.0, pme=(2.6283, 32, 32, 32))
