@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
 // energy of the method (Ewald: qq erfc(ar)/r with the A&S erfc) -- from the
 // RAW i-parameters qiRaw / epsiRaw, while the forces keep using the lambda-scaled ones.  This is the kernel of every step of a force
 // that asks for energy-parameter derivatives (the reference accumulates them whether or not the energy is requested, Q4).
-template <int MC, bool MASKED, bool POLY, bool ENERGY>
+template <int MC, bool MASKED, bool POLY, bool ENERGY, bool SWITCH>
 __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float4* rdPos, const float2* rdSe, const v2f pix, const v2f piy, const v2f piz,
                                                 const v2f sigi, const v2f qiS, const v2f epsiS, const v2f qiRaw, const v2f epsiRaw, const unsigned maskA, const unsigned maskB, const int c,
                                                 v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz, v2f& ecl, v2f& elj) {
@@ -336,6 +336,17 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
         v2f f = es6 * (s6 * 12.0f - 6.0f);
         v2f eLJ = {0.f, 0.f}, eC = {0.f, 0.f};
         if (ENERGY) eLJ = ((epsiRaw * sj.y) * s6) * (s6 - 1.0f);
+        if (SWITCH) {
+            // LJ switching function (ReferenceSlicedLJCoulombIxn.cpp:380-384, 428-431): branch-free, tt clamps to 0 below the switching distance
+            const v2f r = r2 * invR;
+            v2f tt = (r - p.switchDist) * p.invSwitchWidth;
+            tt.x = tt.x > 0.0f ? tt.x : 0.0f; tt.y = tt.y > 0.0f ? tt.y : 0.0f;
+            const v2f t2 = tt * tt;
+            const v2f sw = (t2 * tt) * ((tt * -6.0f + 15.0f) * tt + -10.0f) + 1.0f;
+            const v2f dsw = t2 * ((tt * -30.0f + 60.0f) * tt + -30.0f) * p.invSwitchWidth;
+            f = f * sw - (es6 * (s6 - 1.0f)) * (dsw * r);          // the lambda-scaled pair energy drives the force term
+            if (ENERGY) eLJ = eLJ * sw;
+        }
         // Coulomb
         const v2f qq = qiS * xj.w;
         const v2f invR2 = invR * invR;
@@ -401,7 +412,7 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
 
 // The first nListBlocks work-groups of the launch run the O(N) pair lists (exclusion corrections, then 1-4 exceptions: latency-bound
 // work that overlaps the VALU-bound tile work instead of trailing it as a launch of its own); the others loop over tile work items.
-template <int MC, bool POLY, bool ENERGY>
+template <int MC, bool POLY, bool ENERGY, bool SWITCH>
 __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<float> p, const PairListParams<float> q, const int nExclBlocks, const int nListBlocks) {
     if ((int)blockIdx.x < nListBlocks) {
         if ((int)blockIdx.x < nExclBlocks) { PairListParams<float> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<float, false>(qe, blockIdx.x); }
@@ -488,8 +499,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         // lambda folded into the i-side parameters once per tile
         const v2f qiS = qi * lamC, epsiS = epsi * lamL;
         float fjx = 0, fjy = 0, fjz = 0;
-        if (hasMask) tileStepsPacked<MC, true, POLY, ENERGY>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-        else tileStepsPacked<MC, false, POLY, ENERGY>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+        if (hasMask) tileStepsPacked<MC, true, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+        else tileStepsPacked<MC, false, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
         // rotate-then-subtract leaves lane c holding slot (c+1)&7: one more rotation brings every slot home, then the two
         // partial sums of a slot (lanes c and c+8) are merged
         fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
@@ -521,20 +532,23 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
     dim3 grid(nwg), block(256);
     if constexpr (std::is_same<Real, float>::value && MC != MC_LJPME) {
         static const bool scalarEnergy = getenv("SNB_SCALAR_ENERGY_KERNEL") != nullptr;
-        if (!wrap && !p.useSwitch && !(energy && scalarEnergy)) {
+        if (!wrap && !(energy && scalarEnergy) && !(p.useSwitch && MC == MC_NOCUTOFF)) {
             PairListParams<float> q;
             std::memset(&q, 0, sizeof(q));
             int nExclBlocks = 0, nListBlocks = 0;
             if (lists && !energy) { q = *lists; nExclBlocks = (q.nExclAtoms + 255) / 256; nListBlocks = nExclBlocks + (q.n + 255) / 256; }   // the energy pair lists need their LDS reduction: own launch
             dim3 gridAll(nwg + nListBlocks);
             const bool poly = MC == MC_EWALD && p.ewUsePoly;
-            if (energy) {
-                if (poly) hipLaunchKernelGGL((k_directPacked<MC, true, true>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
-                else hipLaunchKernelGGL((k_directPacked<MC, false, true>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
+#define SNB_PACKED(P, E, S) hipLaunchKernelGGL((k_directPacked<MC, P, E, S>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks)
+            if constexpr (MC == MC_NOCUTOFF) { if (energy) SNB_PACKED(false, true, false); else SNB_PACKED(false, false, false); }
+            else if (p.useSwitch) {
+                if (energy) { if (poly) SNB_PACKED(true, true, true); else SNB_PACKED(false, true, true); }
+                else { if (poly) SNB_PACKED(true, false, true); else SNB_PACKED(false, false, true); }
             } else {
-                if (poly) hipLaunchKernelGGL((k_directPacked<MC, true, false>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
-                else hipLaunchKernelGGL((k_directPacked<MC, false, false>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks);
+                if (energy) { if (poly) SNB_PACKED(true, true, false); else SNB_PACKED(false, true, false); }
+                else { if (poly) SNB_PACKED(true, false, false); else SNB_PACKED(false, false, false); }
             }
+#undef SNB_PACKED
             return lists != nullptr && !energy;
         }
     }
