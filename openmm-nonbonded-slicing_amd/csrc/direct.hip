@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
             if (!WRAP) {
                 const int sc = (code >> SNB_JSHIFT_BITS) & 127;
                 const int kx = sc / 25, ky = (sc - 25 * kx) / 5, kz = sc - 25 * kx - 5 * ky;
-                x.x += Real(kx - 2) * p.boxDiag[0]; x.y += Real(ky - 2) * p.boxDiag[1]; x.z += Real(kz - 2) * p.boxDiag[2];
+                const Real ka = Real(kx - 2), kb = Real(ky - 2), kc = Real(kz - 2);      // lattice image: + ka a + kb b + kc c (rows of p.box)
+                x.x += ka * p.box[0] + kb * p.box[3] + kc * p.box[6]; x.y += kb * p.box[4] + kc * p.box[7]; x.z += kc * p.box[8];
             }
         } else { x.x = Real(3e9) + Real(1e6) * c; x.y = Real(-5e9); x.z = Real(7e9); x.w = 0; se.x = 0; se.y = 0; }
     };
@@ -461,7 +462,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
             x = p.posq[idx]; se = p.sigeps[idx];
             const int sc = (code >> SNB_JSHIFT_BITS) & 127;
             const int kx = sc / 25, ky = (sc - 25 * kx) / 5, kz = sc - 25 * kx - 5 * ky;
-            x.x += float(kx - 2) * p.boxDiag[0]; x.y += float(ky - 2) * p.boxDiag[1]; x.z += float(kz - 2) * p.boxDiag[2];
+            const float ka = float(kx - 2), kb = float(ky - 2), kc = float(kz - 2);      // lattice image: + ka a + kb b + kc c (rows of p.box)
+            x.x += ka * p.box[0] + kb * p.box[3] + kc * p.box[6]; x.y += kb * p.box[4] + kc * p.box[7]; x.z += kc * p.box[8];
         } else { x.x = 3e9f + 1e6f * c; x.y = -5e9f; x.z = 7e9f; x.w = 0; se.x = 0; se.y = 0; }
     };
     struct TileHead { int sj, maskIdx; };

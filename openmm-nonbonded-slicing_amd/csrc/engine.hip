@@ -200,7 +200,7 @@ public:
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
-    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC;
+    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC, dAtomCell;
     DevBuf<long long> dNbTrace, dPmeTrace;
     bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
     double maxAbsQ = 0, maxAbsC6 = 0;
@@ -765,7 +765,8 @@ public:
     // ------------------------------------------------------------------------------------------
     bool gpuRebuild() {
         if (!isPeriodic() || cfg.method == SNB_NoCutoff || N < 64) return false;
-        if (!(box[3] == 0 && box[6] == 0 && box[7] == 0)) return false;
+        static const bool hostTriclinic = getenv("SNB_HOST_TRICLINIC") != nullptr;      // testing aid: old behaviour
+        if (hostTriclinic && !(box[3] == 0 && box[6] == 0 && box[7] == 0)) return false;
         const double R = cfg.cutoff + cfg.neighbor_padding;
         const double volume = box[0] * box[4] * box[8];
         const double aTarget = std::cbrt(32.0 * volume / std::max(N, 1));
@@ -794,7 +795,8 @@ public:
         std::memset(&p, 0, sizeof(p));
         p.nAtoms = N; p.nSubsets = nsub; p.ncx = ncx; p.ncy = ncy;
         p.subsetBits = 1; while ((1 << p.subsetBits) < nsub) p.subsetBits++;
-        p.boxd[0] = box[0]; p.boxd[1] = box[4]; p.boxd[2] = box[8]; p.listCutoff = (float)R;
+        for (int i = 0; i < 9; i++) p.boxm[i] = box[i];
+        p.listCutoff = (float)R;
         p.jumpDist = (float)(2.0 * std::sqrt(2.0) * std::max(box[0] / ncx, box[4] / ncy));   // neighbours along the sort path of a dense region are closer than this
         p.uSubset = dUSubset.p; p.uCharge = dUCharge.p; p.uSigEps = dUSigEps.p; p.uExclStart = exclStart.p; p.uExclList = exclList.p;
         p.slotOfSubset = dSlotOfSubset.p;
@@ -830,6 +832,7 @@ public:
             p.blockCenter = dBlockCenter.p; p.blockHalf = dBlockHalf.p;
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;
+            dAtomCell.resize(Npad); p.atomCell = dAtomCell.p;
             static const bool nbTrace = getenv("SNB_NB_TRACE") != nullptr;
             if (nbTrace) { dNbTrace.resize((size_t)4 * numBlocks); p.dbgOut = dNbTrace.p; }
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.workItems = workItems.p; p.workItemsStage = workItemsStage.p; p.workItemsPartial = workItemsPartial.p; p.counters = dCounters.p;

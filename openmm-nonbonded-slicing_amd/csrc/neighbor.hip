@@ -14,19 +14,36 @@
 
 namespace snb {
 
+// Periodic cell in OpenMM's reduced form: a = (ax, 0, 0), b = (bx, by, 0), c = (cx, cy, cz), |bx| <= ax/2, |cx| <= ax/2, |cy| <= by/2.
+struct Lattice { float ax, bx, by, cx, cy, cz; };
+template <typename Real> __device__ inline Lattice latticeOf(const NbParams<Real>& p) {
+    return Lattice{(float)p.boxm[0], (float)p.boxm[3], (float)p.boxm[4], (float)p.boxm[6], (float)p.boxm[7], (float)p.boxm[8]};
+}
+// nearest periodic image of a displacement (ReferenceForce::getDeltaRPeriodic's triclinic order: c, then b, then a)
+__device__ inline void minImage(float& dx, float& dy, float& dz, const Lattice& L) {
+    float s = rintf(dz / L.cz); dx -= s * L.cx; dy -= s * L.cy; dz -= s * L.cz;
+    s = rintf(dy / L.by); dx -= s * L.bx; dy -= s * L.by;
+    s = rintf(dx / L.ax); dx -= s * L.ax;
+}
 // ---- 1. sort keys -------------------------------------------------------------------------------------------------
 template <typename Real, typename In>
 __global__ void k_nbKeys(const NbParams<Real> p, const In* __restrict__ userPos, int stride) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= p.nAtoms) return;
     double x = (double)userPos[(size_t)u * stride], y = (double)userPos[(size_t)u * stride + 1], z = (double)userPos[(size_t)u * stride + 2];
-    const double wx = x - floor(x / p.boxd[0]) * p.boxd[0], wy = y - floor(y / p.boxd[1]) * p.boxd[1], wz = z - floor(z / p.boxd[2]) * p.boxd[2];
+    // wrap into the primary cell IN FRACTIONAL COORDINATES (the parallelepiped 0 <= f < 1, the same fundamental domain as the PME
+    // mesh); columns and z keys are fractional too, so a triclinic cell sorts exactly like a rectangular one
+    const double* m = p.boxm;
+    double fz = z / m[8], fy = (y - fz * m[7]) / m[4], fx = (x - fy * m[3] - fz * m[6]) / m[0];
+    fx -= floor(fx); fy -= floor(fy); fz -= floor(fz);
+    if (fx >= 1.0) fx = 0.0; if (fy >= 1.0) fy = 0.0; if (fz >= 1.0) fz = 0.0;      // -1e-17 - floor(-1e-17) == 1.0
+    const double wx = fx * m[0] + fy * m[3] + fz * m[6], wy = fy * m[4] + fz * m[7], wz = fz * m[8];
     p.wrapped[3 * (size_t)u] = (Real)wx; p.wrapped[3 * (size_t)u + 1] = (Real)wy; p.wrapped[3 * (size_t)u + 2] = (Real)wz;
     p.offsetU[3 * (size_t)u] = (Real)(wx - x); p.offsetU[3 * (size_t)u + 1] = (Real)(wy - y); p.offsetU[3 * (size_t)u + 2] = (Real)(wz - z);
-    int cx = (int)(wx / p.boxd[0] * p.ncx); cx = cx < 0 ? 0 : (cx >= p.ncx ? p.ncx - 1 : cx);
-    int cy = (int)(wy / p.boxd[1] * p.ncy); cy = cy < 0 ? 0 : (cy >= p.ncy ? p.ncy - 1 : cy);
+    int cx = (int)(fx * p.ncx); cx = cx < 0 ? 0 : (cx >= p.ncx ? p.ncx - 1 : cx);
+    int cy = (int)(fy * p.ncy); cy = cy < 0 ? 0 : (cy >= p.ncy ? p.ncy - 1 : cy);
     const int serp = cx * p.ncy + ((cx & 1) ? (p.ncy - 1 - cy) : cy);
-    double zf = wz / p.boxd[2]; zf = zf < 0 ? 0 : (zf > 1 ? 1 : zf);
+    double zf = fz; zf = zf < 0 ? 0 : (zf > 1 ? 1 : zf);
     if (serp & 1) zf = 1.0 - zf;
     const unsigned long long zq = (unsigned long long)(zf * 1048575.0);
     p.keysIn[u] = ((unsigned long long)p.uSubset[u] << 44) | ((unsigned long long)serp << 20) | zq;
@@ -47,15 +64,10 @@ template <typename Real> __global__ void k_nbJumpFlags(const NbParams<Real> p) {
         start = (p.keysOut[t] >> 44) != (p.keysOut[t - 1] >> 44);
         if (!start) {
             const int u = p.valsOut[t], v = p.valsOut[t - 1];
-            float d2 = 0.f;
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const float L = (float)p.boxd[d];
-                float dl = fabsf((float)p.wrapped[3 * (size_t)u + d] - (float)p.wrapped[3 * (size_t)v + d]);
-                dl = dl > 0.5f * L ? L - dl : dl;
-                d2 += dl * dl;
-            }
-            start = d2 > p.jumpDist * p.jumpDist;
+            float dx = (float)p.wrapped[3 * (size_t)u] - (float)p.wrapped[3 * (size_t)v], dy = (float)p.wrapped[3 * (size_t)u + 1] - (float)p.wrapped[3 * (size_t)v + 1],
+                  dz = (float)p.wrapped[3 * (size_t)u + 2] - (float)p.wrapped[3 * (size_t)v + 2];
+            minImage(dx, dy, dz, latticeOf(p));
+            start = dx * dx + dy * dy + dz * dz > p.jumpDist * p.jumpDist;
         }
         // second pass: every atom of a block found too wide by k_nbWideDetect becomes a segment (= block) of its own
         if (!start && p.blockWide) start = p.blockWide[(t + p.padBefore[t]) >> 5] || p.blockWide[(t - 1 + p.padBefore[t - 1]) >> 5];
@@ -70,15 +82,10 @@ template <typename Real> __global__ void k_nbWideDetect(const NbParams<Real> p) 
     if (t >= p.nAtoms) return;
     const int si = t + p.padBefore[t];
     const int u = p.valsOut[t], u0 = p.valsOut[t - (si & 31)];
-    bool far = false;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        const float L = (float)p.boxd[d];
-        float dl = fabsf((float)p.wrapped[3 * (size_t)u + d] - (float)p.wrapped[3 * (size_t)u0 + d]);
-        dl = dl > 0.5f * L ? L - dl : dl;
-        far = far || dl > p.maxHalfExtent[d];
-    }
-    if (far) p.blockWideOut[si >> 5] = 1;
+    float dx = (float)p.wrapped[3 * (size_t)u] - (float)p.wrapped[3 * (size_t)u0], dy = (float)p.wrapped[3 * (size_t)u + 1] - (float)p.wrapped[3 * (size_t)u0 + 1],
+          dz = (float)p.wrapped[3 * (size_t)u + 2] - (float)p.wrapped[3 * (size_t)u0 + 2];
+    minImage(dx, dy, dz, latticeOf(p));
+    if (fabsf(dx) > p.maxHalfExtent[0] || fabsf(dy) > p.maxHalfExtent[1] || fabsf(dz) > p.maxHalfExtent[2]) p.blockWideOut[si >> 5] = 1;
 }
 template <typename Real> __global__ void k_nbPadExtra(const NbParams<Real> p) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,10 +116,16 @@ template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     Real sh[3] = {0, 0, 0};
     {
         const int u0 = p.valsOut[t - (si & 31)];           // the block's first atom: blocks never cross segments, so ranks t-(si&31)..t are its atoms
-        const Real L[3] = {(Real)p.boxd[0], (Real)p.boxd[1], (Real)p.boxd[2]};
-        const Real w[3] = {v.x, v.y, v.z};
-#pragma unroll
-        for (int d = 0; d < 3; d++) { const Real dl = w[d] - p.wrapped[3 * (size_t)u0 + d]; sh[d] = dl > Real(0.5) * L[d] ? -L[d] : (dl < Real(-0.5) * L[d] ? L[d] : Real(0)); }
+        const float d0x = (float)v.x - (float)p.wrapped[3 * (size_t)u0], d0y = (float)v.y - (float)p.wrapped[3 * (size_t)u0 + 1], d0z = (float)v.z - (float)p.wrapped[3 * (size_t)u0 + 2];
+        float dx = d0x, dy = d0y, dz = d0z;
+        const Lattice L = latticeOf(p);
+        minImage(dx, dy, dz, L);
+        // the difference is an exact lattice vector: rebuild it from integer coefficients so that no rounding noise enters the coordinates
+        const int kz = (int)rintf((dz - d0z) / L.cz);
+        const int ky = (int)rintf(((dy - d0y) - kz * L.cy) / L.by);
+        const int kx = (int)rintf(((dx - d0x) - ky * L.bx - kz * L.cx) / L.ax);
+        sh[0] = (Real)(kx * p.boxm[0] + ky * p.boxm[3] + kz * p.boxm[6]); sh[1] = (Real)(ky * p.boxm[4] + kz * p.boxm[7]); sh[2] = (Real)(kz * p.boxm[8]);
+        p.atomCell[si] = (kx + 1) | ((ky + 1) << 2) | ((kz + 1) << 4);      // lattice cell of the stored position (exact: never re-derived from rounded coordinates)
     }
     v.x += sh[0]; v.y += sh[1]; v.z += sh[2];
     p.posq[si] = v;
@@ -151,7 +164,7 @@ template <typename Real> __global__ void k_nbPad(const NbParams<Real> p) {
         typename Vec<Real>::T4 v; v.x = (Real)(1e9 + 1e6 * (s & 4095)); v.y = (Real)2e9; v.z = (Real)-3e9; v.w = 0;
         p.posq[s] = v;
         typename Vec<Real>::T2 z; z.x = 0; z.y = 0; p.sigeps[s] = z;
-        p.atomSubset[s] = -1; p.atomGrid[s] = -1;
+        p.atomSubset[s] = -1; p.atomGrid[s] = -1; p.atomCell[s] = 1 | (1 << 2) | (1 << 4);
         p.imageOffset[3 * (size_t)s] = 0; p.imageOffset[3 * (size_t)s + 1] = 0; p.imageOffset[3 * (size_t)s + 2] = 0;
     }
 }
@@ -174,7 +187,7 @@ template <typename Real> __global__ void k_nbBounds(const NbParams<Real> p) {
         bool tooWide = false;
         for (int d = 0; d < 3; d++) {
             p.blockCenter[3 * b + d] = 0.5f * (mn[d] + mx[d]); p.blockHalf[3 * b + d] = 0.5f * (mx[d] - mn[d]) + 1e-5f;
-            if ((mx[d] - mn[d]) + 2.f * p.listCutoff >= (float)p.boxd[d]) tooWide = true;   // one image per j-atom needs extent + 2R < L
+            if ((mx[d] - mn[d]) + 2.f * p.listCutoff >= (float)p.boxm[4 * d]) tooWide = true;   // one image per j-atom needs extent + 2R < cell height (ax, by, cz)
         }
         if (tooWide) atomicAdd(&p.counters[3], 1);
     }
@@ -232,8 +245,6 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     const float R = p.listCutoff, R2 = R * R;
     const float cxx = p.blockCenter[3 * I], cyy = p.blockCenter[3 * I + 1], czz = p.blockCenter[3 * I + 2];
     const float hx = p.blockHalf[3 * I], hy = p.blockHalf[3 * I + 1], hz = p.blockHalf[3 * I + 2];
-    const float Lx = (float)p.boxd[0], Ly = (float)p.boxd[1], Lz = (float)p.boxd[2];
-    const float colW = Lx / p.ncx, colH = Ly / p.ncy;
     const int il = lane & 31, half = lane >> 5;
     const int uI = p.sortedToUser[I * 32 + il];
     bool failed = false;
@@ -342,57 +353,36 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     int count = 32;
     bool hasDiag = true;
 
-    const int cx0 = (int)floorf((cxx - hx - R) / colW), cx1 = (int)floorf((cxx + hx + R) / colW);
-    const int cy0 = (int)floorf((cyy - hy - R) / colH), cy1 = (int)floorf((cyy + hy + R) / colH);
-    const float zlo = czz - hz - R, zhi = czz + hz + R;
-    const int nCombX = cx1 - cx0 + 1, nCombY = cy1 - cy0 + 1, nComb = nCombX * nCombY * 3;
-    const float eps = 2e-6f * Lz + 1e-6f;                 // quantised sort keys: widen by a hair
+    // the block's box grown by the list radius: a j-atom is wanted if one of its periodic images lies inside
+    const Lattice Lt = latticeOf(p);
+    const float X0 = cxx - hx - R, X1 = cxx + hx + R, Y0 = cyy - hy - R, Y1 = cyy + hy + R, Z0 = czz - hz - R, Z1 = czz + hz + R;
+    const float feps = 1e-5f;                             // fractional slack for float-vs-double rounding of column / bucket borders
     for (int s = 0; s < p.nSubsets && !failed; s++) {
         int segStart = count;
         const int2* ranges = p.colRange + (size_t)s * p.ncx * p.ncy;
         const int* zIndex = p.zIndex + (size_t)s * p.ncx * p.ncy * 65;
-        // One lane per (column, z image) combination: candidate run = the column's atoms whose z bucket overlaps the wanted interval
-        // (bucket offsets from k_nbZPrefix, no search).  The runs of up to 64 combinations are concatenated and walked 64 candidates
-        // at a time, so every pass has full lanes and independent loads.
-        for (int c0 = 0; c0 < nComb && !failed; c0 += 64) {
-            const int c = c0 + lane;
-            int cStart = 0, cLen = 0, cCode = 0;
-            if (c < nComb) {
-                const int kzI = c % 3, cxy = c / 3;
-                const int gx = cx0 + cxy / nCombY, gy = cy0 + cxy % nCombY, kz = kzI - 1;
-                const int kx = (gx < 0) ? -1 : (gx >= p.ncx ? 1 : 0), ky = (gy < 0) ? -1 : (gy >= p.ncy ? 1 : 0);
-                const int ccx = gx - kx * p.ncx, ccy = gy - ky * p.ncy;
-                const float a = zlo - kz * Lz, b = zhi - kz * Lz;     // wanted z interval in the primary cell
-                if (ccx >= 0 && ccx < p.ncx && ccy >= 0 && ccy < p.ncy && !(b < 0.f || a >= Lz)) {
-                    const int col = ccx * p.ncy + ccy;
-                    const int2 rg = ranges[col];
-                    if (rg.y > rg.x) {
-                        const int serp = ccx * p.ncy + ((ccx & 1) ? (p.ncy - 1 - ccy) : ccy);
-                        float fa = (a - eps) / Lz, fb = (b + eps) / Lz;
-                        fa = fa < 0.f ? 0.f : (fa > 1.f ? 1.f : fa); fb = fb < 0.f ? 0.f : (fb > 1.f ? 1.f : fb);
-                        if (serp & 1) { const float t = 1.f - fb; fb = 1.f - fa; fa = t; }
-                        int blo = ((int)(fa * 1048575.0f) >> 14) - 1, bhi = ((int)(fb * 1048575.0f) >> 14) + 1;   // one bucket of slack for float rounding
-                        blo = blo < 0 ? 0 : blo; bhi = bhi > 63 ? 63 : bhi;
-                        const int* zi = zIndex + (size_t)col * 65;
-                        cStart = zi[blo]; cLen = zi[bhi + 1] - zi[blo];
-                        cCode = (kx + 1) * 9 + (ky + 1) * 3 + (kz + 1);
-                    }
-                }
-            }
-            int incl = cLen;
+        int nCmb = 0;                                     // candidate runs queued in cmbStart / cmbPrefix (lengths) / cmbCode
+
+        // Walks the queued runs, 64 candidates at a time (full lanes, independent loads): exact box test of every candidate in the
+        // image its run was queued for, ballot compaction into the tile list.
+        auto runCandidates = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int len = lane < nCmb ? cmbPrefix[lane] : 0;
+            int incl = len;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
             const int total = __shfl(incl, 63, 64);
             __builtin_amdgcn_wave_barrier();
-            cmbStart[lane] = cStart; cmbPrefix[lane] = incl - cLen; cmbCode[lane] = cCode;
+            cmbPrefix[lane] = incl - len;                 // exclusive prefix; lanes >= nCmb hold `total`
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (int v0 = 0; v0 < total && !failed; v0 += 64) {
                 const int v = v0 + lane;
                 bool ok = v < total;
-                int j = 0, code = 13;
+                int j = 0, code = SNB_JCODE_CENTER;
                 if (ok) {
-                    int k = 0;     // last combination whose exclusive prefix is <= v (empty combinations share a prefix: skip past them)
+                    int k = 0;     // last run whose exclusive prefix is <= v (empty runs are never queued)
 #pragma unroll
                     for (int st = 32; st > 0; st >>= 1) if (k + st < 64 && cmbPrefix[k + st] <= v) k += st;
                     j = cmbStart[k] + (v - cmbPrefix[k]); code = cmbCode[k];
@@ -400,14 +390,16 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
                     ok = (J != I) && ownsPair(I, J);
                 }
                 if (ok) {
-                    // `code` says which lattice image of the WRAPPED j position is wanted; the stored position may already sit one box
-                    // length off (compact blocks), so the shift applied to it -- and recorded in the tile -- is the difference
-                    int kx = code / 9 - 1, ky = (code / 3) % 3 - 1, kz = code % 3 - 1;
+                    // `code` names the lattice image (kx, ky, kz in -1..1) of the WRAPPED j position; the stored position may already sit in
+                    // a neighbouring cell (compact blocks), so the shift applied to it -- and recorded in the tile -- is the difference
+                    int kx = code % 3 - 1, ky = (code / 3) % 3 - 1, kz = code / 9 - 1;
                     const auto q = p.posq[j];
-                    kx -= (int)floorf((float)q.x / Lx); ky -= (int)floorf((float)q.y / Ly); kz -= (int)floorf((float)q.z / Lz);
-                    float dx = fabsf((float)q.x + kx * Lx - cxx) - hx, dy = fabsf((float)q.y + ky * Ly - cyy) - hy, dz = fabsf((float)q.z + kz * Lz - czz) - hz;
+                    const int sc = p.atomCell[j];
+                    kx -= (sc & 3) - 1; ky -= ((sc >> 2) & 3) - 1; kz -= ((sc >> 4) & 3) - 1;
+                    const float px = (float)q.x + kx * Lt.ax + ky * Lt.bx + kz * Lt.cx, py = (float)q.y + ky * Lt.by + kz * Lt.cy, pz = (float)q.z + kz * Lt.cz;
+                    float dx = fabsf(px - cxx) - hx, dy = fabsf(py - cyy) - hy, dz = fabsf(pz - czz) - hz;
                     dx = dx > 0 ? dx : 0; dy = dy > 0 ? dy : 0; dz = dz > 0 ? dz : 0;
-                    ok = (dx * dx + dy * dy + dz * dz < R2) && ((float)q.y < 1e8f);      // padding slots (parked at y = 2e9) can sit inside a run
+                    ok = (dx * dx + dy * dy + dz * dz < R2) && ((float)q.y < 1e8f) && kx >= -2 && kx <= 2 && ky >= -2 && ky <= 2 && kz >= -2 && kz <= 2;   // (padding slots are parked at y = 2e9)
                     code = (kx + 2) * 25 + (ky + 2) * 5 + (kz + 2);
                 }
                 const unsigned long long m = __ballot(ok);
@@ -424,7 +416,54 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
                 count += nNew;
             }
             __builtin_amdgcn_wave_barrier();
+            nCmb = 0;
+        };
+
+        for (int img = 0; img < 27 && !failed; img++) {
+            const int kx = img % 3 - 1, ky = (img / 3) % 3 - 1, kz = img / 9 - 1;
+            // where the WRAPPED atoms of this image must lie: the grown box moved back by kx a + ky b + kz c, in fractional coordinates
+            const float tz = kz * Lt.cz, ty = ky * Lt.by + kz * Lt.cy, tx = kx * Lt.ax + ky * Lt.bx + kz * Lt.cx;
+            float fz0 = (Z0 - tz) / Lt.cz - feps, fz1 = (Z1 - tz) / Lt.cz + feps;
+            if (fz1 < 0.f || fz0 >= 1.f) continue;
+            fz0 = fz0 < 0.f ? 0.f : fz0; fz1 = fz1 > 1.f ? 1.f : fz1;
+            const float sy0 = fz0 * Lt.cy, sy1 = fz1 * Lt.cy;                       // shear of y with z
+            float fy0 = (Y0 - ty - (sy0 > sy1 ? sy0 : sy1)) / Lt.by - feps, fy1 = (Y1 - ty - (sy0 < sy1 ? sy0 : sy1)) / Lt.by + feps;
+            if (fy1 < 0.f || fy0 >= 1.f) continue;
+            fy0 = fy0 < 0.f ? 0.f : fy0; fy1 = fy1 > 1.f ? 1.f : fy1;
+            const float sx0 = fz0 * Lt.cx, sx1 = fz1 * Lt.cx, ux0 = fy0 * Lt.bx, ux1 = fy1 * Lt.bx;     // shear of x with z and y
+            float fx0 = (X0 - tx - (sx0 > sx1 ? sx0 : sx1) - (ux0 > ux1 ? ux0 : ux1)) / Lt.ax - feps, fx1 = (X1 - tx - (sx0 < sx1 ? sx0 : sx1) - (ux0 < ux1 ? ux0 : ux1)) / Lt.ax + feps;
+            if (fx1 < 0.f || fx0 >= 1.f) continue;
+            fx0 = fx0 < 0.f ? 0.f : fx0; fx1 = fx1 > 1.f ? 1.f : fx1;
+            const int gx0 = (int)(fx0 * p.ncx), gy0 = (int)(fy0 * p.ncy);
+            int gx1 = (int)(fx1 * p.ncx), gy1 = (int)(fy1 * p.ncy);
+            gx1 = gx1 > p.ncx - 1 ? p.ncx - 1 : gx1; gy1 = gy1 > p.ncy - 1 ? p.ncy - 1 : gy1;
+            const int nyc = gy1 - gy0 + 1, ncols = (gx1 - gx0 + 1) * nyc;
+            const int code = (kz + 1) * 9 + (ky + 1) * 3 + (kx + 1);
+            for (int c0 = 0; c0 < ncols && !failed; c0 += 64) {
+                const int c = c0 + lane;
+                int cStart = 0, cLen = 0;
+                if (c < ncols) {
+                    const int ccx = gx0 + c / nyc, ccy = gy0 + c % nyc;
+                    const int col = ccx * p.ncy + ccy;
+                    const int2 rg = ranges[col];
+                    if (rg.y > rg.x) {
+                        const int serp = ccx * p.ncy + ((ccx & 1) ? (p.ncy - 1 - ccy) : ccy);
+                        float fa = fz0, fb = fz1;
+                        if (serp & 1) { const float t = 1.f - fb; fb = 1.f - fa; fa = t; }
+                        int blo = ((int)(fa * 1048575.0f) >> 14) - 1, bhi = ((int)(fb * 1048575.0f) >> 14) + 1;   // one bucket of slack for float rounding
+                        blo = blo < 0 ? 0 : blo; bhi = bhi > 63 ? 63 : bhi;
+                        const int* zi = zIndex + (size_t)col * 65;
+                        cStart = zi[blo]; cLen = zi[bhi + 1] - zi[blo];
+                    }
+                }
+                const unsigned long long mq = __ballot(cLen > 0);
+                const int nQ = __popcll(mq);
+                if (nCmb + nQ > 64) runCandidates();
+                if (cLen > 0) { const int o = nCmb + lanePrefix(mq); cmbStart[o] = cStart; cmbPrefix[o] = cLen; cmbCode[o] = code; }
+                nCmb += nQ;
+            }
         }
+        if (nCmb > 0 && !failed) runCandidates();
         // close the subset segment: pad to a whole tile, record the tiles' subset
         const int padded = (count + 31) & ~31;
         for (int k = count + lane; k < padded; k += 64) list[k] = -1;

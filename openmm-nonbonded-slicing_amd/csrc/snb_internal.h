@@ -140,7 +140,7 @@ template <typename Real> void launchEwald(const EwaldParams<Real>& p, hipStream_
 // GPU neighbour build (neighbor.hip)
 template <typename Real> struct NbParams {
     int nAtoms, nPadded, nBlocks, nSubsets, subsetBits, ncx, ncy;
-    double boxd[3];
+    double boxm[9];  // periodic cell, rows a, b, c in OpenMM's reduced (lower-triangular) form
     float listCutoff;
     float jumpDist;  // consecutive sorted atoms further apart than this start a new (padded) block segment
     // static, user order
@@ -157,6 +157,7 @@ template <typename Real> struct NbParams {
     // outputs
     int* sortedToUser; int* userToSorted; typename Vec<Real>::T4* posq; typename Vec<Real>::T2* sigeps; Real* imageOffset;
     int* atomSubset; int* atomGrid; int2* colRange;
+    int* atomCell;   // [Npad] lattice cell (kx+1 | ky+1 << 2 | kz+1 << 4) of the stored position relative to the wrapped one (compact blocks)
     int* zIndex;     // [nSubsets * ncx * ncy][65] atoms of the (subset, column) run below each of 64 z buckets (scratch of the builder)
     int* tileJ; int4* tileInfo; unsigned* masks; int4* workItems; int4* workItemsStage; int4* workItemsPartial;
     int* counters;   // [32 * 65]: line 0 = totals ([0] tiles, [1] full work items, [2] masks, [3] overflow events, [4] partial items, [5] max tiles|masks and

@@ -282,6 +282,39 @@ def test_huge_system_energy_follows_forces(snb, F, prec):
     torch.cuda.empty_cache()
 
 
+TRICLINIC = np.array([[6.0, 0.0, 0.0], [1.5, 6.0, 0.0], [-1.2, 2.0, 6.0]])
+
+
+@pytest.mark.parametrize("method", [2, 4, 5])
+def test_triclinic_cell_on_the_gpu_builder(method, snb, F, oev, prec):
+    """A triclinic cell (OpenMM's reduced form) large enough for the GPU neighbour builder and the PME brick kernels: fractional sort
+    columns, lattice-vector tile images, sheared candidate search.  Energies, forces and derivatives against the oracle; then two
+    forces-only steps (packed kernel, graph replay) after small moves."""
+    n, L = 13824, 6.0
+    pme = (2.6283, 48, 48, 48) if method >= 4 else None
+    ljpme = (2.6283, 24, 24, 24) if method == 5 else None
+    force, pos, _ = systems.random_box(F, n, 3, method, L, 1.0, pme=pme, ljpme=ljpme)
+    pos = (pos / L) @ TRICLINIC                           # the jittered lattice, sheared with the cell
+    box = TRICLINIC.copy()
+    r, o = _compare(make_ev(snb, prec), oev, force, pos, box, TOLS[prec])
+    assert r["stats"].n_tiles > 0 and r["stats"].n_host_rebuilds == 0
+    force2, _, _ = systems.random_box(F, n, 3, method, L, 1.0, pme=pme, ljpme=ljpme, derivatives=False)
+    system = snb.System()
+    for _ in range(n):
+        system.addParticle(1.0)
+    system.setDefaultPeriodicBoxVectors(*box)
+    system.addForce(force2)
+    ctx = snb.Context(system, precision=prec, neighbor_padding=0.1, rebuild_interval=10)
+    rng = np.random.default_rng(3)
+    for step in range(3):
+        ctx.setPositions(pos)
+        fr = ctx.getState(getForces=True).getForces()
+        fo = oev(force2, pos, box)["forces"]
+        err = np.linalg.norm(fo - fr, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)
+        assert err.max() <= TOLS[prec], "step %d: max force error %g" % (step, err.max())
+        pos = pos + rng.normal(0.0, 0.004, pos.shape)
+
+
 def test_parameter_update_without_rebuild(snb, F, oev, prec):
     """updateParametersInContext with new charges / sigmas / epsilons / exception parameters but the same subsets and exception
     pairs (the alchemical use of the reference's copyParametersToContext, CommonNonbondedSlicingKernels.cpp:1404-1568) must give the
