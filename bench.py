@@ -144,11 +144,28 @@ CONFIGS = {
     "c3": (300000, 14.42, 4, 4, 120, 0, "single"),
     "c4": (300000, 14.42, 8, 4, 120, 0, "single"),
     "c5": (1000000, 21.54, 4, 5, 180, 90, "double"),
+    "c3t": (300000, 14.42, 4, 4, 120, 0, "single"),      # c3 in a triclinic cell (shear_workload)
 }
 # 1-GPU rates of this build on MI355X (bench.py --config <name>, round 1), quoted beside N > 1 results of the same workload
 ONE_GPU_NS_DAY = {"c4": 201.1, "c3": 284.0, "c2": 617.1}
 ALPHA = 2.6283
 CUTOFF = 1.0
+
+
+def workload_box(w):
+    """Box vectors (rows a, b, c, flattened) of a workload: cubic, or the sheared cell of the triclinic variants."""
+    return np.ascontiguousarray(w.get("box", np.diag([w["L"]] * 3)), dtype=np.float64).reshape(9)
+
+
+def shear_workload(w):
+    """Triclinic variant of a cubic workload: the same atoms in a cell of the same volume with OpenMM-reduced box vectors
+    a = (L,0,0), b = (L/3,L,0), c = (-L/4,L/4,L); positions are sheared with the cell (a synthetic perf/parity workload)."""
+    L = w["L"]
+    H = np.array([[L, 0.0, 0.0], [L / 3.0, L, 0.0], [-L / 4.0, L / 4.0, L]])
+    w = dict(w)
+    w["pos"] = np.ascontiguousarray((w["pos"] / L) @ H)
+    w["box"] = H
+    return w
 
 
 class ForceView:
@@ -192,7 +209,7 @@ def oracle_eval(w, method, grid, dgrid):
     cfg.include_direct = 1; cfg.include_reciprocal = 1; cfg.background_term = 1; cfg.correct_q1 = 1
     S = w["nsub"] * (w["nsub"] + 1) // 2
     forces = np.zeros((n, 3)); sliceE = np.zeros((S, 2))
-    box = np.diag([w["L"]] * 3).astype(np.float64).reshape(9)
+    box = workload_box(w)
     dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)); ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
     t0 = time.perf_counter()
     rc = L.orc_evaluate(ctypes.byref(cfg), dp(w["pos"]), dp(box), dp(w["q"]), dp(w["sigma"]), dp(w["epsilon"]), ip(w["subset"]), len(w["exc_qq"]),
@@ -220,7 +237,7 @@ class Engine:
         self.ok(self.L.snb_set_particles(self.h, dp(w["q"]), dp(w["sigma"]), dp(w["epsilon"]), ip(w["subset"])))
         self.ok(self.L.snb_set_exceptions(self.h, len(w["exc_qq"]), ip(w["exc_pairs"]), dp(w["exc_qq"]), dp(w["exc_sigma"]), dp(w["exc_eps"]), None))
         self.ok(self.L.snb_set_lambdas(self.h, dp(np.ascontiguousarray(w["lam"]))))
-        box = np.diag([w["L"]] * 3).astype(np.float64).reshape(9)
+        box = workload_box(w)
         self.ok(self.L.snb_set_box(self.h, dp(box)))
 
     def close(self):
@@ -289,6 +306,8 @@ def main():
     pkg = importlib.import_module("openmm-nonbonded-slicing_amd")
     pkg.capi.build()
     w = build_workload(n_target, Lbox, nsub, np.random.default_rng(SEED))
+    if cfg_name.endswith("t"):
+        w = shear_workload(w)
     N = len(w["q"])
     is_double = precision == "double"
     # the engine enqueues on torch's current stream: one stream, no host synchronisation inside the timed loop
@@ -354,7 +373,7 @@ def main():
         "metric": "ns/day (force evaluation only, dt = 2 fs)", "value": round(ns_day, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64" if is_double else "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d-atom cubic box L=%.3f nm, %d subsets, %s %d^3%s, cutoff 1.0 nm, alpha 2.6283/nm, %d exclusions, list skin %.2f nm"
+        "config": {"workload": ("%s: %d-atom " + ("triclinic cell a=(L,0,0) b=(L/3,L,0) c=(-L/4,L/4,L)" if "box" in w else "cubic box") + " L=%.3f nm, %d subsets, %s %d^3%s, cutoff 1.0 nm, alpha 2.6283/nm, %d exclusions, list skin %.2f nm")
                    % (cfg_name, N, Lbox, nsub, "PME" if method == 4 else "LJPME", st.grid[0], (" + dispersion %d^3" % st.dgrid[0]) if method == 5 else "",
                       len(w["exc_qq"]), args.padding),
                    "tiles_32x32": T, "blocks": int(st.n_blocks), "rebuild_interval": args.rebuild_interval, "rebuilds_in_timed_region": int(st.n_rebuilds) - rebuilds_before, "host_rebuilds": int(st.n_host_rebuilds), "neighbor_rebuild_ms": round(st.last_rebuild_ms, 2),
