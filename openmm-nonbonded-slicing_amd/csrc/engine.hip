@@ -944,9 +944,9 @@ public:
         const bool energy = includeEnergy != 0;
         lastRecip = includeRecip && (isPme() || cfg.method == SNB_Ewald);
         // Forces-only steps replay a captured hipGraph (the ~14 small launches of a step are host-launch-bound otherwise:
-        // 7-8 us of idle GPU between kernels).  Every 8th step -- and every energy step -- is enqueued eagerly with HIP events
+        // 7-8 us of idle GPU between kernels).  Every 16th step -- and every energy step -- is enqueued eagerly with HIP events
         // around the pair kernel and the reciprocal pipeline; those samples feed snb_stats' kernel timers.
-        const bool eager = energy || cfg.disable_graph || (execCount++ % 8 == 0);
+        const bool eager = energy || cfg.disable_graph || (execCount++ % 16 == 0);
         if (eager) {
             EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
             if (ev.pending) harvest(ev);
