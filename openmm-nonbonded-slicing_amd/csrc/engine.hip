@@ -200,7 +200,8 @@ public:
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
-    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC, dAtomCell;
+    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC, dAtomCell, dExtent;
+    double tileCell[9] = {0};      // the cell the tile image codes refer to (the box; an enclosing cell for CutoffNonPeriodic)
     DevBuf<long long> dNbTrace, dPmeTrace;
     bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
     double maxAbsQ = 0, maxAbsC6 = 0;
@@ -764,10 +765,31 @@ public:
     // host builder must take over (per-pair-wrap regime, gather-capacity overflow).
     // ------------------------------------------------------------------------------------------
     bool gpuRebuild() {
-        if (!isPeriodic() || cfg.method == SNB_NoCutoff || N < 64) return false;
+        if (cfg.method == SNB_NoCutoff || N < 64) return false;
         static const bool hostTriclinic = getenv("SNB_HOST_TRICLINIC") != nullptr;      // testing aid: old behaviour
-        if (hostTriclinic && !(box[3] == 0 && box[6] == 0 && box[7] == 0)) return false;
+        if (hostTriclinic && (!isPeriodic() || !(box[3] == 0 && box[6] == 0 && box[7] == 0))) return false;
         const double R = cfg.cutoff + cfg.neighbor_padding;
+        // The cell the builder works in: the periodic box, or -- CutoffNonPeriodic -- a rectangular cell around the atoms' bounding box with
+        // more than a list radius of empty margin on every side, so that no periodic image of anything is ever in reach
+        double cell[9], origin[3] = {0, 0, 0};
+        for (int i = 0; i < 9; i++) cell[i] = box[i];
+        if (!isPeriodic()) {
+            dExtent.resize(6);
+            launchExtent(devUserPos, posIsDouble, posStride4, N, dExtent.p, stream);
+            int h[6];
+            HIPCHECK(hipMemcpyAsync(h, dExtent.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+            HIPCHECK(hipStreamSynchronize(stream));
+            auto dec = [](int i) { i = i >= 0 ? i : i ^ 0x7FFFFFFF; float f; std::memcpy(&f, &i, 4); return (double)f; };
+            const double margin = R + 0.5 * cfg.neighbor_padding + 0.05;
+            for (int d = 0; d < 3; d++) {
+                const double lo = dec(h[d]), hi = dec(h[3 + d]);
+                if (!(hi >= lo) || !std::isfinite(lo) || !std::isfinite(hi)) return false;
+                origin[d] = lo - margin;
+                cell[4 * d] = (hi - lo) + 2.0 * margin;
+            }
+            cell[1] = cell[2] = cell[3] = cell[5] = cell[6] = cell[7] = 0;
+        }
+        const double* box = cell;      // (shadows the member for the rest of the build)
         const double volume = box[0] * box[4] * box[8];
         const double aTarget = std::cbrt(32.0 * volume / std::max(N, 1));
         for (int d = 0; d < 3; d++) if (!(4.0 * aTarget + 2 * R < box[4 * d])) return false;   // tile-image scheme needs extent + 2R < L (checked exactly on the GPU too)
@@ -796,6 +818,8 @@ public:
         p.nAtoms = N; p.nSubsets = nsub; p.ncx = ncx; p.ncy = ncy;
         p.subsetBits = 1; while ((1 << p.subsetBits) < nsub) p.subsetBits++;
         for (int i = 0; i < 9; i++) p.boxm[i] = box[i];
+        for (int d = 0; d < 3; d++) p.origin[d] = origin[d];
+        for (int i = 0; i < 9; i++) tileCell[i] = box[i];
         p.listCutoff = (float)R;
         p.jumpDist = (float)(2.0 * std::sqrt(2.0) * std::max(box[0] / ncx, box[4] / ncy));   // neighbours along the sort path of a dense region are closer than this
         p.uSubset = dUSubset.p; p.uCharge = dUCharge.p; p.uSigEps = dUSigEps.p; p.uExclStart = exclStart.p; p.uExclList = exclList.p;
@@ -1055,7 +1079,7 @@ public:
             const bool sw = cfg.use_switch && cfg.method != SNB_NoCutoff && cfg.method != SNB_LJPME;
             p.useSwitch = sw ? 1 : 0; p.switchDist = (Real)cfg.switch_distance;
             p.invSwitchWidth = (Real)(sw ? 1.0 / (cfg.cutoff - cfg.switch_distance) : 0.0);
-            for (int i = 0; i < 9; i++) p.box[i] = (Real)box[i];
+            for (int i = 0; i < 9; i++) p.box[i] = (Real)(gpuBuilt ? tileCell[i] : box[i]);
             if (isPeriodic()) { p.invBoxDiag[0] = (Real)(1.0 / box[0]); p.invBoxDiag[1] = (Real)(1.0 / box[4]); p.invBoxDiag[2] = (Real)(1.0 / box[8]); }
             p.boxDiag[0] = (Real)box[0]; p.boxDiag[1] = (Real)box[4]; p.boxDiag[2] = (Real)box[8];
             int mc = MC_NOCUTOFF;

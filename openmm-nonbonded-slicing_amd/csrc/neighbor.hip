@@ -25,12 +25,33 @@ __device__ inline void minImage(float& dx, float& dy, float& dz, const Lattice& 
     s = rintf(dy / L.by); dx -= s * L.bx; dy -= s * L.by;
     s = rintf(dx / L.ax); dx -= s * L.ax;
 }
+// ---- 0. bounding box of the user positions (non-periodic methods: the builder runs in an enclosing cell with no image in reach) ------
+__device__ inline int orderedInt(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+template <typename In> __global__ void k_nbExtent(const In* __restrict__ userPos, int stride, int n, int* __restrict__ ext) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    if (u < n) for (int d = 0; d < 3; d++) { const float v = (float)userPos[(size_t)u * stride + d]; lo[d] = v; hi[d] = v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
+    if ((threadIdx.x & 63) == 0) for (int d = 0; d < 3; d++) { atomicMin(&ext[d], orderedInt(lo[d])); atomicMax(&ext[3 + d], orderedInt(hi[d])); }
+}
+void launchExtent(const void* userPos, int isDouble, int stride4, int n, int* ext, hipStream_t s) {
+    const int init[6] = {0x7F7FFFFF, 0x7F7FFFFF, 0x7F7FFFFF, (int)0x80800000, (int)0x80800000, (int)0x80800000};      // ordered +max / -max
+    (void)hipMemcpyAsync(ext, init, sizeof(init), hipMemcpyHostToDevice, s);
+    const int stride = stride4 ? 4 : 3;
+    if (isDouble) hipLaunchKernelGGL((k_nbExtent<double>), dim3((n + 255) / 256), dim3(256), 0, s, (const double*)userPos, stride, n, ext);
+    else hipLaunchKernelGGL((k_nbExtent<float>), dim3((n + 255) / 256), dim3(256), 0, s, (const float*)userPos, stride, n, ext);
+}
+
 // ---- 1. sort keys -------------------------------------------------------------------------------------------------
 template <typename Real, typename In>
 __global__ void k_nbKeys(const NbParams<Real> p, const In* __restrict__ userPos, int stride) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= p.nAtoms) return;
-    double x = (double)userPos[(size_t)u * stride], y = (double)userPos[(size_t)u * stride + 1], z = (double)userPos[(size_t)u * stride + 2];
+    const double x0 = (double)userPos[(size_t)u * stride], y0 = (double)userPos[(size_t)u * stride + 1], z0 = (double)userPos[(size_t)u * stride + 2];
+    const double x = x0 - p.origin[0], y = y0 - p.origin[1], z = z0 - p.origin[2];      // (origin != 0 only for the enclosing cell of a non-periodic system)
     // wrap into the primary cell IN FRACTIONAL COORDINATES (the parallelepiped 0 <= f < 1, the same fundamental domain as the PME
     // mesh); columns and z keys are fractional too, so a triclinic cell sorts exactly like a rectangular one
     const double* m = p.boxm;
@@ -39,7 +60,7 @@ __global__ void k_nbKeys(const NbParams<Real> p, const In* __restrict__ userPos,
     if (fx >= 1.0) fx = 0.0; if (fy >= 1.0) fy = 0.0; if (fz >= 1.0) fz = 0.0;      // -1e-17 - floor(-1e-17) == 1.0
     const double wx = fx * m[0] + fy * m[3] + fz * m[6], wy = fy * m[4] + fz * m[7], wz = fz * m[8];
     p.wrapped[3 * (size_t)u] = (Real)wx; p.wrapped[3 * (size_t)u + 1] = (Real)wy; p.wrapped[3 * (size_t)u + 2] = (Real)wz;
-    p.offsetU[3 * (size_t)u] = (Real)(wx - x); p.offsetU[3 * (size_t)u + 1] = (Real)(wy - y); p.offsetU[3 * (size_t)u + 2] = (Real)(wz - z);
+    p.offsetU[3 * (size_t)u] = (Real)(wx - x0); p.offsetU[3 * (size_t)u + 1] = (Real)(wy - y0); p.offsetU[3 * (size_t)u + 2] = (Real)(wz - z0);
     int cx = (int)(fx * p.ncx); cx = cx < 0 ? 0 : (cx >= p.ncx ? p.ncx - 1 : cx);
     int cy = (int)(fy * p.ncy); cy = cy < 0 ? 0 : (cy >= p.ncy ? p.ncy - 1 : cy);
     const int serp = cx * p.ncy + ((cx & 1) ? (p.ncy - 1 - cy) : cy);

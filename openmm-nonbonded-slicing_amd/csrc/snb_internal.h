@@ -141,6 +141,7 @@ template <typename Real> void launchEwald(const EwaldParams<Real>& p, hipStream_
 template <typename Real> struct NbParams {
     int nAtoms, nPadded, nBlocks, nSubsets, subsetBits, ncx, ncy;
     double boxm[9];  // periodic cell, rows a, b, c in OpenMM's reduced (lower-triangular) form
+    double origin[3];  // subtracted from the user positions before wrapping (the enclosing cell of a non-periodic system; else 0)
     float listCutoff;
     float jumpDist;  // consecutive sorted atoms further apart than this start a new (padded) block segment
     // static, user order
@@ -166,6 +167,7 @@ template <typename Real> struct NbParams {
     int shardRank, shardCount;   // tiles and work items are built only for i-blocks with block % shardCount == shardRank
     long long* dbgOut;   // SNB_NB_TRACE: per-block start/end wall_clock64 stamps (100 MHz) of the tile builder
 };
+void launchExtent(const void* userPos, int isDouble, int stride4, int n, int* ext, hipStream_t s);   // ext[6]: ordered-int min xyz, max xyz
 template <typename Real> size_t nbSortTempBytes(int n);
 template <typename Real> void launchNeighborSort(const NbParams<Real>& p, const void* userPos, int isDouble, int stride4, void* sortTemp, size_t sortTempBytes, hipStream_t s);
 template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipStream_t s);

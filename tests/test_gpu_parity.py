@@ -315,6 +315,17 @@ def test_triclinic_cell_on_the_gpu_builder(method, snb, F, oev, prec):
         pos = pos + rng.normal(0.0, 0.004, pos.shape)
 
 
+def test_nonperiodic_cutoff_on_the_gpu_builder(snb, F, oev, prec):
+    """CutoffNonPeriodic at a size where the GPU neighbour builder applies: it runs inside an enclosing cell with more than a list
+    radius of empty margin, so no image is ever in reach; the answer must be the oracle's non-periodic one and no list may be
+    built on the host."""
+    n, L = 13824, 6.0
+    force, pos, box = systems.random_box(F, n, 3, 1, L, 1.0)
+    pos = pos + np.array([-7.3, 4.1, 12.0])               # away from the origin (kept moderate: single precision carries absolute coordinates)
+    r, o = _compare(make_ev(snb, prec), oev, force, pos, None, TOLS[prec])
+    assert r["stats"].n_tiles > 0 and r["stats"].n_host_rebuilds == 0
+
+
 def test_parameter_update_without_rebuild(snb, F, oev, prec):
     """updateParametersInContext with new charges / sigmas / epsilons / exception parameters but the same subsets and exception
     pairs (the alchemical use of the reference's copyParametersToContext, CommonNonbondedSlicingKernels.cpp:1404-1568) must give the
