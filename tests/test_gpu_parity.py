@@ -326,6 +326,30 @@ def test_nonperiodic_cutoff_on_the_gpu_builder(snb, F, oev, prec):
     assert r["stats"].n_tiles > 0 and r["stats"].n_host_rebuilds == 0
 
 
+def test_lambda_changes_between_replayed_steps(snb, F, oev, prec):
+    """The alchemical inner loop: context.setParameter on scaling parameters between forces-only steps.  The lambdas live in a device
+    table the captured step graph reads, so a replayed step must follow the new values without a rebuild or a re-capture."""
+    n, L = 13824, 6.0
+    force, pos, box = systems.random_box(F, n, 3, 4, L, 1.0, pme=(2.6283, 48, 48, 48), derivatives=False)
+    system = snb.System()
+    for _ in range(n):
+        system.addParticle(1.0)
+    system.setDefaultPeriodicBoxVectors(*box)
+    system.addForce(force)
+    ctx = snb.Context(system, precision=prec, neighbor_padding=0.1, rebuild_interval=50)
+    ctx.setPositions(pos)
+    kern = ctx._kernelFor(force)
+    for step, (le, lv, l12) in enumerate([(0.7, 0.9, 0.45), (0.2, 0.9, 0.45), (0.2, 0.35, 1.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)]):
+        params = {"lam_elec_01": le, "lam_vdw_01": lv, "lam_12": l12}
+        for k, v in params.items():
+            ctx.setParameter(k, v)
+        fr = ctx.getState(getForces=True).getForces()
+        fo = oev(force, pos, box, dict(ctx.getParameters()))["forces"]
+        err = np.linalg.norm(fo - fr, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)
+        assert err.max() <= TOLS[prec], "step %d: max force error %g" % (step, err.max())
+    assert kern.getStats().n_rebuilds == 1
+
+
 def test_parameter_update_without_rebuild(snb, F, oev, prec):
     """updateParametersInContext with new charges / sigmas / epsilons / exception parameters but the same subsets and exception
     pairs (the alchemical use of the reference's copyParametersToContext, CommonNonbondedSlicingKernels.cpp:1404-1568) must give the
