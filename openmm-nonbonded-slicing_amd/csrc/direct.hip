@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
 // that asks for energy-parameter derivatives (the reference accumulates them whether or not the energy is requested, Q4).
 template <int MC, bool MASKED, bool POLY, bool ENERGY, bool SWITCH>
 __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float4* rdPos, const float2* rdSe, const v2f pix, const v2f piy, const v2f piz,
-                                                const v2f sigi, const v2f qiS, const v2f epsiS, const v2f qiRaw, const v2f epsiRaw, const unsigned maskA, const unsigned maskB, const int c,
+                                                const v2f sigi, const v2f qiS, const v2f epsiS, const v2f qiRaw, const v2f epsiRaw, const v2f c6iRaw, const float lamL, const unsigned maskA, const unsigned maskB, const int c,
                                                 v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz, v2f& ecl, v2f& elj) {
 #pragma unroll 4
     for (int s = 0; s < 8; s++) {
@@ -348,12 +348,31 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
             f = f * sw - (es6 * (s6 - 1.0f)) * (dsw * r);          // the lambda-scaled pair energy drives the force term
             if (ENERGY) eLJ = eLJ * sw;
         }
+        const v2f invR2 = invR * invR;
+        if (MC == MC_LJPME) {
+            // LJPME: the mesh carries the geometric-mean dispersion; inside the cutoff the real-space term corrects to Lorentz-Berthelot
+            // (multiplicative grid term + potential shifts, ReferenceSlicedLJCoulombIxn.cpp:398-426)
+            const v2f dar2 = r2 * (p.alphaD * p.alphaD), dar4 = dar2 * dar2;
+            const float sj3 = sj.x * sj.x * sj.x;
+            const v2f c6 = c6iRaw * (8.0f * sj3 * sj.y);
+            const v2f coef = (invR2 * invR2 * invR2) * c6;
+            const v2f ed = dar2 * -1.4426950408889634f;
+            const v2f expd = {__builtin_amdgcn_exp2f(ed.x), __builtin_amdgcn_exp2f(ed.y)};
+            const v2f epre = dar4 * 0.5f + dar2 + 1.0f;
+            const v2f dpre = (dar4 * dar2) * (1.0f / 6.0f) + epre;
+            const v2f fmul = (coef * 6.0f) * (1.0f - expd * dpre);
+            f = f + fmul * lamL;
+            if (ENERGY) {
+                const v2f sg = sigi + sj.x;
+                v2f sg2 = sg * sg; const v2f sg6 = (sg2 * sg2 * sg2) * p.invCut6;
+                eLJ = eLJ + coef * (1.0f - expd * epre) + (epsiRaw * sj.y) * ((1.0f - sg6) * sg6) - c6 * p.multShift6;
+            }
+        }
         // Coulomb
         const v2f qq = qiS * xj.w;
-        const v2f invR2 = invR * invR;
         v2f qqRaw = {0.f, 0.f};
         if (ENERGY) qqRaw = qiRaw * xj.w;
-        if (MC == MC_EWALD && POLY) {
+        if ((MC == MC_EWALD || MC == MC_LJPME) && POLY) {
             // [erfc(ar)/r + 2a/sqrt(pi) e^{-(ar)^2}] / r^2 = 1/r^3 - Bt(r^2), Bt a degree-11 polynomial in t = r^2 * ewScale - 1: no exp, no rcp
             const v2f t = r2 * p.ewScale - 1.0f;
             v2f bt = t * p.ewPoly[11] + p.ewPoly[10];
@@ -374,7 +393,7 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
                 poly = poly * tt + 0.254829592f;
                 eC = (qqRaw * invR) * (poly * tt * ex);
             }
-        } else if (MC == MC_EWALD) {
+        } else if (MC == MC_EWALD || MC == MC_LJPME) {
             const v2f r = r2 * invR;
             const v2f ar = r * p.alpha;
             const v2f e2 = r2 * (-p.alpha2l2e);
@@ -439,6 +458,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     const v2f pix = {pa.x, pb.x}, piy = {pa.y, pb.y}, piz = {pa.z, pb.z};
     const v2f qi = {pa.w * p.k4pe, pb.w * p.k4pe}, sigi = {sa.x, sb.x}, epsi = {sa.y, sb.y};
     v2f fix = {0.f, 0.f}, fiy = {0.f, 0.f}, fiz = {0.f, 0.f};
+    const v2f c6i = {8.0f * sa.x * sa.x * sa.x * sa.y, 8.0f * sb.x * sb.x * sb.x * sb.y};      // LJPME: c6 of the two i-atoms
     v2f ecl = {0.f, 0.f}, elj = {0.f, 0.f};
     int curSlice = -1;
     auto flushEnergy = [&]() {   // raw energies of the slice just finished: wave sum in double, one atomic per term
@@ -501,8 +521,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         // lambda folded into the i-side parameters once per tile
         const v2f qiS = qi * lamC, epsiS = epsi * lamL;
         float fjx = 0, fjy = 0, fjz = 0;
-        if (hasMask) tileStepsPacked<MC, true, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-        else tileStepsPacked<MC, false, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+        if (hasMask) tileStepsPacked<MC, true, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, lamL, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+        else tileStepsPacked<MC, false, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, lamL, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
         // rotate-then-subtract leaves lane c holding slot (c+1)&7: one more rotation brings every slot home, then the two
         // partial sums of a slot (lanes c and c+8) are merged
         fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
@@ -532,7 +552,7 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
     int nwg = (myItems + 3) / 4;
     { static const int cap = getenv("SNB_DIRECT_WGS") ? atoi(getenv("SNB_DIRECT_WGS")) : 0; if (cap > 0 && nwg > cap) nwg = cap; }
     dim3 grid(nwg), block(256);
-    if constexpr (std::is_same<Real, float>::value && MC != MC_LJPME) {
+    if constexpr (std::is_same<Real, float>::value) {
         static const bool scalarEnergy = getenv("SNB_SCALAR_ENERGY_KERNEL") != nullptr;
         if (!wrap && !(energy && scalarEnergy) && !(p.useSwitch && MC == MC_NOCUTOFF)) {
             PairListParams<float> q;
@@ -540,10 +560,10 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
             int nExclBlocks = 0, nListBlocks = 0;
             if (lists && !energy) { q = *lists; nExclBlocks = (q.nExclAtoms + 255) / 256; nListBlocks = nExclBlocks + (q.n + 255) / 256; }   // the energy pair lists need their LDS reduction: own launch
             dim3 gridAll(nwg + nListBlocks);
-            const bool poly = MC == MC_EWALD && p.ewUsePoly;
+            const bool poly = (MC == MC_EWALD || MC == MC_LJPME) && p.ewUsePoly;
 #define SNB_PACKED(P, E, S) hipLaunchKernelGGL((k_directPacked<MC, P, E, S>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks)
             if constexpr (MC == MC_NOCUTOFF) { if (energy) SNB_PACKED(false, true, false); else SNB_PACKED(false, false, false); }
-            else if (p.useSwitch) {
+            else if (p.useSwitch && MC != MC_LJPME) {      // (no switching function under LJPME, Q2)
                 if (energy) { if (poly) SNB_PACKED(true, true, true); else SNB_PACKED(false, true, true); }
                 else { if (poly) SNB_PACKED(true, false, true); else SNB_PACKED(false, false, true); }
             } else {
