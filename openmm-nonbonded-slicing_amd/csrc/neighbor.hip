@@ -249,6 +249,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     __shared__ int s_tileSub[4][NB_MAXT];
     __shared__ int s_query[4][128];      // exclusion partners (sorted index) still to be located in the gathered list
     __shared__ int s_qrow[4][128];       // ... and the i-row each belongs to
+    __shared__ int s_imgI[4][27][5]; __shared__ float s_imgF[4][27][2];      // surviving lattice images of the block (see below)
     __shared__ int s_cmb[4][3][64];      // candidate runs of the current batch of (column, z image) combinations: start, exclusive prefix, image code
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -378,6 +379,35 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     const Lattice Lt = latticeOf(p);
     const float X0 = cxx - hx - R, X1 = cxx + hx + R, Y0 = cyy - hy - R, Y1 = cyy + hy + R, Z0 = czz - hz - R, Z1 = czz + hz + R;
     const float feps = 1e-5f;                             // fractional slack for float-vs-double rounding of column / bucket borders
+    // The lattice images that can reach the grown box, with their column rectangles and fractional z ranges: geometry only, so it is
+    // worked out once per block and reused for every j-subset (typically 1-4 of the 27 images survive).
+    int (*imgI)[5] = s_imgI[wid]; float (*imgF)[2] = s_imgF[wid];
+    int nImg = 0;
+    for (int img = 0; img < 27; img++) {
+        const int kx = img % 3 - 1, ky = (img / 3) % 3 - 1, kz = img / 9 - 1;
+        // where the WRAPPED atoms of this image must lie: the grown box moved back by kx a + ky b + kz c, in fractional coordinates
+        const float tz = kz * Lt.cz, ty = ky * Lt.by + kz * Lt.cy, tx = kx * Lt.ax + ky * Lt.bx + kz * Lt.cx;
+        float fz0 = (Z0 - tz) / Lt.cz - feps, fz1 = (Z1 - tz) / Lt.cz + feps;
+        if (fz1 < 0.f || fz0 >= 1.f) continue;
+        fz0 = fz0 < 0.f ? 0.f : fz0; fz1 = fz1 > 1.f ? 1.f : fz1;
+        const float sy0 = fz0 * Lt.cy, sy1 = fz1 * Lt.cy;                       // shear of y with z
+        float fy0 = (Y0 - ty - (sy0 > sy1 ? sy0 : sy1)) / Lt.by - feps, fy1 = (Y1 - ty - (sy0 < sy1 ? sy0 : sy1)) / Lt.by + feps;
+        if (fy1 < 0.f || fy0 >= 1.f) continue;
+        fy0 = fy0 < 0.f ? 0.f : fy0; fy1 = fy1 > 1.f ? 1.f : fy1;
+        const float sx0 = fz0 * Lt.cx, sx1 = fz1 * Lt.cx, ux0 = fy0 * Lt.bx, ux1 = fy1 * Lt.bx;     // shear of x with z and y
+        float fx0 = (X0 - tx - (sx0 > sx1 ? sx0 : sx1) - (ux0 > ux1 ? ux0 : ux1)) / Lt.ax - feps, fx1 = (X1 - tx - (sx0 < sx1 ? sx0 : sx1) - (ux0 < ux1 ? ux0 : ux1)) / Lt.ax + feps;
+        if (fx1 < 0.f || fx0 >= 1.f) continue;
+        fx0 = fx0 < 0.f ? 0.f : fx0; fx1 = fx1 > 1.f ? 1.f : fx1;
+        const int gx0 = (int)(fx0 * p.ncx), gy0 = (int)(fy0 * p.ncy);
+        int gx1 = (int)(fx1 * p.ncx), gy1 = (int)(fy1 * p.ncy);
+        gx1 = gx1 > p.ncx - 1 ? p.ncx - 1 : gx1; gy1 = gy1 > p.ncy - 1 ? p.ncy - 1 : gy1;
+        const int nyc = gy1 - gy0 + 1, ncols = (gx1 - gx0 + 1) * nyc;
+        const int code = (kz + 1) * 9 + (ky + 1) * 3 + (kx + 1);
+        if (lane == 0) { imgI[nImg][0] = gx0; imgI[nImg][1] = gy0; imgI[nImg][2] = nyc; imgI[nImg][3] = ncols; imgI[nImg][4] = code; imgF[nImg][0] = fz0; imgF[nImg][1] = fz1; }
+        nImg++;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int s = 0; s < p.nSubsets && !failed; s++) {
         int segStart = count;
         const int2* ranges = p.colRange + (size_t)s * p.ncx * p.ncy;
@@ -440,26 +470,9 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
             nCmb = 0;
         };
 
-        for (int img = 0; img < 27 && !failed; img++) {
-            const int kx = img % 3 - 1, ky = (img / 3) % 3 - 1, kz = img / 9 - 1;
-            // where the WRAPPED atoms of this image must lie: the grown box moved back by kx a + ky b + kz c, in fractional coordinates
-            const float tz = kz * Lt.cz, ty = ky * Lt.by + kz * Lt.cy, tx = kx * Lt.ax + ky * Lt.bx + kz * Lt.cx;
-            float fz0 = (Z0 - tz) / Lt.cz - feps, fz1 = (Z1 - tz) / Lt.cz + feps;
-            if (fz1 < 0.f || fz0 >= 1.f) continue;
-            fz0 = fz0 < 0.f ? 0.f : fz0; fz1 = fz1 > 1.f ? 1.f : fz1;
-            const float sy0 = fz0 * Lt.cy, sy1 = fz1 * Lt.cy;                       // shear of y with z
-            float fy0 = (Y0 - ty - (sy0 > sy1 ? sy0 : sy1)) / Lt.by - feps, fy1 = (Y1 - ty - (sy0 < sy1 ? sy0 : sy1)) / Lt.by + feps;
-            if (fy1 < 0.f || fy0 >= 1.f) continue;
-            fy0 = fy0 < 0.f ? 0.f : fy0; fy1 = fy1 > 1.f ? 1.f : fy1;
-            const float sx0 = fz0 * Lt.cx, sx1 = fz1 * Lt.cx, ux0 = fy0 * Lt.bx, ux1 = fy1 * Lt.bx;     // shear of x with z and y
-            float fx0 = (X0 - tx - (sx0 > sx1 ? sx0 : sx1) - (ux0 > ux1 ? ux0 : ux1)) / Lt.ax - feps, fx1 = (X1 - tx - (sx0 < sx1 ? sx0 : sx1) - (ux0 < ux1 ? ux0 : ux1)) / Lt.ax + feps;
-            if (fx1 < 0.f || fx0 >= 1.f) continue;
-            fx0 = fx0 < 0.f ? 0.f : fx0; fx1 = fx1 > 1.f ? 1.f : fx1;
-            const int gx0 = (int)(fx0 * p.ncx), gy0 = (int)(fy0 * p.ncy);
-            int gx1 = (int)(fx1 * p.ncx), gy1 = (int)(fy1 * p.ncy);
-            gx1 = gx1 > p.ncx - 1 ? p.ncx - 1 : gx1; gy1 = gy1 > p.ncy - 1 ? p.ncy - 1 : gy1;
-            const int nyc = gy1 - gy0 + 1, ncols = (gx1 - gx0 + 1) * nyc;
-            const int code = (kz + 1) * 9 + (ky + 1) * 3 + (kx + 1);
+        for (int im = 0; im < nImg && !failed; im++) {
+            const int gx0 = imgI[im][0], gy0 = imgI[im][1], nyc = imgI[im][2], ncols = imgI[im][3], code = imgI[im][4];
+            const float fz0 = imgF[im][0], fz1 = imgF[im][1];
             for (int c0 = 0; c0 < ncols && !failed; c0 += 64) {
                 const int c = c0 + lane;
                 int cStart = 0, cLen = 0;
