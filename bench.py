@@ -263,6 +263,9 @@ class Engine:
         self.ok(self.L.snb_execute(self.h, 1, int(energy), 1, 1, ctypes.byref(e)))
         return e.value
 
+    def set_shard_blocks(self, begin, end, period):
+        self.ok(self.L.snb_set_shard_blocks(self.h, int(begin), int(end), int(period)))
+
     def set_force_output(self, ptr, is_double, accumulate=0):
         self.ok(self.L.snb_set_force_output(self.h, ctypes.c_void_p(ptr), int(is_double), int(accumulate)))
 
@@ -288,6 +291,7 @@ def main():
     ap.add_argument("--padding", type=float, default=0.1, help="neighbour-list skin in nm")
     ap.add_argument("--rebuild-interval", type=int, default=20, help="re-sort atoms and rebuild the tile lists every this many steps (inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-balance", action="store_true", help="N > 1: keep the even i-block split instead of balancing direct-space work against the ranks' reciprocal work")
     ap.add_argument("--check", action="store_true", help="also compare forces/energies with the CPU oracle (slow at full size)")
     args = ap.parse_args()
 
@@ -334,6 +338,27 @@ def main():
     t_rebuild0 = time.perf_counter()
     fenced_step(0); eng.sync()
     first_ms = (time.perf_counter() - t_rebuild0) * 1e3
+    block_ranges = None
+    if world > 1 and not args.no_balance:
+        # untimed, before the warm-up: two rounds of load balancing.  Each rank times its own compute (no all-reduce), the times are
+        # all-gathered, and every rank derives the same uneven i-block ranges (sharding.balance_block_ranges): ranks that carry a PME
+        # grid hand direct-space blocks to ranks that do not.
+        for _ in range(2):
+            eng.sync(); torch.cuda.synchronize(); eng.reset_timers()
+            tb = time.perf_counter()
+            for i in range(48):
+                torch.add(pos0, jit, alpha=math.sin(0.37 * i), out=pos)
+                eng.set_positions_device(pos.data_ptr(), is_double); eng.execute(False)
+            eng.sync(); torch.cuda.synchronize()
+            ms = (time.perf_counter() - tb) * 1e3 / 48
+            stb = eng.stats()
+            d = stb.sum_direct_ms / max(stb.n_timed, 1)
+            mine = torch.tensor([d, max(ms - d, 0.0)], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            times = [[float(x) for x in t.tolist()] for t in every]
+            block_ranges, period = pkg.sharding.balance_block_ranges([t[0] for t in times], [t[1] for t in times])
+            eng.set_shard_blocks(block_ranges[rank][0], block_ranges[rank][1], period)
     for i in range(1, args.warmup + 1):
         fenced_step(i)
     eng.sync(); torch.cuda.synchronize()
@@ -396,8 +421,10 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_file) + ": " + rec["formula"]
         except Exception as exc:   # a malformed summary must not hide the measurement
             out["roofline"]["traffic_source"] = "unreadable %s (%s)" % (pmc_file, exc)
+    if block_ranges is not None:
+        out["config"]["i_block_ranges_of_128"] = [list(r) for r in block_ranges]
     if world > 1 and cfg_name in ONE_GPU_NS_DAY:
-        # the N > 1 line runs the 8-subset box of BASELINE.json's multi-GPU config; its own 1-GPU rate (not the 4-subset headline's) is the fair yardstick
+        # the 1-GPU rate of the SAME workload (c3 by default; c4 is the 8-subset box of BASELINE.json's multi-GPU config)
         out["config"]["one_gpu_value_same_workload"] = ONE_GPU_NS_DAY[cfg_name]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: the same workload generator at 24k atoms (same density, cutoff, alpha, grid spacing), a few evaluations

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SNB_ABI_VERSION 2
+#define SNB_ABI_VERSION 3
 
 typedef struct snb_engine* snb_handle;
 
@@ -141,6 +141,12 @@ snb_status snb_get_forces(snb_handle h, void* out, int32_t is_device, int32_t is
  * snb_get_forces on the same pointer is a no-op.  out == NULL switches this off.  (The reference's execute() adds into the
  * platform's force buffer itself, NonbondedSlicingKernels.h:59; this is that behaviour without an extra launch per step.) */
 snb_status snb_set_force_output(snb_handle h, void* out, int32_t is_double, int32_t accumulate);
+/* Optional, sharded engines: direct-space ownership of the 32-atom i-blocks.  The engine evaluates the tiles of block I when
+ * I % period lies in [begin, end); the default is (shard_rank, shard_rank + 1, shard_count).  The ranges of all ranks must partition
+ * [0, period).  Lets the host shift direct-space work away from ranks that carry PME grids (the role of the load balancing between
+ * devices in OpenMM's parallel kernels, which the reference inherits from its platform); takes effect with a neighbour rebuild at
+ * the next snb_execute.  An empty range (begin == end) is allowed. */
+snb_status snb_set_shard_blocks(snb_handle h, int32_t begin, int32_t end, int32_t period);
 /* Raw (unscaled) energies of the last execute with include_energy: out[S][2] = (Coulomb, vdW). */
 snb_status snb_get_slice_energies(snb_handle h, double* out);
 snb_status snb_synchronize(snb_handle h);

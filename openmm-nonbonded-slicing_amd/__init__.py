@@ -16,6 +16,11 @@ def __getattr__(name):
         import importlib
         if name == "capi":
             return importlib.import_module(__name__ + "._capi")
+    if name == "sharding":
+        import importlib
+        return importlib.import_module(__name__ + ".sharding")
+    if name in ("HipCalcSlicedNonbondedForceKernel", "Context", "System", "State"):
+        import importlib
         mod = importlib.import_module(__name__ + ".context")
         return getattr(mod, name)
     raise AttributeError(name)

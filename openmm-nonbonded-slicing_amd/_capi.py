@@ -11,13 +11,13 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsnb_hip.so")
-SNB_ABI_VERSION = 2
+SNB_ABI_VERSION = 3
 
 # every symbol include/snb.h declares (tests check the library exports each one)
 SYMBOLS = [
     "snb_create", "snb_destroy", "snb_last_error", "snb_set_particles", "snb_set_exceptions", "snb_set_lambdas",
     "snb_set_dispersion_coefficients", "snb_compute_dispersion_coefficients", "snb_set_box", "snb_set_positions",
-    "snb_rebuild_neighbors", "snb_execute", "snb_get_forces", "snb_set_force_output", "snb_get_slice_energies", "snb_synchronize",
+    "snb_rebuild_neighbors", "snb_execute", "snb_get_forces", "snb_set_force_output", "snb_set_shard_blocks", "snb_get_slice_energies", "snb_synchronize",
     "snb_get_pme_parameters", "snb_get_ljpme_parameters", "snb_get_stats", "snb_reset_timers", "snb_legal_grid_size", "snb_abi_version",
     "snb_test_fft3d",
 ]
@@ -82,6 +82,7 @@ def lib():
     L.snb_execute.argtypes = [vp, i32, i32, i32, i32, dp]
     L.snb_get_forces.argtypes = [vp, vp, i32, i32, i32]
     L.snb_set_force_output.argtypes = [vp, vp, i32, i32]
+    L.snb_set_shard_blocks.argtypes = [vp, i32, i32, i32]
     L.snb_get_slice_energies.argtypes = [vp, dp]
     L.snb_synchronize.argtypes = [vp]
     L.snb_get_pme_parameters.argtypes = [vp, dp, ip]

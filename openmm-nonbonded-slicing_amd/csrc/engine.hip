@@ -60,6 +60,7 @@ struct EngineBase {
     virtual void execute(int, int, int, int, double*) = 0;
     virtual void getForces(void*, int, int, int) = 0;
     virtual void setForceOutput(void*, int, int) = 0;
+    virtual void setShardBlocks(int, int, int) = 0;
     virtual void getSliceEnergies(double*) = 0;
     virtual void sync() = 0;
     virtual void getStats(snb_stats*) = 0;
@@ -216,6 +217,15 @@ public:
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
+    // direct-space ownership: i-block I belongs to this engine when I % shardPeriod lies in [shardBegin, shardEnd); the default is
+    // (shard_rank, shard_rank + 1, shard_count); snb_set_shard_blocks lets the host rebalance direct-space work between ranks
+    int shardBegin = 0, shardEnd = 1, shardPeriod = 1;
+    bool ownsBlock(int b) const { const int r = b % shardPeriod; return r >= shardBegin && r < shardEnd; }
+    void setShardBlocks(int begin, int end, int period) override {
+        if (period < 1 || begin < 0 || end < begin || end > period) throw std::runtime_error("snb_set_shard_blocks: need 0 <= begin <= end <= period");
+        if (begin == shardBegin && end == shardEnd && period == shardPeriod) return;
+        shardBegin = begin; shardEnd = end; shardPeriod = period; needRebuild = true;
+    }
     bool valuesDirty = false, excValuesDirty = false, haveExceptions = false;   // parameter values changed, structure did not
     // displacement watch: reference positions of the last rebuild and two flags in mapped host memory (read without synchronising)
     DevBuf<T4> posRef; int* hDispFlags = nullptr; int* dDispFlags = nullptr; int64_t listOverruns = 0;
@@ -242,6 +252,7 @@ public:
         lambdas.assign((size_t)S * 2, 1.0); dispCoef.assign(S, 0.0); hostSliceE.assign((size_t)S * 2, 0.0);
         sliceE.resize((size_t)S * 2 * SNB_SLICE_E_PARTS);
         if (cfg.shard_count < 1) cfg.shard_count = 1;
+        shardBegin = cfg.shard_count > 1 ? cfg.shard_rank : 0; shardEnd = shardBegin + 1; shardPeriod = cfg.shard_count;
         // tabulated Ewald force factor: opt-in.  Measured on MI355X it only trades 4 % of the VALU instructions for LDS gathers (the packed
         // analytic erfc is already cheap) and leaves the kernel time unchanged, so the analytic form stays the default.
         if (cfg.method >= SNB_Ewald) buildEwaldPoly();
@@ -667,7 +678,7 @@ public:
         // evaluates identically, whatever order its own builder emitted the items in
         shardTiles = 0;
         for (int b = 0; b < numBlocks; b++) {
-            if (b % cfg.shard_count != cfg.shard_rank) continue;
+            if (!ownsBlock(b)) continue;
             shardTiles += hBlockTiles[b].y;
             for (int o = 0; o < hBlockTiles[b].y; o += CH) hWork.push_back(make_int4(b, hBlockTiles[b].x + o, std::min(CH, hBlockTiles[b].y - o), 0));
         }
@@ -852,7 +863,7 @@ public:
         for (int attempt = 0; attempt < 3; attempt++) {
             tileJ.resize(tileCap * 32); tileInfo.resize(tileCap); masks.resize(tileCap * 32); workItems.resize(2 * (tileCap / 4 + 2 * numBlocks + 64)); workItemsStage.resize(tileCap / 4 + 2 * numBlocks + 64); workItemsPartial.resize(tileCap / 4 + 2 * numBlocks + 64);
             p.nPadded = Npad; p.nBlocks = numBlocks; p.blockSubset = blockSubset.p;
-            p.shardRank = cfg.shard_rank; p.shardCount = cfg.shard_count;
+            p.shardBegin = shardBegin; p.shardWidth = shardEnd - shardBegin; p.shardPeriod = shardPeriod;
             p.blockCenter = dBlockCenter.p; p.blockHalf = dBlockHalf.p;
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;
@@ -1043,7 +1054,8 @@ public:
         }
         PairListParams<Real> q;
         std::memset(&q, 0, sizeof(q));
-        const bool haveLists = includeDirect && cfg.shard_rank == 0;   // O(N) pair lists: rank 0 only when sharded
+        // O(N) pair lists: one rank only when sharded -- the LAST one, which carries no PME grid once there are more ranks than grids
+        const bool haveLists = includeDirect && cfg.shard_rank == cfg.shard_count - 1;
         if (haveLists) {
             q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.sliceE = sliceE.p; q.lambdas = dLambdas.p;
             const bool exPeriodic = (cfg.method == SNB_NoCutoff || cfg.method == SNB_CutoffNonPeriodic) ? false : cfg.exceptions_periodic != 0;
@@ -1309,6 +1321,7 @@ snb_status snb_get_forces(snb_handle h, void* out, int32_t isDevice, int32_t isD
     if (!out) return SNB_ERR_INVALID_ARGUMENT;
     return guard(h, [&] { h->impl->getForces(out, isDevice, isDouble, acc); });
 }
+snb_status snb_set_shard_blocks(snb_handle h, int32_t begin, int32_t end, int32_t period) { return guard(h, [&] { h->impl->setShardBlocks(begin, end, period); }); }
 snb_status snb_set_force_output(snb_handle h, void* out, int32_t isDouble, int32_t acc) { return guard(h, [&] { h->impl->setForceOutput(out, isDouble, acc); }); }
 snb_status snb_get_slice_energies(snb_handle h, double* out) { if (!out) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->getSliceEnergies(out); }); }
 snb_status snb_synchronize(snb_handle h) { return guard(h, [&] { h->impl->sync(); }); }

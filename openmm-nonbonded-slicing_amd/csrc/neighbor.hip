@@ -253,9 +253,10 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     __shared__ int s_cmb[4][3][64];      // candidate runs of the current batch of (column, z image) combinations: start, exclusive prefix, image code
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // sharded engines build only the i-blocks they own, I % shardCount == shardRank (a deterministic rule, the same on every rank);
-    // the grid is sized for the owned blocks so that every wave of a work-group has work
-    const int I = (blockIdx.x * 4 + wid) * p.shardCount + p.shardRank;
+    // sharded engines build only the i-blocks they own, I % shardPeriod in [shardBegin, shardBegin + shardWidth) (a deterministic
+    // rule, the same on every rank); the grid is sized for the owned blocks so that every wave of a work-group has work
+    const int kOwned = blockIdx.x * 4 + wid;
+    const int I = (kOwned / p.shardWidth) * p.shardPeriod + p.shardBegin + kOwned % p.shardWidth;
     if (I >= p.nBlocks) return;
     const long long tStart = p.dbgOut ? (long long)wall_clock64() : 0;
     int* list = s_list[wid];
@@ -583,8 +584,8 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipSt
         hipLaunchKernelGGL((k_nbPad<Real>), dim3((p.nPadded + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbZPrefix<Real>), dim3((p.nSubsets * p.ncx * p.ncy + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbBounds<Real>), dim3((p.nBlocks + 7) / 8), block, 0, s, p);
-        const int nOwned = (p.nBlocks - p.shardRank + p.shardCount - 1) / p.shardCount;
-        hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((nOwned + 3) / 4), block, 0, s, p);
+        const int nOwned = (p.nBlocks / p.shardPeriod) * p.shardWidth + std::min(std::max(p.nBlocks % p.shardPeriod - p.shardBegin, 0), p.shardWidth);
+        if (nOwned > 0) hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((nOwned + 3) / 4), block, 0, s, p);
         hipLaunchKernelGGL((k_nbCompactWork<Real>), dim3(2 * NB_PARTS), block, 0, s, p);
     }
 }

@@ -164,7 +164,7 @@ template <typename Real> struct NbParams {
     int* counters;   // [32 * 65]: line 0 = totals ([0] tiles, [1] full work items, [2] masks, [3] overflow events, [4] partial items, [5] max tiles|masks and
                      // [6] max work items of a partition), lines 1..64 = the partitions' allocation counters (same slots)
     int tileCapacity, workCapacity, maskCapacity;
-    int shardRank, shardCount;   // tiles and work items are built only for i-blocks with block % shardCount == shardRank
+    int shardBegin, shardWidth, shardPeriod;   // tiles and work items are built only for i-blocks with block % shardPeriod in [shardBegin, shardBegin + shardWidth)
     long long* dbgOut;   // SNB_NB_TRACE: per-block start/end wall_clock64 stamps (100 MHz) of the tile builder
 };
 void launchExtent(const void* userPos, int isDouble, int stride4, int n, int* ext, hipStream_t s);   // ext[6]: ordered-int min xyz, max xyz

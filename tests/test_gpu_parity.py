@@ -464,6 +464,39 @@ def test_bench_workload_24k_vs_oracle(snb):
         assert ferr < tol and eerr < tol, (prec, ferr, eerr)
 
 
+
+def test_uneven_shard_block_ranges_sum_to_unsharded(snb, oev):
+    """snb_set_shard_blocks (include/snb.h): three engines with uneven i-block ranges, one of them empty, one re-ranged after its
+    first evaluation, still add up to the full result (the load-balanced decomposition bench.py --gpus N uses)."""
+    import torch
+    import bench
+    w = bench.build_workload(12000, 4.932, 4, np.random.default_rng(bench.SEED))
+    fo, so, _, _ = bench.oracle_eval(w, 4, 42, 0)
+    n = len(w["q"])
+    pos = torch.tensor(w["pos"], dtype=torch.float64, device="cuda")
+    ftot = np.zeros((n, 3)); etot = np.zeros_like(so)
+    ranges = [(0, 0), (0, 5), (5, 16)]
+    for rank in range(3):
+        eng = bench.Engine(snb, w, 4, 42, 0, "double", 0, rank, 3, 0.05, 1 << 30)
+        forces = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+        eng.set_positions_device(pos.data_ptr(), True)
+        if rank == 2:
+            eng.execute(True); eng.sync()          # first with the default ownership, then re-ranged: the lists must be rebuilt
+        eng.set_shard_blocks(ranges[rank][0], ranges[rank][1], 16)
+        eng.execute(True); eng.forces_to(forces.data_ptr(), True); eng.sync()
+        ftot += forces.cpu().numpy(); etot += eng.slice_energies(so.shape[0])
+        if rank == 0:
+            assert eng.stats().n_tiles == 0
+        eng.close()
+    ferr = np.max(np.linalg.norm(ftot - fo, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0))
+    eerr = np.max(np.abs(etot - so) / np.maximum(np.abs(so), 1.0))
+    assert ferr < 1e-5 and eerr < 1e-5, (ferr, eerr)
+    eng = bench.Engine(snb, w, 4, 42, 0, "single", 0, 0, 2, 0.05, 1 << 30)
+    with pytest.raises(RuntimeError):
+        eng.set_shard_blocks(3, 2, 4)
+    eng.close()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_engines_sum_to_unsharded(world, snb, oev):
     """The multi-GPU decomposition rehearsed on ONE GPU: `world` engines with shard_rank 0..world-1 evaluate the
