@@ -303,7 +303,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # SNB_BENCH_REHEARSE=1: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (ranks share devices, gloo carries the
+        # collectives through the host) -- exercises the code path, its numbers mean nothing.  The measured run is RCCL, one rank per GPU.
+        if os.environ.get("SNB_BENCH_REHEARSE"):
+            local = local % torch.cuda.device_count()
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # N > 1 shards the SAME headline workload (strong scaling: 4 subset grids over min(N, 4) ranks, i-blocks over all N ranks); the
