@@ -680,7 +680,7 @@ public:
         for (int b = 0; b < numBlocks; b++) {
             if (!ownsBlock(b)) continue;
             shardTiles += hBlockTiles[b].y;
-            for (int o = 0; o < hBlockTiles[b].y; o += CH) hWork.push_back(make_int4(b, hBlockTiles[b].x + o, std::min(CH, hBlockTiles[b].y - o), 0));
+            for (int o = 0; o < hBlockTiles[b].y; o += CH) hWork.push_back(make_int4(b, hBlockTiles[b].x + o, std::min(CH, hBlockTiles[b].y - o), blkSubset[b]));
         }
         std::stable_sort(hWork.begin(), hWork.end(), [&](const int4& a, const int4& b) { return a.z > b.z; });
         numWorkItems = (int)hWork.size();
@@ -864,6 +864,7 @@ public:
             tileJ.resize(tileCap * 32); tileInfo.resize(tileCap); masks.resize(tileCap * 32); workItems.resize(2 * (tileCap / 4 + 2 * numBlocks + 64)); workItemsStage.resize(tileCap / 4 + 2 * numBlocks + 64); workItemsPartial.resize(tileCap / 4 + 2 * numBlocks + 64);
             p.nPadded = Npad; p.nBlocks = numBlocks; p.blockSubset = blockSubset.p;
             p.shardBegin = shardBegin; p.shardWidth = shardEnd - shardBegin; p.shardPeriod = shardPeriod;
+            { static const bool boxOnly = getenv("SNB_BOX_PRUNE") != nullptr; p.exactPrune = boxOnly ? 0 : 1; }
             p.blockCenter = dBlockCenter.p; p.blockHalf = dBlockHalf.p;
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;
@@ -896,6 +897,15 @@ public:
             }
             if (h[3] == 0) {
                 numTiles = h[0]; numWorkItems = h[1] + h[4]; numMaskTiles = h[2]; wrapMode = false;
+                if (getenv("SNB_DEBUG_WORK")) {      // consistency of the work list: the items must cover every tile exactly once
+                    std::vector<int4> hw(numWorkItems);
+                    HIPCHECK(hipMemcpy(hw.data(), workItems.p, sizeof(int4) * numWorkItems, hipMemcpyDeviceToHost));
+                    long long sumZ = 0; int hist[9] = {0};
+                    for (auto& w : hw) { sumZ += w.z; hist[std::min(std::max(w.z, 0), 8)]++; }
+                    fprintf(stderr, "[snb] work list: %d items (%d full + %d partial), tiles %d, sum of item sizes %lld, sizes 1..8:", numWorkItems, h[1], h[4], (int)numTiles, sumZ);
+                    for (int k = 1; k <= 8; k++) fprintf(stderr, " %d", hist[k]);
+                    fprintf(stderr, "\n");
+                }
                 shardTiles = numTiles;      // the builder only emitted the blocks this engine owns
                 gpuBuilt = true;
                 needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;

@@ -251,6 +251,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     __shared__ int s_qrow[4][128];       // ... and the i-row each belongs to
     __shared__ int s_imgI[4][27][5]; __shared__ float s_imgF[4][27][2];      // surviving lattice images of the block (see below)
     __shared__ int s_cmb[4][3][64];      // candidate runs of the current batch of (column, z image) combinations: start, exclusive prefix, image code
+    __shared__ float4 s_ipos[4][32];     // the block's own atoms (exact pruning of the gathered list)
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // sharded engines build only the i-blocks they own, I % shardPeriod in [shardBegin, shardBegin + shardWidth) (a deterministic
@@ -364,8 +365,9 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
             if (t < nT && ((anyBits >> t) & 1ull)) p.masks[(size_t)(mi0 + __popcll(anyBits & ((1ull << t) - 1ull))) * 32 + il] = mask[t][il];
         }
         for (int t = lane; t < nT; t += 64) p.tileInfo[first + t] = make_int4(tileSub[t], ((anyBits >> t) & 1ull) ? mi0 + __popcll(anyBits & ((1ull << t) - 1ull)) : -1, 0, 0);
-        for (int k = lane; k < nFull; k += 64) p.workItemsStage[w0 + k] = make_int4(I, first + 8 * k, 8, 0);
-        if (nPart && lane == 0) p.workItemsPartial[wp] = make_int4(I, first + 8 * nFull, nT & 7, 0);
+        const int subI = p.blockSubset[I];      // carried in the work item: the pair kernel needs it before the block's atoms arrive
+        for (int k = lane; k < nFull; k += 64) p.workItemsStage[w0 + k] = make_int4(I, first + 8 * k, 8, subI);
+        if (nPart && lane == 0) p.workItemsPartial[wp] = make_int4(I, first + 8 * nFull, nT & 7, subI);
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -409,6 +411,46 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // Exact pruning.  The box test admits every atom within R of the block's bounding box; an atom only belongs in the list if it is
+    // within R of one of the block's ATOMS, which removes about a sixth of them (and with them a sixth of the pair kernel's tiles).
+    // The entries gathered since the last call are re-tested densely (64 survivors of the box test per pass) and compacted in place.
+    float4* ipos = s_ipos[wid];
+    const bool exact = p.exactPrune != 0;
+    if (lane < 32) { const auto q = p.posq[I * 32 + lane]; ipos[lane] = make_float4((float)q.x, (float)q.y, (float)q.z, 0.f); }
+    int filtered = 32;                                    // list[0 .. filtered) has been through the exact test (the diagonal tile needs none)
+    auto exactFilter = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int out = filtered;
+        for (int b0 = filtered; b0 < count; b0 += 64) {
+            const int k = b0 + lane;
+            bool keep = k < count;
+            const int e = keep ? list[k] : 0;
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (keep) {
+                const int sc = (e >> SNB_JSHIFT_BITS) & 127;
+                const int kx = sc / 25 - 2, ky = (sc % 25) / 5 - 2, kz = sc % 5 - 2;
+                const auto q = p.posq[e & SNB_JIDX_MASK];
+                px = (float)q.x + kx * Lt.ax + ky * Lt.bx + kz * Lt.cx; py = (float)q.y + ky * Lt.by + kz * Lt.cy; pz = (float)q.z + kz * Lt.cz;
+            }
+            float best = 3e38f;
+#pragma unroll 8
+            for (int a = 0; a < 32; a++) {
+                const float4 xi = ipos[a];                // LDS broadcast
+                const float ddx = px - xi.x, ddy = py - xi.y, ddz = pz - xi.z;
+                best = fminf(best, ddx * ddx + ddy * ddy + ddz * ddz);
+            }
+            keep = keep && best < R2;
+            __builtin_amdgcn_wave_barrier();             // every lane has read its entry before the slots below it are rewritten
+            const unsigned long long m = __ballot(keep);
+            if (keep) list[out + lanePrefix(m)] = e;
+            out += __popcll(m);
+        }
+        count = out; filtered = out;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
     for (int s = 0; s < p.nSubsets && !failed; s++) {
         int segStart = count;
         const int2* ranges = p.colRange + (size_t)s * p.ncx * p.ncy;
@@ -456,13 +498,14 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
                 }
                 const unsigned long long m = __ballot(ok);
                 const int nNew = __popcll(m);
+                if (count + nNew > NB_CAP - 32 && exact) exactFilter();      // make room first
                 if (count + nNew > NB_CAP - 32) {
                     // list full: close the current segment, publish this chunk and start a fresh list
                     const int padded = (count + 31) & ~31;
                     for (int k = count + lane; k < padded; k += 64) list[k] = -1;
                     for (int t = (segStart >> 5) + lane; t < (padded >> 5); t += 64) tileSub[t] = s;
                     flush(padded, hasDiag);
-                    hasDiag = false; count = 0; segStart = 0;
+                    hasDiag = false; count = 0; segStart = 0; filtered = 0;
                 }
                 if (ok) list[count + lanePrefix(m)] = j | (code << SNB_JSHIFT_BITS);
                 count += nNew;
@@ -499,11 +542,12 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
             }
         }
         if (nCmb > 0 && !failed) runCandidates();
+        if (exact && !failed) exactFilter();
         // close the subset segment: pad to a whole tile, record the tiles' subset
         const int padded = (count + 31) & ~31;
         for (int k = count + lane; k < padded; k += 64) list[k] = -1;
         for (int t = (segStart >> 5) + lane; t < (padded >> 5); t += 64) tileSub[t] = s;
-        count = padded;
+        count = padded; filtered = padded;
     }
     const long long tGather = p.dbgOut ? (long long)wall_clock64() : 0;
     if (!failed && count > 0) flush(count, hasDiag);
