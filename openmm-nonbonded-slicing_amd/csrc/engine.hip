@@ -828,6 +828,7 @@ public:
         std::memset(&p, 0, sizeof(p));
         p.nAtoms = N; p.nSubsets = nsub; p.ncx = ncx; p.ncy = ncy;
         p.subsetBits = 1; while ((1 << p.subsetBits) < nsub) p.subsetBits++;
+        p.colBits = 1; while ((1ll << p.colBits) < (long long)ncx * ncy) p.colBits++;
         for (int i = 0; i < 9; i++) p.boxm[i] = box[i];
         for (int d = 0; d < 3; d++) p.origin[d] = origin[d];
         for (int i = 0; i < 9; i++) tileCell[i] = box[i];

@@ -67,7 +67,7 @@ __global__ void k_nbKeys(const NbParams<Real> p, const In* __restrict__ userPos,
     double zf = fz; zf = zf < 0 ? 0 : (zf > 1 ? 1 : zf);
     if (serp & 1) zf = 1.0 - zf;
     const unsigned long long zq = (unsigned long long)(zf * 1048575.0);
-    p.keysIn[u] = ((unsigned long long)p.uSubset[u] << 44) | ((unsigned long long)serp << 20) | zq;
+    p.keysIn[u] = ((unsigned long long)p.uSubset[u] << (20 + p.colBits)) | ((unsigned long long)serp << 20) | zq;      // only the bits in use are sorted
     p.valsIn[u] = u;
 }
 
@@ -82,7 +82,7 @@ template <typename Real> __global__ void k_nbJumpFlags(const NbParams<Real> p) {
     if (t >= p.nAtoms) return;
     bool start = t == 0;
     if (!start) {
-        start = (p.keysOut[t] >> 44) != (p.keysOut[t - 1] >> 44);
+        start = (p.keysOut[t] >> (20 + p.colBits)) != (p.keysOut[t - 1] >> (20 + p.colBits));
         if (!start) {
             const int u = p.valsOut[t], v = p.valsOut[t - 1];
             float dx = (float)p.wrapped[3 * (size_t)u] - (float)p.wrapped[3 * (size_t)v], dy = (float)p.wrapped[3 * (size_t)u + 1] - (float)p.wrapped[3 * (size_t)v + 1],
@@ -125,8 +125,8 @@ template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     if (t >= p.nAtoms) return;
     const unsigned long long key = p.keysOut[t];
     const int u = p.valsOut[t];
-    const int s = (int)(key >> 44);
-    const int serp = (int)((key >> 20) & 0xFFFFFF);
+    const int s = (int)(key >> (20 + p.colBits));
+    const int serp = (int)((key >> 20) & ((1u << p.colBits) - 1u));
     const int si = t + p.padBefore[t];
     if ((si & 31) == 0) p.blockSubset[si >> 5] = s;
     p.sortedToUser[si] = u; p.userToSorted[u] = si;
@@ -251,7 +251,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     __shared__ int s_qrow[4][128];       // ... and the i-row each belongs to
     __shared__ int s_imgI[4][27][5]; __shared__ float s_imgF[4][27][2];      // surviving lattice images of the block (see below)
     __shared__ int s_cmb[4][3][64];      // candidate runs of the current batch of (column, z image) combinations: start, exclusive prefix, image code
-    __shared__ float4 s_ipos[4][32];     // the block's own atoms (exact pruning of the gathered list)
+    __shared__ float4 s_ipos[4][16]; __shared__ float2 s_iposZ[4][16];     // the block's own atoms, two per entry: (x0, x1, y0, y1) and (z0, z1) (exact pruning of the gathered list)
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // sharded engines build only the i-blocks they own, I % shardPeriod in [shardBegin, shardBegin + shardWidth) (a deterministic
@@ -414,9 +414,12 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     // Exact pruning.  The box test admits every atom within R of the block's bounding box; an atom only belongs in the list if it is
     // within R of one of the block's ATOMS, which removes about a sixth of them (and with them a sixth of the pair kernel's tiles).
     // The entries gathered since the last call are re-tested densely (64 survivors of the box test per pass) and compacted in place.
-    float4* ipos = s_ipos[wid];
+    float4* ipos = s_ipos[wid]; float2* iposZ = s_iposZ[wid];
     const bool exact = p.exactPrune != 0;
-    if (lane < 32) { const auto q = p.posq[I * 32 + lane]; ipos[lane] = make_float4((float)q.x, (float)q.y, (float)q.z, 0.f); }
+    if (lane < 16) {
+        const auto q0 = p.posq[I * 32 + 2 * lane], q1 = p.posq[I * 32 + 2 * lane + 1];
+        ipos[lane] = make_float4((float)q0.x, (float)q1.x, (float)q0.y, (float)q1.y); iposZ[lane] = make_float2((float)q0.z, (float)q1.z);
+    }
     int filtered = 32;                                    // list[0 .. filtered) has been through the exact test (the diagonal tile needs none)
     auto exactFilter = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -434,11 +437,13 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
                 px = (float)q.x + kx * Lt.ax + ky * Lt.bx + kz * Lt.cx; py = (float)q.y + ky * Lt.by + kz * Lt.cy; pz = (float)q.z + kz * Lt.cz;
             }
             float best = 3e38f;
+            typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll 8
-            for (int a = 0; a < 32; a++) {
-                const float4 xi = ipos[a];                // LDS broadcast
-                const float ddx = px - xi.x, ddy = py - xi.y, ddz = pz - xi.z;
-                best = fminf(best, ddx * ddx + ddy * ddy + ddz * ddz);
+            for (int a = 0; a < 16; a++) {                // two i-atoms per pass (packed fp32), LDS broadcast reads
+                const float4 xy = ipos[a]; const float2 zz = iposZ[a];
+                const v2f ddx = v2f{xy.x, xy.y} - px, ddy = v2f{xy.z, xy.w} - py, ddz = v2f{zz.x, zz.y} - pz;
+                const v2f d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                best = fminf(best, fminf(d2.x, d2.y));
             }
             keep = keep && best < R2;
             __builtin_amdgcn_wave_barrier();             // every lane has read its entry before the slots below it are rewritten
@@ -555,6 +560,16 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     if (p.dbgOut && lane == 0) { p.dbgOut[2 * I] = tStart; p.dbgOut[2 * I + 1] = (long long)wall_clock64(); p.dbgOut[2 * p.nBlocks + 2 * I] = tProlog; p.dbgOut[2 * p.nBlocks + 2 * I + 1] = tGather; }
 }
 
+// ---- clears of phase B: builder counters (not [7], the padded count of phase A), column ranges, z index (large = unset), user map ----
+template <typename Real> __global__ void k_nbClear(const NbParams<Real> p) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nCols = (size_t)p.nSubsets * p.ncx * p.ncy;
+    if (i < 7 || (i >= 32 && i < (size_t)32 * (1 + NB_PARTS))) p.counters[i] = 0;
+    if (i < nCols) p.colRange[i] = make_int2(0, 0);
+    if (i < nCols * 65) p.zIndex[i] = 0x7F7F7F7F;
+    if (i < (size_t)p.nPadded) p.sortedToUser[i] = -1;
+}
+
 // ---- 5. work items of the 64 partitions -> one contiguous array, full (8-tile) items first; totals into counters[0..7] ------------
 template <typename Real> __global__ __launch_bounds__(256) void k_nbCompactWork(const NbParams<Real> p) {
     __shared__ int s_off[2][NB_PARTS + 1];
@@ -600,7 +615,7 @@ template <typename Real> void launchNeighborSort(const NbParams<Real>& p, const 
     if (n <= 0) return;
     if (isDouble) hipLaunchKernelGGL((k_nbKeys<Real, double>), gridN, block, 0, s, p, (const double*)userPos, stride);
     else hipLaunchKernelGGL((k_nbKeys<Real, float>), gridN, block, 0, s, p, (const float*)userPos, stride);
-    (void)rocprim::radix_sort_pairs(sortTemp, sortTempBytes, p.keysIn, p.keysOut, p.valsIn, p.valsOut, (size_t)n, 0, 44 + p.subsetBits, s);
+    (void)rocprim::radix_sort_pairs(sortTemp, sortTempBytes, p.keysIn, p.keysOut, p.valsIn, p.valsOut, (size_t)n, 0, 20 + p.colBits + p.subsetBits, s);
     (void)hipMemsetAsync(p.blockWideOut, 0, sizeof(int) * (size_t)n, s);
     NbParams<Real> p0 = p;
     p0.blockWide = nullptr;                                 // pass 1: subset boundaries and jumps
@@ -618,11 +633,11 @@ template <typename Real> void launchNeighborSort(const NbParams<Real>& p, const 
 template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipStream_t s) {
     const int n = p.nAtoms;
     dim3 block(256), gridN((n + 255) / 256);
-    (void)hipMemsetAsync(p.counters, 0, sizeof(int) * 7, s);
-    (void)hipMemsetAsync(p.counters + 32, 0, sizeof(int) * 32 * NB_PARTS, s);
-    (void)hipMemsetAsync(p.colRange, 0, sizeof(int2) * (size_t)p.nSubsets * p.ncx * p.ncy, s);
-    (void)hipMemsetAsync(p.zIndex, 0x7F, sizeof(int) * (size_t)p.nSubsets * p.ncx * p.ncy * 65, s);
-    (void)hipMemsetAsync(p.sortedToUser, 0xFF, sizeof(int) * (size_t)p.nPadded, s);
+    {   // one launch instead of five memset nodes (each costs ~10 us of launch gap at this point of the rebuild)
+        const size_t nCols = (size_t)p.nSubsets * p.ncx * p.ncy;
+        const size_t most = std::max(std::max(nCols * 65, (size_t)p.nPadded), (size_t)32 * (1 + NB_PARTS));
+        hipLaunchKernelGGL((k_nbClear<Real>), dim3((unsigned)((most + 255) / 256)), block, 0, s, p);
+    }
     if (n > 0) {
         hipLaunchKernelGGL((k_nbScatter<Real>), gridN, block, 0, s, p);
         hipLaunchKernelGGL((k_nbPad<Real>), dim3((p.nPadded + 255) / 256), block, 0, s, p);

@@ -139,7 +139,7 @@ template <typename Real> void launchEwald(const EwaldParams<Real>& p, hipStream_
 
 // GPU neighbour build (neighbor.hip)
 template <typename Real> struct NbParams {
-    int nAtoms, nPadded, nBlocks, nSubsets, subsetBits, ncx, ncy;
+    int nAtoms, nPadded, nBlocks, nSubsets, subsetBits, colBits, ncx, ncy;      // sort key = subset | serpentine column (colBits) | z (20 bits)
     double boxm[9];  // periodic cell, rows a, b, c in OpenMM's reduced (lower-triangular) form
     double origin[3];  // subtracted from the user positions before wrapping (the enclosing cell of a non-periodic system; else 0)
     float listCutoff;
