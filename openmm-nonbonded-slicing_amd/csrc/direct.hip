@@ -14,6 +14,7 @@
 // lambda scaling costs two multiplies per TILE and per-slice energies are two accumulators per tile -- there is no
 // per-pair slice arithmetic at all (the reference computes the slice index and loads LAMBDA[slice] per pair).
 #include "snb_internal.h"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -546,7 +547,11 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
 }
 
 
-template <typename Real, int MC> static bool launchDirectMC(const DirectParams<Real>& p, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s) {
+// evStart/evStop (both or neither): hipExtLaunchKernelGGL stamps them with the kernel's own begin and end -- the duration rocprofv3 reports,
+// without the marker-packet overhead of hipEventRecord pairs around the launch.  *timed tells the caller whether a kernel took them.
+#define SNB_LAUNCH(KERNEL, GRID, ...) do { if (evStart) { hipExtLaunchKernelGGL(KERNEL, GRID, block, 0, s, evStart, evStop, 0, __VA_ARGS__); *timed = true; } \
+                                           else hipLaunchKernelGGL(KERNEL, GRID, block, 0, s, __VA_ARGS__); } while (0)
+template <typename Real, int MC> static bool launchDirectMC(const DirectParams<Real>& p, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s, hipEvent_t evStart, hipEvent_t evStop, bool* timed) {
     const int myItems = p.numWork;
     if (myItems <= 0) return false;
     int nwg = (myItems + 3) / 4;
@@ -561,7 +566,7 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
             if (lists && !energy) { q = *lists; nExclBlocks = (q.nExclAtoms + 255) / 256; nListBlocks = nExclBlocks + (q.n + 255) / 256; }   // the energy pair lists need their LDS reduction: own launch
             dim3 gridAll(nwg + nListBlocks);
             const bool poly = (MC == MC_EWALD || MC == MC_LJPME) && p.ewUsePoly;
-#define SNB_PACKED(P, E, S) hipLaunchKernelGGL((k_directPacked<MC, P, E, S>), gridAll, block, 0, s, p, q, nExclBlocks, nListBlocks)
+#define SNB_PACKED(P, E, S) SNB_LAUNCH((k_directPacked<MC, P, E, S>), gridAll, p, q, nExclBlocks, nListBlocks)
             if constexpr (MC == MC_NOCUTOFF) { if (energy) SNB_PACKED(false, true, false); else SNB_PACKED(false, false, false); }
             else if (p.useSwitch && MC != MC_LJPME) {      // (no switching function under LJPME, Q2)
                 if (energy) { if (poly) SNB_PACKED(true, true, true); else SNB_PACKED(false, true, true); }
@@ -575,28 +580,28 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
         }
     }
     if (wrap) {
-        if (energy) hipLaunchKernelGGL((k_direct<Real, MC, true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((k_direct<Real, MC, true, false>), grid, block, 0, s, p);
+        if (energy) SNB_LAUNCH((k_direct<Real, MC, true, true>), grid, p);
+        else SNB_LAUNCH((k_direct<Real, MC, true, false>), grid, p);
     } else {
-        if (energy) hipLaunchKernelGGL((k_direct<Real, MC, false, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((k_direct<Real, MC, false, false>), grid, block, 0, s, p);
+        if (energy) SNB_LAUNCH((k_direct<Real, MC, false, true>), grid, p);
+        else SNB_LAUNCH((k_direct<Real, MC, false, false>), grid, p);
     }
     return false;
 }
 
 // Returns true when the launch also ran the pair lists passed in `lists` (single-precision forces-only tile kernel); otherwise the
 // caller launches them itself.
-template <typename Real> bool launchDirect(const DirectParams<Real>& p0, int mc, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s) {
+template <typename Real> bool launchDirect(const DirectParams<Real>& p0, int mc, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s, hipEvent_t evStart, hipEvent_t evStop, bool* timed) {
     const DirectParams<Real>& p = p0;
     switch (mc) {
-        case MC_NOCUTOFF: return launchDirectMC<Real, MC_NOCUTOFF>(p, wrap, energy, lists, s);
-        case MC_RF: return launchDirectMC<Real, MC_RF>(p, wrap, energy, lists, s);
-        case MC_EWALD: return launchDirectMC<Real, MC_EWALD>(p, wrap, energy, lists, s);
-        default: return launchDirectMC<Real, MC_LJPME>(p, wrap, energy, lists, s);
+        case MC_NOCUTOFF: return launchDirectMC<Real, MC_NOCUTOFF>(p, wrap, energy, lists, s, evStart, evStop, timed);
+        case MC_RF: return launchDirectMC<Real, MC_RF>(p, wrap, energy, lists, s, evStart, evStop, timed);
+        case MC_EWALD: return launchDirectMC<Real, MC_EWALD>(p, wrap, energy, lists, s, evStart, evStop, timed);
+        default: return launchDirectMC<Real, MC_LJPME>(p, wrap, energy, lists, s, evStart, evStop, timed);
     }
 }
-template bool launchDirect<float>(const DirectParams<float>&, int, bool, bool, const PairListParams<float>*, hipStream_t);
-template bool launchDirect<double>(const DirectParams<double>&, int, bool, bool, const PairListParams<double>*, hipStream_t);
+template bool launchDirect<float>(const DirectParams<float>&, int, bool, bool, const PairListParams<float>*, hipStream_t, hipEvent_t, hipEvent_t, bool*);
+template bool launchDirect<double>(const DirectParams<double>&, int, bool, bool, const PairListParams<double>*, hipStream_t, hipEvent_t, hipEvent_t, bool*);
 
 // ---- 1-4 exceptions: ReferenceSlicedLJCoulomb14.cpp:61-95 ----------------------------------------
 template <typename Real, bool ENERGY> __device__ __forceinline__ void exceptionsBody(const PairListParams<Real>& p, const int blk) {

@@ -1077,8 +1077,7 @@ public:
             q.pairs = pairs14.p; q.params = params14.p; q.n = n14;
             q.nExclAtoms = (ew && nExcl > 0) ? Npad : 0;
         }
-        bool listsDone = !haveLists;
-        if (ev) HIPCHECK(hipEventRecord(ev->e[1], stream));
+        bool listsDone = !haveLists, kernelTimed = false;
         if (includeDirect) {
             DirectParams<Real> p;
             std::memset(&p, 0, sizeof(p));
@@ -1110,10 +1109,10 @@ public:
             else if (cfg.method == SNB_Ewald || cfg.method == SNB_PME) mc = MC_EWALD;
             else if (cfg.method == SNB_LJPME) mc = MC_LJPME;
             static const bool noFuse = getenv("SNB_NO_FUSED_LISTS") != nullptr;
-            if (launchDirect<Real>(p, mc, wrapMode, energy, (haveLists && !noFuse) ? &q : nullptr, stream)) listsDone = true;
+            if (launchDirect<Real>(p, mc, wrapMode, energy, (haveLists && !noFuse) ? &q : nullptr, stream, ev ? ev->e[1] : nullptr, ev ? ev->e[2] : nullptr, &kernelTimed)) listsDone = true;
         }
+        if (ev && !kernelTimed) { HIPCHECK(hipEventRecord(ev->e[1], stream)); HIPCHECK(hipEventRecord(ev->e[2], stream)); }   // no tile kernel this step
         if (!listsDone) launchPairLists<Real>(q, energy, stream);
-        if (ev) HIPCHECK(hipEventRecord(ev->e[2], stream));
         if (ev) HIPCHECK(hipEventRecord(ev->e[3], stream));
         if (includeRecip && isPme()) {
             if (nGrids > 0) {

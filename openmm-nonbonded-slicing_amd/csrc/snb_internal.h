@@ -174,7 +174,8 @@ template <typename Real> void launchNeighborSort(const NbParams<Real>& p, const 
 template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipStream_t s);
 
 // ---- launchers implemented in the .hip translation units -------------------------------------
-template <typename Real> bool launchDirect(const DirectParams<Real>& p, int methodClass, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s);   // true: lists ran inside the launch
+template <typename Real> bool launchDirect(const DirectParams<Real>& p, int methodClass, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s,
+                                          hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, bool* timed = nullptr);   // true: lists ran inside the launch
 template <typename Real> void launchPairLists(const PairListParams<Real>& p, bool energy, hipStream_t s);
 template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStream_t s);   // true: forward z FFT already done
 template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s, bool zDone);
