@@ -16,9 +16,12 @@ def __getattr__(name):
         import importlib
         if name == "capi":
             return importlib.import_module(__name__ + "._capi")
-    if name == "sharding":
+    if name in ("sharding", "serialization"):
         import importlib
-        return importlib.import_module(__name__ + ".sharding")
+        return importlib.import_module(__name__ + "." + name)
+    if name == "XmlSerializer":
+        import importlib
+        return importlib.import_module(__name__ + ".serialization").XmlSerializer
     if name in ("HipCalcSlicedNonbondedForceKernel", "Context", "System", "State"):
         import importlib
         mod = importlib.import_module(__name__ + ".context")

@@ -81,6 +81,7 @@ class SlicedNonbondedForce:
         self._includeDirect = True
         self._forceGroup = 0
         self._recipForceGroup = -1
+        self._name = "SlicedNonbondedForce"      # OpenMM Force::getName default: the class name
         self.useCuFFT = True  # kept for surface compatibility; meaningless here
         if source is not None:
             self._copyFrom(source)
@@ -148,6 +149,8 @@ class SlicedNonbondedForce:
     def setExceptionsUsePeriodicBoundaryConditions(self, p): self._exceptionsPeriodic = bool(p)
     def getIncludeDirectSpace(self): return self._includeDirect
     def setIncludeDirectSpace(self, inc): self._includeDirect = bool(inc)
+    def getName(self): return self._name
+    def setName(self, name): self._name = str(name)
     def getForceGroup(self): return self._forceGroup
     def setForceGroup(self, g): self._forceGroup = int(g)
     def getReciprocalSpaceForceGroup(self): return self._recipForceGroup
