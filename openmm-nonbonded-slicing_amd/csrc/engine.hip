@@ -866,6 +866,7 @@ public:
             p.nPadded = Npad; p.nBlocks = numBlocks; p.blockSubset = blockSubset.p;
             p.shardBegin = shardBegin; p.shardWidth = shardEnd - shardBegin; p.shardPeriod = shardPeriod;
             { static const bool boxOnly = getenv("SNB_BOX_PRUNE") != nullptr; p.exactPrune = boxOnly ? 0 : 1; }
+            { static const int it = getenv("SNB_ITEM_TILES") ? std::max(1, std::min(32, atoi(getenv("SNB_ITEM_TILES")))) : 8; p.itemTiles = it; }
             p.blockCenter = dBlockCenter.p; p.blockHalf = dBlockHalf.p;
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;

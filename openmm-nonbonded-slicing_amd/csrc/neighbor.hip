@@ -334,7 +334,8 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         // full (8-tile) work items and the at most one partial item go to separate queues: the engine appends the partial
         // ones behind the full ones so that the short items fill the tail of the launch
         int first = 0, w0 = 0, wp = 0;
-        const int nFull = nT / 8, nPart = (nT & 7) ? 1 : 0;
+        const int CH = p.itemTiles;                       // tiles per full work item
+        const int nFull = nT / CH, nPart = (nT % CH) ? 1 : 0;
         const int part = I & (NB_PARTS - 1);
         int* cnt = p.counters + 32 * (1 + part);
         const int tileRegion = p.tileCapacity / NB_PARTS, workRegion = p.workCapacity / NB_PARTS;
@@ -366,8 +367,8 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         }
         for (int t = lane; t < nT; t += 64) p.tileInfo[first + t] = make_int4(tileSub[t], ((anyBits >> t) & 1ull) ? mi0 + __popcll(anyBits & ((1ull << t) - 1ull)) : -1, 0, 0);
         const int subI = p.blockSubset[I];      // carried in the work item: the pair kernel needs it before the block's atoms arrive
-        for (int k = lane; k < nFull; k += 64) p.workItemsStage[w0 + k] = make_int4(I, first + 8 * k, 8, subI);
-        if (nPart && lane == 0) p.workItemsPartial[wp] = make_int4(I, first + 8 * nFull, nT & 7, subI);
+        for (int k = lane; k < nFull; k += 64) p.workItemsStage[w0 + k] = make_int4(I, first + CH * k, CH, subI);
+        if (nPart && lane == 0) p.workItemsPartial[wp] = make_int4(I, first + CH * nFull, nT % CH, subI);
         __builtin_amdgcn_wave_barrier();
     };
 

@@ -164,6 +164,7 @@ template <typename Real> struct NbParams {
     int* counters;   // [32 * 65]: line 0 = totals ([0] tiles, [1] full work items, [2] masks, [3] overflow events, [4] partial items, [5] max tiles|masks and
                      // [6] max work items of a partition), lines 1..64 = the partitions' allocation counters (same slots)
     int tileCapacity, workCapacity, maskCapacity;
+    int itemTiles;               // tiles per full work item of the pair kernel (8; SNB_ITEM_TILES)
     int exactPrune;              // k_nbBuildTiles: re-test the gathered atoms against the block's atoms (SNB_BOX_PRUNE=1 switches it off)
     int shardBegin, shardWidth, shardPeriod;   // tiles and work items are built only for i-blocks with block % shardPeriod in [shardBegin, shardBegin + shardWidth)
     long long* dbgOut;   // SNB_NB_TRACE: per-block start/end wall_clock64 stamps (100 MHz) of the tile builder
