@@ -589,6 +589,34 @@ def largeSystem(F, method, seed=0):
     return f, positions, cubic(boxSize)
 
 
+# --- :683-758 testChangingParameters: dimer lattice generator; the parameter change applied to every fifth particle ----------------------
+def changingParametersSystem(F):
+    numMolecules = 600; cutoff = 2.0; boxSize = 20.0
+    f = F(1)
+    positions = np.zeros((2 * numMolecules, 3))
+    M = int(numMolecules ** (1.0 / 3.0))
+    if M * M * M < numMolecules:
+        M += 1
+    for k in range(numMolecules):
+        iz = k // (M * M); iy = (k - iz * M * M) // M; ix = k - M * (iy + iz * M)
+        x, y, z = (ix + 0.5) * boxSize / M, (iy + 0.5) * boxSize / M, (iz + 0.5) * boxSize / M
+        dx, dy, dz = (0.5 - ix % 2) / 2, (0.5 - iy % 2) / 2, (0.5 - iz % 2) / 2
+        eps = 0.1 if k < numMolecules // 2 else 0.2
+        f.addParticle(-1.0, 0.2, eps); f.addParticle(1.0, 0.1, eps)
+        positions[2 * k] = [x + dx, y + dy, z + dz]
+        positions[2 * k + 1] = [x - dx, y - dy, z - dz]
+        f.addException(2 * k, 2 * k + 1, 0.0, 0.15, 0.0)
+    f.setNonbondedMethod(4)
+    f.setCutoffDistance(cutoff)
+    return f, positions, cubic(boxSize)
+
+
+def changeEveryFifthParticle(f):
+    for i in range(0, f.getNumParticles(), 5):      # :746-752
+        charge, sigma, epsilon = f.getParticleParameters(i)
+        f.setParticleParameters(i, 1.5 * charge, 1.1 * sigma, 1.7 * epsilon)
+
+
 # --- :557-612 testHugeSystem: energy change along the force direction (size-independent property; gridSize 150 = 3.4 M particles) -------
 def testHugeSystem(evEnergy, evForces, F, gridSize=150, tol=1e-4, seed=0, scaledDown=False):
     spacing = 0.3; boxSize = gridSize * spacing

@@ -256,6 +256,38 @@ def test_large_system_vs_oracle(method, snb, F, oev, prec):
     _compare(make_ev(snb, prec), oev, force, pos, box if method == 2 else None, TOLS[prec])
 
 
+def test_changing_parameters(snb, F, oev, prec):
+    """testChangingParameters (TestSlicedNonbondedForce.h:683-758): 600 dimers on the reference's staggered lattice, PME with a 2 nm
+    cutoff in a 20 nm box, direct and reciprocal space in separate force groups; then every fifth particle gets 1.5 q, 1.1 sigma,
+    1.7 epsilon through updateParametersInContext.  The reference compares with OpenMM's NonbondedForce (tol 2e-3); the partner here
+    is the oracle, before and after the update, group by group."""
+    force, pos, box = K.changingParametersSystem(F)
+    force.setPMEParameters(1.5, 48, 48, 48)
+    force.setReciprocalSpaceForceGroup(3); force.setForceGroup(1)
+    system = snb.System()
+    for _ in range(force.getNumParticles()):
+        system.addParticle(1.0)
+    system.setDefaultPeriodicBoxVectors(*box)
+    system.addForce(force)
+    ctx = snb.Context(system, precision=prec)
+    ctx.setPositions(pos)
+    tol = 2e-3 if prec == "single" else 1e-5
+
+    def check():
+        for groups, direct, recip in ((1 << 1, True, False), (1 << 3, False, True), (-1, True, True)):
+            st = ctx.getState(getEnergy=True, getForces=True, groups=groups)
+            o = oev(force, pos, box, None, direct, recip)
+            K.assertEqualTo(o["energy"], st.getPotentialEnergy(), tol)
+            fo, fr = o["forces"], st.getForces()
+            err = np.linalg.norm(fo - fr, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)
+            assert err.max() <= tol, (groups, err.max())
+
+    check()
+    K.changeEveryFifthParticle(force)
+    force.updateParametersInContext(ctx)
+    check()
+
+
 def test_huge_system_energy_follows_forces(snb, F, prec):
     """testHugeSystem (TestSlicedNonbondedForce.h:557-612) at its full size: 150^3 = 3 375 000 particles, CutoffPeriodic with a
     switching function; stepping along the force direction must change the energy by |F| * delta."""

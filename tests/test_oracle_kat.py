@@ -67,6 +67,25 @@ def test_huge_system_property_small(ev, F):
     K.testHugeSystem(lambda f, x, b: ev(f, x, b)["energy"], lambda f, x, b: ev(f, x, b)["forces"], F, gridSize=12, scaledDown=True)
 
 
+def test_changing_parameters_system(ev, F):
+    """testChangingParameters' system (TestSlicedNonbondedForce.h:683-758) on the oracle: the direct and the reciprocal force group add up to
+    the whole, before and after every fifth particle is changed, and the forces stay the gradient of the energy (the GPU test compares
+    the engine's updateParametersInContext with these numbers)."""
+    force, pos, box = K.changingParametersSystem(F)
+    force.setPMEParameters(1.5, 48, 48, 48)
+    energies = []
+    for _ in range(2):
+        d, r, t = ev(force, pos, box, None, True, False), ev(force, pos, box, None, False, True), ev(force, pos, box)
+        K.assertEqualTo(t["energy"], d["energy"] + r["energy"], 1e-10)
+        K.assertForces(t["forces"], d["forces"] + r["forces"], 1e-10)
+        step = 1e-4 * t["forces"] / np.linalg.norm(t["forces"])
+        e2 = ev(force, pos - step, box)["energy"]; e1 = ev(force, pos + step, box)["energy"]
+        K.assertEqualTo(np.linalg.norm(t["forces"]), (e2 - e1) / 2e-4, 1e-4)
+        energies.append(t["energy"])
+        K.changeEveryFifthParticle(force)
+    assert abs(energies[0] - energies[1]) > 1.0
+
+
 def test_fft_against_numpy(oracle):
     rng = np.random.default_rng(1)
     for shape in [(28, 25, 30), (21, 25, 27), (8, 6, 10), (7, 11, 13)]:
