@@ -476,63 +476,84 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     const float2* rdSe = mySe + 16 * row + (c & 7) + 8;
 
     // two-tile-deep software pipeline, as in k_direct
-    float4 pj; float2 sej;
-    auto fetch = [&](int code, float4& x, float2& se) {
-        if (code != -1) {
-            const int idx = code & SNB_JIDX_MASK;
-            x = p.posq[idx]; se = p.sigeps[idx];
-            const int sc = (code >> SNB_JSHIFT_BITS) & 127;
-            const int kx = sc / 25, ky = (sc - 25 * kx) / 5, kz = sc - 25 * kx - 5 * ky;
-            const float ka = float(kx - 2), kb = float(ky - 2), kc = float(kz - 2);      // lattice image: + ka a + kb b + kc c (rows of p.box)
-            x.x += ka * p.box[0] + kb * p.box[3] + kc * p.box[6]; x.y += kb * p.box[4] + kc * p.box[7]; x.z += kc * p.box[8];
-        } else { x.x = 3e9f + 1e6f * c; x.y = -5e9f; x.z = 7e9f; x.w = 0; se.x = 0; se.y = 0; }
+    // Software pipeline over the item's tiles with TWO register sets used alternately (the tile loop is unrolled by two).  While tile t
+    // (set X) is evaluated, the atoms, masks and lambdas of tile t+1 are requested into set Y, and the list entry + header of tile t+2
+    // into the jcode/head fields of X (X's own entry has been copied to `curCode` by then).  No requested register is copied, shifted
+    // or converted before the trip in which it is consumed -- a copy (a loop-carried "next = loaded" move), the image shift added at
+    // the load, or a uniform header moved to SGPRs behind its load each cost a full memory round trip per tile, atomics included,
+    // because the wait counter is in-order.
+    struct TileRegs { int jcode, sj, maskIdx; float4 pj; float2 sej; float shx, shy, shz; unsigned mA, mB; float2 lam; };
+    TileRegs A, B;
+    int vzero; asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));      // a zero the compiler cannot see through (keeps the header load in VGPRs)
+    // (the j-force atomics of a tile are issued at the start of the NEXT trip: an atomic sits behind a conditional skip the wait-count
+    // pass cannot count, so any wait after it degrades to "everything"; issued first, they are a whole tile old when that wait comes)
+    float pendX = 0.f, pendY = 0.f, pendZ = 0.f; int pendIdx = -1;
+    auto flushPending = [&]() { if (pendIdx >= 0) { gAdd(&p.fx[pendIdx], pendX); gAdd(&p.fy[pendIdx], pendY); gAdd(&p.fz[pendIdx], pendZ); } };
+    auto requestList = [&](TileRegs& r, int t) {                    // list entry + header of tile t
+        r.jcode = p.tileJ[t * 32 + stageJ];
+        const int2 v = *reinterpret_cast<const int2*>(&p.tileInfo[t + vzero]);
+        r.sj = v.x; r.maskIdx = v.y;
     };
-    struct TileHead { int sj, maskIdx; };
-    auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x, v.y}; };
-    int jcode = p.tileJ[tBegin * 32 + stageJ];
-    TileHead head = loadHead(tBegin);
-    int jcodeNext = -1; TileHead headNext = head;
-    if (tBegin + 1 < tEnd) { jcodeNext = p.tileJ[(tBegin + 1) * 32 + stageJ]; headNext = loadHead(tBegin + 1); }
-    fetch(jcode, pj, sej);
-    unsigned maskAPre = 0, maskBPre = 0;
-    if (head.maskIdx >= 0) { maskAPre = p.masks[head.maskIdx * 32 + c]; maskBPre = p.masks[head.maskIdx * 32 + 16 + c]; }
-    int slicePre = sliceOf(si, head.sj);
-    float lamCPre = p.lambdas[2 * slicePre], lamLPre = p.lambdas[2 * slicePre + 1];
-
-    for (int t = tBegin; t < tEnd; t++) {
+    auto requestAtoms = [&](TileRegs& r) {                          // needs r.jcode / r.sj / r.maskIdx (requested a tile earlier)
+        const int code = r.jcode;
+        asm volatile("" :: "v"(code), "v"(r.sj), "v"(r.maskIdx));   // the wait for the list entry belongs HERE, before anything younger is issued
+        flushPending();
+        const int idx = code == -1 ? 0 : (code & SNB_JIDX_MASK);
+        r.pj = p.posq[idx]; r.sej = p.sigeps[idx];
+        const int sc = (code >> SNB_JSHIFT_BITS) & 127;
+        const int kx = sc / 25, ky = (sc - 25 * kx) / 5, kz = sc - 25 * kx - 5 * ky;
+        const float ka = float(kx - 2), kb = float(ky - 2), kc = float(kz - 2);      // lattice image: + ka a + kb b + kc c (rows of p.box)
+        r.shx = ka * p.box[0] + kb * p.box[3] + kc * p.box[6]; r.shy = kb * p.box[4] + kc * p.box[7]; r.shz = kc * p.box[8];
+        const int mi = r.maskIdx < 0 ? 0 : r.maskIdx;              // unconditional loads: a conditionally loaded register is a phi with a copy
+        r.mA = p.masks[mi * 32 + c]; r.mB = p.masks[mi * 32 + 16 + c];
+        r.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * sliceOf(si, r.sj)]);
+    };
+    // what the staging of a tile leaves behind for its evaluation
+    struct Staged { int code; bool hasMask; unsigned maskA, maskB; float lamC, lamL; int slice; };
+    auto stage = [&](TileRegs& R) {                                 // tile R -> LDS (the wait for its atoms sits here, in straight-line code)
+        Staged st;
         __builtin_amdgcn_wave_barrier();
-        myPos[lane] = pj; mySe[lane] = sej;
-        const int curCode = jcode;
-        const bool hasMask = head.maskIdx >= 0;
-        const unsigned maskA = maskAPre >> (8 * row), maskB = maskBPre >> (8 * row);   // my j-quarter's 8 bits
-        const float lamC = lamCPre, lamL = lamLPre;
-        if (ENERGY && slicePre != curSlice) { flushEnergy(); curSlice = slicePre; }
+        st.code = R.jcode;
+        if (st.code != -1) { myPos[lane] = make_float4(R.pj.x + R.shx, R.pj.y + R.shy, R.pj.z + R.shz, R.pj.w); mySe[lane] = R.sej; }
+        else { myPos[lane] = make_float4(3e9f + 1e6f * c, -5e9f, 7e9f, 0.f); mySe[lane] = make_float2(0.f, 0.f); }      // padding slot: parked far away
+        st.hasMask = R.maskIdx >= 0;
+        st.maskA = st.hasMask ? R.mA >> (8 * row) : 0u; st.maskB = st.hasMask ? R.mB >> (8 * row) : 0u;   // my j-quarter's 8 bits
+        st.lamC = R.lam.x; st.lamL = R.lam.y;
+        st.slice = ENERGY ? sliceOf(si, R.sj) : 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        jcode = jcodeNext; head = headNext;
-        if (t + 1 < tEnd) {
-            fetch(jcode, pj, sej);
-            maskAPre = 0; maskBPre = 0;
-            if (head.maskIdx >= 0) { maskAPre = p.masks[head.maskIdx * 32 + c]; maskBPre = p.masks[head.maskIdx * 32 + 16 + c]; }
-            slicePre = sliceOf(si, head.sj);
-            lamCPre = p.lambdas[2 * slicePre]; lamLPre = p.lambdas[2 * slicePre + 1];
-        }
-        if (t + 2 < tEnd) { jcodeNext = p.tileJ[(t + 2) * 32 + stageJ]; headNext = loadHead(t + 2); }
-
-        // lambda folded into the i-side parameters once per tile
-        const v2f qiS = qi * lamC, epsiS = epsi * lamL;
+        return st;
+    };
+    // One trip: request (unconditionally -- past the item's end the indices are clamped and the data unused, so that the number of
+    // memory operations in flight is a compile-time constant and every wait can be exact), evaluate the staged tile X, scatter its
+    // j-forces, then stage Y.  The wait for Y's atoms thus comes after a whole tile of arithmetic and leaves the younger requests and
+    // the atomics in flight.
+    auto tile = [&](TileRegs& X, TileRegs& Y, const int t, Staged& st) {
+        requestAtoms(Y);      // (issues the previous tile's j-force atomics first)
+        requestList(X, t + 2 < tEnd ? t + 2 : tEnd - 1);
+        if (ENERGY && st.slice != curSlice) { flushEnergy(); curSlice = st.slice; }
+        const v2f qiS = qi * st.lamC, epsiS = epsi * st.lamL;      // lambda folded into the i-side parameters once per tile
         float fjx = 0, fjy = 0, fjz = 0;
-        if (hasMask) tileStepsPacked<MC, true, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, lamL, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-        else tileStepsPacked<MC, false, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, lamL, maskA, maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+        if (st.hasMask) tileStepsPacked<MC, true, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, st.lamL, st.maskA, st.maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+        else tileStepsPacked<MC, false, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, st.lamL, st.maskA, st.maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
         // rotate-then-subtract leaves lane c holding slot (c+1)&7: one more rotation brings every slot home, then the two
         // partial sums of a slot (lanes c and c+8) are merged
         fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
-        fjx += rowRor8(fjx); fjy += rowRor8(fjy); fjz += rowRor8(fjz);
-        if (c < 8 && curCode != -1) {                    // entry c < 8 of quarter `row` == j-slot 8*row + c == the atom this lane staged
-            const int jidx = curCode & SNB_JIDX_MASK;
-            gAdd(&p.fx[jidx], fjx); gAdd(&p.fy[jidx], fjy); gAdd(&p.fz[jidx], fjz);
-        }
+        pendX = fjx + rowRor8(fjx); pendY = fjy + rowRor8(fjy); pendZ = fjz + rowRor8(fjz);
+        const int curCode = st.code;
+        pendIdx = (c < 8 && curCode != -1) ? (curCode & SNB_JIDX_MASK) : -1;      // entry c < 8 of quarter `row` == j-slot 8*row + c == the atom this lane staged
+        st = stage(Y);
+    };
+    requestList(A, tBegin);
+    B = A;
+    requestList(B, tBegin + 1 < tEnd ? tBegin + 1 : tBegin);
+    requestAtoms(A);
+    Staged st = stage(A);
+    for (int t = tBegin; t < tEnd; t += 2) {
+        tile(A, B, t, st);
+        if (t + 1 < tEnd) tile(B, A, t + 1, st);
     }
+    flushPending();
     // the four rows hold partial sums for the same i-atoms (different j-quarters)
     float ox = fix.x, oy = fiy.x, oz = fiz.x, ux = fix.y, uy = fiy.y, uz = fiz.y;
     ox += __shfl_xor(ox, 16, 64); oy += __shfl_xor(oy, 16, 64); oz += __shfl_xor(oz, 16, 64);
