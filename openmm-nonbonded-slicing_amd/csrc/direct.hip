@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
         } else { x.x = Real(3e9) + Real(1e6) * c; x.y = Real(-5e9); x.z = Real(7e9); x.w = 0; se.x = 0; se.y = 0; }
     };
     struct TileHead { int sj, maskIdx; };
-    auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x, v.y}; };
+    auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x, v.y}; };      // (slice of the tile, mask index)
     auto loadMask = [&](const TileHead& h) { return (h.maskIdx >= 0) ? p.masks[h.maskIdx * 32 + il] : 0u; };
     int jcode = p.tileJ[tBegin * 32 + stageJ];
     TileHead head = loadHead(tBegin);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
     if (tBegin + 1 < tEnd) { jcodeNext = p.tileJ[(tBegin + 1) * 32 + stageJ]; headNext = loadHead(tBegin + 1); }
     fetch(jcode, pj, sej);
     unsigned maskPre = loadMask(head);
-    int slicePre = sliceOf(si, head.sj);
+    int slicePre = head.sj;
     Real lamCPre = p.lambdas[2 * slicePre], lamLPre = p.lambdas[2 * slicePre + 1];
 
     for (int t = tBegin; t < tEnd; t++) {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
         if (t + 1 < tEnd) {
             fetch(jcode, pj, sej);
             maskPre = loadMask(head);
-            slicePre = sliceOf(si, head.sj);
+            slicePre = head.sj;
             lamCPre = p.lambdas[2 * slicePre]; lamLPre = p.lambdas[2 * slicePre + 1];
         }
         if (t + 2 < tEnd) { jcodeNext = p.tileJ[(t + 2) * 32 + stageJ]; headNext = loadHead(t + 2); }
@@ -444,6 +444,14 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
     __shared__ float4 s_pos[4][64];
     __shared__ float2 s_se[4][64];
+    __shared__ float4 s_shift[128];      // lattice-image shift of every 7-bit image code (125 in use): + ka a + kb b + kc c (rows of p.box)
+    if (threadIdx.x < 128) {
+        const int sc = threadIdx.x;
+        const int kx = sc / 25, ky = (sc - 25 * kx) / 5, kz = sc - 25 * kx - 5 * ky;
+        const float ka = float(kx - 2), kb = float(ky - 2), kc = float(kz - 2);
+        s_shift[sc] = sc < 125 ? make_float4(ka * p.box[0] + kb * p.box[3] + kc * p.box[6], kb * p.box[4] + kc * p.box[7], kc * p.box[8], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int item = tileBlock * 4 + wid; item < p.numWork; item += nTileBlocks * 4) {   // no block-level barrier inside the loop
@@ -500,13 +508,11 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         flushPending();
         const int idx = code == -1 ? 0 : (code & SNB_JIDX_MASK);
         r.pj = p.posq[idx]; r.sej = p.sigeps[idx];
-        const int sc = (code >> SNB_JSHIFT_BITS) & 127;
-        const int kx = sc / 25, ky = (sc - 25 * kx) / 5, kz = sc - 25 * kx - 5 * ky;
-        const float ka = float(kx - 2), kb = float(ky - 2), kc = float(kz - 2);      // lattice image: + ka a + kb b + kc c (rows of p.box)
-        r.shx = ka * p.box[0] + kb * p.box[3] + kc * p.box[6]; r.shy = kb * p.box[4] + kc * p.box[7]; r.shz = kc * p.box[8];
+        const float4 sh = s_shift[(code >> SNB_JSHIFT_BITS) & 127];      // lattice image of the entry (table filled at kernel start)
+        r.shx = sh.x; r.shy = sh.y; r.shz = sh.z;
         const int mi = r.maskIdx < 0 ? 0 : r.maskIdx;              // unconditional loads: a conditionally loaded register is a phi with a copy
         r.mA = p.masks[mi * 32 + c]; r.mB = p.masks[mi * 32 + 16 + c];
-        r.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * sliceOf(si, r.sj)]);
+        r.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * r.sj]);      // (r.sj holds the tile's slice index, written by the builder)
     };
     // what the staging of a tile leaves behind for its evaluation
     struct Staged { int code; bool hasMask; unsigned maskA, maskB; float lamC, lamL; int slice; };
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         st.hasMask = R.maskIdx >= 0;
         st.maskA = st.hasMask ? R.mA >> (8 * row) : 0u; st.maskB = st.hasMask ? R.mB >> (8 * row) : 0u;   // my j-quarter's 8 bits
         st.lamC = R.lam.x; st.lamL = R.lam.y;
-        st.slice = ENERGY ? sliceOf(si, R.sj) : 0;
+        st.slice = R.sj;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         return st;

@@ -620,7 +620,7 @@ public:
                 int mi = (int)(hMasks.size() / 32);
                 hMasks.resize(hMasks.size() + 32, 0u);
                 for (int i = 0; i < 32; i++) { unsigned m = 0; for (int j = 0; j <= i; j++) m |= 1u << j; hMasks[(size_t)mi * 32 + i] = m; }   // keep j > i only
-                hTileInfo.push_back(make_int4(blkSubset[I], mi, 0, 0));
+                hTileInfo.push_back(make_int4(blkSubset[I] * (blkSubset[I] + 3) / 2, mi, blkSubset[I], 0));      // (slice, mask, j subset)
                 tileMask.push_back(mi);
                 for (int k = 0; k < 32; k++) slotOf[I * 32 + k] = k;    // slots 0..31 = diagonal tile
             }
@@ -635,7 +635,7 @@ public:
                     cnt++; pos++;
                 }
                 for (; cnt < 32; cnt++) hTileJ.push_back(-1);
-                hTileInfo.push_back(make_int4(sjSub, -1, 0, 0));
+                { const int a = std::max(blkSubset[I], sjSub), b = std::min(blkSubset[I], sjSub); hTileInfo.push_back(make_int4(a * (a + 1) / 2 + b, -1, sjSub, 0)); }
                 tileMask.push_back(-1);
             }
             // exclusion masks

@@ -216,6 +216,7 @@ template <typename Real> __global__ void k_nbBounds(const NbParams<Real> p) {
 
 // ---- 4. tiles ------------------------------------------------------------------------------------------------------
 __device__ inline bool ownsPair(int I, int J) { return ((I + J) & 1) ? (I > J) : (I < J); }
+__device__ inline int nbSliceOf(int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
 __device__ inline int lanePrefix(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0)); }
 
 constexpr int NB_PARTS = 64;         // allocation counters are partitioned (block I -> partition I % 64, one 128-byte line each): 9 k wavefronts bumping the
@@ -365,7 +366,8 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
             const int t = t2 + half;
             if (t < nT && ((anyBits >> t) & 1ull)) p.masks[(size_t)(mi0 + __popcll(anyBits & ((1ull << t) - 1ull))) * 32 + il] = mask[t][il];
         }
-        for (int t = lane; t < nT; t += 64) p.tileInfo[first + t] = make_int4(tileSub[t], ((anyBits >> t) & 1ull) ? mi0 + __popcll(anyBits & ((1ull << t) - 1ull)) : -1, 0, 0);
+        const int subIb = p.blockSubset[I];
+        for (int t = lane; t < nT; t += 64) p.tileInfo[first + t] = make_int4(nbSliceOf(subIb, tileSub[t]), ((anyBits >> t) & 1ull) ? mi0 + __popcll(anyBits & ((1ull << t) - 1ull)) : -1, tileSub[t], 0);
         const int subI = p.blockSubset[I];      // carried in the work item: the pair kernel needs it before the block's atoms arrive
         for (int k = lane; k < nFull; k += 64) p.workItemsStage[w0 + k] = make_int4(I, first + CH * k, CH, subI);
         if (nPart && lane == 0) p.workItemsPartial[wp] = make_int4(I, first + CH * nFull, nT % CH, subI);

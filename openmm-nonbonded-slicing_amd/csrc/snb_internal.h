@@ -9,7 +9,7 @@
 //     fx,fy,fz : Real[Npad]  direct-space force accumulators (atomics)
 //   tiles (32 i-atoms of one block x 32 individually gathered j-atoms of ONE subset):
 //     tileJ    : int32[T][32]  sorted j index | (periodic-image code << 27)
-//     tileInfo : int4[T]       x = j subset, y = exclusion-mask index or -1
+//     tileInfo : int4[T]       x = slice index of (i-block subset, j subset), y = exclusion-mask index or -1, z = j subset
 //     masks    : uint32[M][32] bit j of word i set = pair (i,j) excluded
 #pragma once
 #include <hip/hip_runtime.h>
