@@ -221,7 +221,8 @@ __device__ inline int lanePrefix(unsigned long long m) { return __builtin_amdgcn
 
 constexpr int NB_PARTS = 64;         // allocation counters are partitioned (block I -> partition I % 64, one 128-byte line each): 9 k wavefronts bumping the
                                      // same three counters were serialised in L2 and cost ~250 us of a 600 us build
-constexpr int NB_CAP = 1024;        // j entries gathered per published chunk (32 tiles); larger neighbourhoods publish several chunks
+constexpr int NB_CAP = 768;         // j entries gathered per published chunk (24 tiles); larger neighbourhoods publish several chunks.  768: four
+                                    // work-groups per CU instead of three with 1024 (LDS), builder 0.52 -> 0.43 ms on c3; 640 adds 2 % tiles
 constexpr int NB_MAXT = NB_CAP / 32;
 
 // First index in the z-sorted run [a, b) whose z is not "before" zq (ascending runs: before = z < zq; descending runs:
