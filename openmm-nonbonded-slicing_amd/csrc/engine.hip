@@ -237,6 +237,7 @@ public:
     };
     void* outPtr = nullptr; int outIsDouble = 0, outAccumulate = 0; bool outputWritten = false;   // snb_set_force_output
     hipGraphExec_t graphExec = nullptr; GraphKey graphKey{}; long long execCount = 0;
+    hipGraphExec_t sortGraphExec = nullptr; std::vector<unsigned char> sortGraphKey; bool sortGraphBroken = false;      // phase A of the neighbour rebuild
     void dropGraph() { if (graphExec) { (void)hipGraphExecDestroy(graphExec); graphExec = nullptr; } }
     bool lastRecip = false;
     snb_stats stats;
@@ -279,6 +280,7 @@ public:
         (void)hipStreamSynchronize(stream);
         if (dPmeTrace.p) { long long h[4] = {0, 0, 0, 0}; (void)hipMemcpy(h, dPmeTrace.p, 32, hipMemcpyDeviceToHost); if (h[2] > 0) fprintf(stderr, "[snb] interpolation bricks: mean load %.2f us, mean compute %.2f us per work-group (%lld work-groups)\n", h[0] / 100.0 / h[2], h[1] / 100.0 / h[2], h[2]); }
         dropGraph();
+        if (sortGraphExec) { (void)hipGraphExecDestroy(sortGraphExec); sortGraphExec = nullptr; }
         for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
         for (int k = 0; k < 3; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
         if (hDispFlags) (void)hipHostFree(hDispFlags);
@@ -843,7 +845,33 @@ public:
         p.userToSorted = dUserToSorted.p; p.colRange = colRange.p; p.zIndex = dZIndex.p; p.counters = dCounters.p;
         if (!evRebuild[0]) { HIPCHECK(hipEventCreate(&evRebuild[0])); HIPCHECK(hipEventCreate(&evRebuild[1])); HIPCHECK(hipEventCreate(&evRebuild[2])); }
         HIPCHECK(hipEventRecord(evRebuild[0], stream));
-        launchNeighborSort<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream);
+        {
+            // Phase A is ~30 small launches (key pass, radix sort, segmentation scans) with nothing but launch latency between them:
+            // captured once per (parameters, buffers, position pointer) and replayed, the way the step itself is.  Any failure to
+            // capture (a library call that is not capturable) falls back to plain launches for good.
+            struct SortKey { NbParams<Real> p; const void* pos; int isDouble, stride4; void* temp; size_t tempBytes; };
+            static_assert(std::is_trivially_copyable<SortKey>::value, "SortKey is compared bytewise");
+            SortKey key; std::memset(&key, 0, sizeof(key));
+            key.p = p; key.pos = devUserPos; key.isDouble = posIsDouble; key.stride4 = posStride4; key.temp = dSortTemp.p; key.tempBytes = tempBytes;
+            static const bool noSortGraph = getenv("SNB_NO_SORT_GRAPH") != nullptr;
+            bool replayed = false;
+            if (!noSortGraph && !sortGraphBroken && !cfg.disable_graph) {
+                if (!sortGraphExec || sortGraphKey.size() != sizeof(key) || std::memcmp(sortGraphKey.data(), &key, sizeof(key)) != 0) {
+                    if (sortGraphExec) { (void)hipGraphExecDestroy(sortGraphExec); sortGraphExec = nullptr; }
+                    hipGraph_t graph = nullptr;
+                    if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                        launchNeighborSort<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream);
+                        const hipError_t endErr = hipStreamEndCapture(stream, &graph);
+                        if (endErr == hipSuccess && graph && hipGraphInstantiate(&sortGraphExec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                            sortGraphKey.assign(reinterpret_cast<const unsigned char*>(&key), reinterpret_cast<const unsigned char*>(&key) + sizeof(key));
+                        } else { sortGraphExec = nullptr; sortGraphBroken = true; (void)hipGetLastError(); }
+                        if (graph) (void)hipGraphDestroy(graph);
+                    } else { sortGraphBroken = true; (void)hipGetLastError(); }
+                }
+                if (sortGraphExec) { HIPCHECK(hipGraphLaunch(sortGraphExec, stream)); replayed = true; }
+            }
+            if (!replayed) launchNeighborSort<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream);
+        }
         HIPCHECK(hipEventRecord(evRebuild[2], stream));
         int npadDev = 0;
         HIPCHECK(hipMemcpyAsync(&npadDev, dCounters.p + 7, sizeof(int), hipMemcpyDeviceToHost, stream));
