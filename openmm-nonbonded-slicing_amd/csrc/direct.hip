@@ -208,7 +208,6 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
 
     const T4 pi = p.posq[I * 32 + il];
     const T2 sei = p.sigeps[I * 32 + il];
-    const int si = p.blockSubset[I];
     const Real qi = pi.w * p.k4pe;
     Real c6i = 0;
     if (MC == MC_LJPME) c6i = Real(8) * sei.x * sei.x * sei.x * sei.y;
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
             }
         } else { x.x = Real(3e9) + Real(1e6) * c; x.y = Real(-5e9); x.z = Real(7e9); x.w = 0; se.x = 0; se.y = 0; }
     };
-    struct TileHead { int sj, maskIdx; };
+    struct TileHead { int slice, maskIdx; };
     auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x, v.y}; };      // (slice of the tile, mask index)
     auto loadMask = [&](const TileHead& h) { return (h.maskIdx >= 0) ? p.masks[h.maskIdx * 32 + il] : 0u; };
     int jcode = p.tileJ[tBegin * 32 + stageJ];
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
     if (tBegin + 1 < tEnd) { jcodeNext = p.tileJ[(tBegin + 1) * 32 + stageJ]; headNext = loadHead(tBegin + 1); }
     fetch(jcode, pj, sej);
     unsigned maskPre = loadMask(head);
-    int slicePre = head.sj;
+    int slicePre = head.slice;
     Real lamCPre = p.lambdas[2 * slicePre], lamLPre = p.lambdas[2 * slicePre + 1];
 
     for (int t = tBegin; t < tEnd; t++) {
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
         if (t + 1 < tEnd) {
             fetch(jcode, pj, sej);
             maskPre = loadMask(head);
-            slicePre = head.sj;
+            slicePre = head.slice;
             lamCPre = p.lambdas[2 * slicePre]; lamLPre = p.lambdas[2 * slicePre + 1];
         }
         if (t + 2 < tEnd) { jcodeNext = p.tileJ[(t + 2) * 32 + stageJ]; headNext = loadHead(t + 2); }
@@ -463,7 +462,6 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
 
     const float4 pa = p.posq[I * 32 + c], pb = p.posq[I * 32 + 16 + c];
     const float2 sa = p.sigeps[I * 32 + c], sb = p.sigeps[I * 32 + 16 + c];
-    const int si = p.blockSubset[I];
     const v2f pix = {pa.x, pb.x}, piy = {pa.y, pb.y}, piz = {pa.z, pb.z};
     const v2f qi = {pa.w * p.k4pe, pb.w * p.k4pe}, sigi = {sa.x, sb.x}, epsi = {sa.y, sb.y};
     v2f fix = {0.f, 0.f}, fiy = {0.f, 0.f}, fiz = {0.f, 0.f};
@@ -490,7 +488,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     // or converted before the trip in which it is consumed -- a copy (a loop-carried "next = loaded" move), the image shift added at
     // the load, or a uniform header moved to SGPRs behind its load each cost a full memory round trip per tile, atomics included,
     // because the wait counter is in-order.
-    struct TileRegs { int jcode, sj, maskIdx; float4 pj; float2 sej; float shx, shy, shz; unsigned mA, mB; float2 lam; };
+    struct TileRegs { int jcode, slice, maskIdx; float4 pj; float2 sej; float shx, shy, shz; unsigned mA, mB; float2 lam; };
     TileRegs A, B;
     int vzero; asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));      // a zero the compiler cannot see through (keeps the header load in VGPRs)
     // (the j-force atomics of a tile are issued at the start of the NEXT trip: an atomic sits behind a conditional skip the wait-count
@@ -500,11 +498,11 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     auto requestList = [&](TileRegs& r, int t) {                    // list entry + header of tile t
         r.jcode = p.tileJ[t * 32 + stageJ];
         const int2 v = *reinterpret_cast<const int2*>(&p.tileInfo[t + vzero]);
-        r.sj = v.x; r.maskIdx = v.y;
+        r.slice = v.x; r.maskIdx = v.y;
     };
-    auto requestAtoms = [&](TileRegs& r) {                          // needs r.jcode / r.sj / r.maskIdx (requested a tile earlier)
+    auto requestAtoms = [&](TileRegs& r) {                          // needs r.jcode / r.slice / r.maskIdx (requested a tile earlier)
         const int code = r.jcode;
-        asm volatile("" :: "v"(code), "v"(r.sj), "v"(r.maskIdx));   // the wait for the list entry belongs HERE, before anything younger is issued
+        asm volatile("" :: "v"(code), "v"(r.slice), "v"(r.maskIdx));   // the wait for the list entry belongs HERE, before anything younger is issued
         flushPending();
         const int idx = code == -1 ? 0 : (code & SNB_JIDX_MASK);
         r.pj = p.posq[idx]; r.sej = p.sigeps[idx];
@@ -512,7 +510,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         r.shx = sh.x; r.shy = sh.y; r.shz = sh.z;
         const int mi = r.maskIdx < 0 ? 0 : r.maskIdx;              // unconditional loads: a conditionally loaded register is a phi with a copy
         r.mA = p.masks[mi * 32 + c]; r.mB = p.masks[mi * 32 + 16 + c];
-        r.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * r.sj]);      // (r.sj holds the tile's slice index, written by the builder)
+        r.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * r.slice]);      // (the slice index comes with the tile header, written by the builder)
     };
     // what the staging of a tile leaves behind for its evaluation
     struct Staged { int code; bool hasMask; unsigned maskA, maskB; float lamC, lamL; int slice; };
@@ -525,7 +523,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         st.hasMask = R.maskIdx >= 0;
         st.maskA = st.hasMask ? R.mA >> (8 * row) : 0u; st.maskB = st.hasMask ? R.mB >> (8 * row) : 0u;   // my j-quarter's 8 bits
         st.lamC = R.lam.x; st.lamL = R.lam.y;
-        st.slice = R.sj;
+        st.slice = R.slice;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         return st;
