@@ -1051,7 +1051,7 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
     // the brick is cut into zSlabs slabs along z (more, smaller work-groups): a slab owns the atoms whose base cell lies in it and
     // stages sz + 4 planes (the stencil reaches 4 cells up, with periodic wrap)
     const int zs = blockIdx.x % zSlabs, brickId = blockIdx.x / zSlabs;
-    const int sz = nz / zSlabs, z0 = zs * sz, bz = zSlabs == 1 ? nz : sz + 4;
+    const int sz = nz / zSlabs, z0 = zs * sz, bz = sz + 4;      // four wrap-around planes on top even for a single slab: the five z points of a stencil line are then always consecutive in LDS
     const int Bx = brickId / nby, By = brickId - Bx * nby;
     const int x0 = Bx * cx, y0 = By * cy;
     const int bx = cx + EXTRA, by = cy + EXTRA;
@@ -1121,9 +1121,10 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
                     int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;
                     Real tx[5], ty[5], tz[5], dx[5], dy[5], dz[5];
                     bspline5<Real>(fr[0], tx, dx); bspline5<Real>(fr[1], ty, dy); bspline5<Real>(fr[2], tz, dz);
-                    int zi[5], zl[5];                                    // global (wrapped) and slab-local z of the five stencil planes
+                    int zi[5];                                           // global (wrapped) z of the five stencil planes (slow path only)
 #pragma unroll
-                    for (int iz = 0; iz < 5; iz++) { int z = idx[2] + iz; zi[iz] = z >= nz ? z - nz : z; zl[iz] = zSlabs == 1 ? zi[iz] : idx[2] - z0 + iz; }
+                    for (int iz = 0; iz < 5; iz++) { int z = idx[2] + iz; zi[iz] = z >= nz ? z - nz : z; }
+                    const int zb = idx[2] - z0;                          // slab-local z of the first plane; the other four follow without a wrap
                     Real fx = 0, fy = 0, fz = 0, psi = 0;
                     const bool inBrick = rx >= -HALO_LO && rx + 4 < bx - HALO_LO && ry >= -HALO_LO && ry + 4 < by - HALO_LO;
 #pragma unroll
@@ -1134,7 +1135,7 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
                             if (inBrick) {
                                 const Real* line = brick + (size_t)((rx + HALO_LO + ix) * by + (ry + HALO_LO + iy)) * bz;
 #pragma unroll
-                                for (int iz = 0; iz < 5; iz++) { const Real gv = line[zl[iz]]; sv += tz[iz] * gv; sdz += dz[iz] * gv; }
+                                for (int iz = 0; iz < 5; iz++) { const Real gv = line[zb + iz]; sv += tz[iz] * gv; sdz += dz[iz] * gv; }
                             } else {   // drifted further than the halo since the last re-sort: correct but slow path through global memory
                                 int x = idx[0] + ix; if (x >= p.d.nx) x -= p.d.nx;
                                 int y = idx[1] + iy; if (y >= p.d.ny) y -= p.d.ny;
@@ -1169,7 +1170,7 @@ template <typename Real> static void launchInterpolateBricks(const PmeParams<Rea
         static const int zsEnv = getenv("SNB_INTERP_ZSLABS") ? atoi(getenv("SNB_INTERP_ZSLABS")) : 0;
         int zSlabs = 1;      // measured on c3: 1 slab 52 us, 2 slabs 70, 4 slabs 72 (every slab rescans the columns' atoms)
         if (zsEnv > 0 && p.d.nz % zsEnv == 0 && p.d.nz / zsEnv >= 8) zSlabs = zsEnv;
-        const int bz = zSlabs == 1 ? p.d.nz : p.d.nz / zSlabs + 4;
+        const int bz = p.d.nz / zSlabs + 4;
         const size_t lds = ((sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * bz + 15) & ~(size_t)15) + sizeof(double) * p.nsubTotal * (p.nsubTotal + 1);
         static const bool noBrick = getenv("SNB_NO_INTERP_BRICKS") != nullptr;   // testing aid: force the 32-lanes-per-atom kernel
         if (lds <= 150 * 1024 && !noBrick && p.nsubTotal * p.groupX * p.groupY <= 256) {
@@ -1195,7 +1196,7 @@ template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hip
             if (gEnv >= 0 ? step >= gEnv : nb <= 256) break;
             PmeParams<Real> t = q;
             if (step == 0 && t.sortNcx % (2 * t.groupX) == 0) t.groupX *= 2; else if (t.sortNcy % (2 * t.groupY) == 0) t.groupY *= 2; else break;
-            const size_t need = sizeof(Real) * (size_t)(t.groupX * (t.d.nx / t.sortNcx) + 6) * (t.groupY * (t.d.ny / t.sortNcy) + 6) * t.d.nz + 1024;
+            const size_t need = sizeof(Real) * (size_t)(t.groupX * (t.d.nx / t.sortNcx) + 6) * (t.groupY * (t.d.ny / t.sortNcy) + 6) * (t.d.nz + 4) + 1024;
             if (need > 150 * 1024 || t.nsubTotal * t.groupX * t.groupY > 256) break;
             q = t;
         }
