@@ -580,6 +580,20 @@ __device__ inline Cx<Real>* fftLines(Cx<Real>* a, Cx<Real>* b, int n, const int*
 
 extern __shared__ __align__(16) unsigned char s_dyn[];
 
+// Copy loops of the FFT kernels: `for (i = tid; i < n; i += NT) lds[f(i)] = global[g(i)]` compiles to ONE request in flight per thread
+// (the LDS store of trip i sits between the loads of trips i and i+1), i.e. n/NT dependent memory round trips -- 15 of them in the y
+// pass.  U requests are issued back to back into registers first, then stored.
+template <int U, typename T, typename LoadF, typename StoreF>
+__device__ __forceinline__ void batchedCopy(const int begin, const int end, const int stride, LoadF load, StoreF store) {
+    for (int i0 = begin; i0 < end; i0 += U * stride) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * stride; if (i < end) v[u] = load(i); }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * stride; if (i < end) store(i, v[u]); }
+    }
+}
+
 
 // ---- z axis: real <-> half-complex.  One work-group transforms NL contiguous real lines, TWO PER COMPLEX FFT: lines 2c and 2c+1
 // travel as the real and imaginary part of complex line c (z = a + i b, Z = A + i B with A, B Hermitian), so the z passes do half
@@ -618,14 +632,20 @@ template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bound
         }
     } else {
         const Cx<Real>* in = reinterpret_cast<const Cx<Real>*>(p.gridCplx) + line0 * nzc;
-        for (int it = tid; it < nb * nzc; it += 256) {
-            const int c = dzc.div(it), k = it - c * nzc;
-            const Cx<Real> a = in[(2 * c) * nzc + k];
-            Cx<Real> b = {Real(0), Real(0)};
-            if (2 * c + 1 < nl) b = in[(2 * c + 1) * nzc + k];
-            A[k * BS + c] = {a.x - b.y, a.y + b.x};                                         // A_k + i B_k
-            if (k > 0 && nz - k >= nzc) A[(nz - k) * BS + c] = {a.x + b.y, b.x - a.y};      // conj(A_k) + i conj(B_k)
-        }
+        struct Two { Cx<Real> a, b; };
+        batchedCopy<4, Two>(tid, nb * nzc, 256,
+            [&](int it) {
+                const int c = dzc.div(it), k = it - c * nzc;
+                Two t; t.a = in[(2 * c) * nzc + k]; t.b = {Real(0), Real(0)};
+                if (2 * c + 1 < nl) t.b = in[(2 * c + 1) * nzc + k];
+                return t;
+            },
+            [&](int it, const Two& t) {
+                const int c = dzc.div(it), k = it - c * nzc;
+                const Cx<Real> a = t.a, b = t.b;
+                A[k * BS + c] = {a.x - b.y, a.y + b.x};                                         // A_k + i B_k
+                if (k > 0 && nz - k >= nzc) A[(nz - k) * BS + c] = {a.x + b.y, b.x - a.y};      // conj(A_k) + i conj(B_k)
+            });
         Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, +1, tw, nb, BS, tid, 256);
         __syncthreads();
         Real* out = p.gridReal + line0 * nz;
@@ -652,10 +672,9 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(256) void 
     const int tid = threadIdx.x;
     for (int k = tid; k < n; k += 256) tw[k] = reinterpret_cast<const Cx<Real>*>(axis == 1 ? p.twy : p.twx)[k];
     const FastDiv dnb(nb);
-    for (int it = tid; it < n * nb; it += 256) {
-        const int k = dnb.div(it), b = it - k * nb;
-        A[k * NB + b] = g[(size_t)k * strideK + b];
-    }
+    batchedCopy<8, Cx<Real>>(tid, n * nb, 256,
+        [&](int it) { const int k = dnb.div(it), b = it - k * nb; return g[(size_t)k * strideK + b]; },
+        [&](int it, const Cx<Real>& v) { const int k = dnb.div(it), b = it - k * nb; A[k * NB + b] = v; });
     Cx<Real>* R = fftLines<Real, R1, R2>(A, B, n, axis == 1 ? p.d.fy : p.d.fx, axis == 1 ? p.d.nfy : p.d.nfx, sign, tw, nb, NB, tid, 256);
     __syncthreads();
     for (int it = tid; it < n * nb; it += 256) {
@@ -722,13 +741,15 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
     const int tid = threadIdx.x;
     // load: when nbc < NB the unused batch slots are zero-filled so the FFT can run on the full batch shape
     const FastDiv dBS(BS), dNB(NB), dNzc(p.d.nzc);
-    for (int it = tid; it < nx * BS; it += NT) {
-        const int k = dBS.div(it), bb = it - k * BS;
-        const int sub = dNB.div(bb), col = bb - sub * NB;
-        Cx<Real> v = {Real(0), Real(0)};
-        if (col < nbc) v = g[sub * strideSub + (size_t)k * strideK + c0 + col];
-        A[k * BS + bb] = v;
-    }
+    batchedCopy<8, Cx<Real>>(tid, nx * BS, NT,
+        [&](int it) {
+            const int k = dBS.div(it), bb = it - k * BS;
+            const int sub = dNB.div(bb), col = bb - sub * NB;
+            Cx<Real> v = {Real(0), Real(0)};
+            if (col < nbc) v = g[sub * strideSub + (size_t)k * strideK + c0 + col];
+            return v;
+        },
+        [&](int it, const Cx<Real>& v) { A[it] = v; });      // (k * BS + bb == it)
     for (int k = tid; k < nx; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twx)[k];
     Cx<Real>* S = fftLines<Real, R1, R2>(A, B, nx, p.d.fx, p.d.nfx, -1, tw, BS, BS, tid, NT);
     Cx<Real>* O = (S == A) ? B : A;
