@@ -288,6 +288,31 @@ def test_changing_parameters(snb, F, oev, prec):
     check()
 
 
+def test_box_change_between_rebuilds(snb, F, oev, prec):
+    """A barostat-like sequence: the periodic box (and the coordinates with it) is rescaled between evaluations.  Every rebuild must
+    pick the new cell up -- the replayed graph of the rebuild's sort phase is keyed on it -- and the answers must stay the oracle's."""
+    n, L = 13824, 6.0
+    force, pos, box = systems.random_box(F, n, 3, 4, L, 1.0, pme=(2.6283, 48, 48, 48))
+    system = snb.System()
+    for _ in range(n):
+        system.addParticle(1.0)
+    system.setDefaultPeriodicBoxVectors(*box)
+    system.addForce(force)
+    ctx = snb.Context(system, precision=prec, neighbor_padding=0.05, rebuild_interval=1)
+    tol = TOLS[prec]
+    pos = np.asarray(pos, dtype=float)
+    for scale in (1.0, 1.01, 1.01, 0.995, 1.0):      # (the repeated value replays the captured sort phase)
+        b = [[v * scale for v in row] for row in box]
+        ctx.setPeriodicBoxVectors(*b)
+        ctx.setPositions(pos * scale)
+        st = ctx.getState(getEnergy=True, getForces=True)
+        o = oev(force, pos * scale, b)
+        K.assertEqualTo(o["energy"], st.getPotentialEnergy(), tol)
+        fo, fr = o["forces"], st.getForces()
+        err = np.linalg.norm(fo - fr, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)
+        assert err.max() <= tol, (scale, err.max())
+
+
 def test_huge_system_energy_follows_forces(snb, F, prec):
     """testHugeSystem (TestSlicedNonbondedForce.h:557-612) at its full size: 150^3 = 3 375 000 particles, CutoffPeriodic with a
     switching function; stepping along the force direction must change the energy by |F| * delta."""
