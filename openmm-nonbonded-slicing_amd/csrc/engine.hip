@@ -1019,9 +1019,9 @@ public:
         const bool energy = includeEnergy != 0;
         lastRecip = includeRecip && (isPme() || cfg.method == SNB_Ewald);
         // Forces-only steps replay a captured hipGraph (the ~14 small launches of a step are host-launch-bound otherwise:
-        // 7-8 us of idle GPU between kernels).  Every 16th step -- and every energy step -- is enqueued eagerly with HIP events
+        // 7-8 us of idle GPU between kernels).  Every 32nd step -- and every energy step -- is enqueued eagerly with HIP events
         // around the pair kernel and the reciprocal pipeline; those samples feed snb_stats' kernel timers.
-        const bool eager = energy || cfg.disable_graph || (execCount++ % 16 == 0);
+        const bool eager = energy || cfg.disable_graph || (execCount++ % 32 == 0);
         if (eager) {
             EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
             if (ev.pending) harvest(ev);
@@ -1193,7 +1193,8 @@ public:
         stats.sum_direct_ms += a; stats.sum_recip_ms += b; stats.sum_total_ms += c; stats.n_timed++;
         ev.pending = false;
     }
-    void resetTimers() override { for (auto& r : ring) if (r.pending) harvest(r); stats.sum_direct_ms = stats.sum_recip_ms = stats.sum_total_ms = 0; stats.n_timed = 0; }
+    // (also restarts the eager-step cadence: the first step after a reset is a timed one, so even a short measured region has a sample)
+    void resetTimers() override { for (auto& r : ring) if (r.pending) harvest(r); stats.sum_direct_ms = stats.sum_recip_ms = stats.sum_total_ms = 0; stats.n_timed = 0; execCount = 0; }
 
     void runPme(PmeParams<Real>& pp, hipStream_t st) {
         const bool zDone = launchPmeSpread<Real>(pp, st);
