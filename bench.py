@@ -387,6 +387,21 @@ def main():
         elapsed = float(tt.item())
     st = eng.stats()
     ms_per_step = elapsed * 1e3 / args.steps
+    resident_ms = None
+    if world == 1:
+        # For the record (never `value`): the same evaluations fed from two coordinate sets generated beforehand, i.e. nothing but
+        # force evaluations on the stream.  The coordinate-update kernel of the main region stands where an integrator would; each
+        # transition between a plain kernel and a replayed step graph costs ~17 us of idle GPU on this stack.
+        ring = [pos0 + math.sin(0.37 * j) * jit for j in (1, 2)]
+        n_res = max(20, min(args.steps, 100))
+        for i in range(4):
+            eng.set_positions_device(ring[i % 2].data_ptr(), is_double); eng.execute(False); eng.forces_to(forces.data_ptr(), is_double)
+        eng.sync(); torch.cuda.synchronize()
+        tr = time.perf_counter()
+        for i in range(n_res):
+            eng.set_positions_device(ring[i % 2].data_ptr(), is_double); eng.execute(False); eng.forces_to(forces.data_ptr(), is_double)
+        eng.sync(); torch.cuda.synchronize()
+        resident_ms = (time.perf_counter() - tr) * 1e3 / n_res
     ns_day = 86.4 * 2.0 / ms_per_step
     T = int(st.n_tiles)
     direct_ms = st.sum_direct_ms / max(st.n_timed, 1)
@@ -411,6 +426,7 @@ def main():
                    % (cfg_name, N, Lbox, nsub, "PME" if method == 4 else "LJPME", st.grid[0], (" + dispersion %d^3" % st.dgrid[0]) if method == 5 else "",
                       len(w["exc_qq"]), args.padding),
                    "tiles_32x32": T, "blocks": int(st.n_blocks), "rebuild_interval": args.rebuild_interval, "rebuilds_in_timed_region": int(st.n_rebuilds) - rebuilds_before, "host_rebuilds": int(st.n_host_rebuilds), "neighbor_rebuild_ms": round(st.last_rebuild_ms, 2),
+                   "ms_per_step_resident_coordinates": round(resident_ms, 4) if resident_ms is not None else None,
                    "first_call_ms": round(first_ms, 1), "energy_step_ms": round(energy_ms, 3), "energy_step_gpu_ms": round(eng.stats().last_total_ms, 3),
                    "gpu_ms_per_step": round(gpu_ms, 4), "direct_kernel_ms": round(direct_ms, 4), "reciprocal_ms": round(recip_ms, 4),
                    "parallelism": ("subset-grid + i-block sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},

@@ -236,9 +236,12 @@ public:
         bool operator==(const GraphKey& o) const { return pos == o.pos && isDouble == o.isDouble && stride4 == o.stride4 && direct == o.direct && recip == o.recip && out == o.out && outDouble == o.outDouble && outAcc == o.outAcc; }
     };
     void* outPtr = nullptr; int outIsDouble = 0, outAccumulate = 0; bool outputWritten = false;   // snb_set_force_output
-    hipGraphExec_t graphExec = nullptr; GraphKey graphKey{}; long long execCount = 0;
+    // captured step graphs, a few at a time: a caller that alternates between position (or output) buffers keeps one graph per buffer
+    struct CachedGraph { GraphKey key; hipGraphExec_t exec; };
+    std::vector<CachedGraph> graphs; size_t graphVictim = 0; long long execCount = 0;
+    static constexpr size_t MAX_GRAPHS = 4;
     hipGraphExec_t sortGraphExec = nullptr; std::vector<unsigned char> sortGraphKey; bool sortGraphBroken = false;      // phase A of the neighbour rebuild
-    void dropGraph() { if (graphExec) { (void)hipGraphExecDestroy(graphExec); graphExec = nullptr; } }
+    void dropGraph() { for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); graphs.clear(); graphVictim = 0; }
     bool lastRecip = false;
     snb_stats stats;
 
@@ -1029,8 +1032,9 @@ public:
             ev.pending = true;
         } else {
             GraphKey key{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0, outPtr, outIsDouble, outAccumulate};
-            if (!graphExec || !(key == graphKey)) {
-                dropGraph();
+            hipGraphExec_t graphExec = nullptr;
+            for (auto& g : graphs) if (g.key == key) { graphExec = g.exec; break; }
+            if (!graphExec) {
                 if (!stream2 && concurrentPme) {   // created outside the capture
                     int lo = 0, hi = 0;
                     HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -1044,7 +1048,8 @@ public:
                 HIPCHECK(hipStreamEndCapture(stream, &graph));
                 HIPCHECK(hipGraphInstantiate(&graphExec, graph, nullptr, nullptr, 0));
                 HIPCHECK(hipGraphDestroy(graph));
-                graphKey = key;
+                if (graphs.size() < MAX_GRAPHS) graphs.push_back({key, graphExec});
+                else { (void)hipGraphExecDestroy(graphs[graphVictim].exec); graphs[graphVictim] = {key, graphExec}; graphVictim = (graphVictim + 1) % MAX_GRAPHS; }
             }
             HIPCHECK(hipGraphLaunch(graphExec, stream));
         }

@@ -210,6 +210,40 @@ def test_forces_only_steps_vs_oracle(case, snb, F, oev, prec):
         pos = pos + rng.normal(0.0, 0.004, pos.shape)      # the list (skin 0.1 nm) is reused, the graph replayed
 
 
+def test_alternating_position_buffers_keep_their_step_graphs(snb):
+    """A caller that alternates between several device position buffers (double buffering against its integrator) must get, from every
+    buffer, what a fresh single-buffer engine gives for those coordinates: the engine keeps one captured step graph per buffer (a handful),
+    drops them all at a rebuild and evicts the oldest beyond its capacity (six buffers here, capacity four)."""
+    import torch
+    import bench
+    w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+    n = len(w["q"])
+    base = torch.tensor(w["pos"], dtype=torch.float32, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    bufs = [base + torch.randn(base.shape, generator=g, device="cuda") * 0.002 for _ in range(6)]
+    eng = bench.Engine(snb, w, 4, 54, 0, "single", 0, 0, 1, 0.1, 12)
+    out = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    got = {}
+    for step in range(40):                 # several rebuilds (every 12 steps), eager (timed) and replayed steps, evictions
+        k = (step * 5 + step // 7) % 6
+        eng.set_positions_device(bufs[k].data_ptr(), False); eng.execute(False); eng.forces_to(out.data_ptr(), False); eng.sync()
+        f = out.double().cpu().numpy()
+        assert np.isfinite(f).all()
+        if k in got:
+            err = np.linalg.norm(f - got[k], axis=1) / np.maximum(np.linalg.norm(got[k], axis=1), 1.0)
+            assert err.max() < 5e-4, (step, k, err.max())      # same coordinates; the sorted order, the list age and the float summation order differ
+        else:
+            got[k] = f
+    eng.close()
+    ref = bench.Engine(snb, w, 4, 54, 0, "single", 0, 0, 1, 0.1, 1 << 30)
+    for k in (0, 3, 5):
+        ref.set_positions_device(bufs[k].data_ptr(), False); ref.execute(False); ref.forces_to(out.data_ptr(), False); ref.sync()
+        f = out.double().cpu().numpy()
+        err = np.linalg.norm(f - got[k], axis=1) / np.maximum(np.linalg.norm(f, axis=1), 1.0)
+        assert err.max() < 5e-4, (k, err.max())
+    ref.close()
+
+
 def test_force_output_inside_the_step_graph(snb):
     """snb_set_force_output: the user-order force write becomes the last kernel of the (graph-replayed) step; the buffer must hold
     what snb_get_forces would have delivered, on eager and on replayed steps alike."""
