@@ -148,7 +148,7 @@ CONFIGS = {
     "c3l": (300000, 14.42, 4, 5, 120, 60, "single"),     # c3 with LJPME (dispersion mesh 60^3)
 }
 # 1-GPU rates of this build on MI355X (bench.py --config <name>, round 1), quoted beside N > 1 results of the same workload
-ONE_GPU_NS_DAY = {"c4": 235.1, "c3": 340.0, "c2": 746.6}
+ONE_GPU_NS_DAY = {"c4": 259.9, "c3": 361.5, "c2": 889.1}
 ALPHA = 2.6283
 CUTOFF = 1.0
 
@@ -311,6 +311,10 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
+    # a stream of our own for the harness kernels and the engine, as any application has: on the legacy default stream every transition
+    # between a harness kernel and the engine's work costs ~17 us of idle GPU (measured on c3: 0.508 vs 0.483 ms per step)
+    if not os.environ.get("SNB_BENCH_NULL_STREAM"):
+        torch.cuda.set_stream(torch.cuda.Stream())
     dev = torch.device("cuda", local)
     # N > 1 shards the SAME headline workload (strong scaling: 4 subset grids over min(N, 4) ranks, i-blocks over all N ranks); the
     # 8-subset box of BASELINE.json's multi-GPU config is `--config c4`
@@ -390,8 +394,7 @@ def main():
     resident_ms = None
     if world == 1:
         # For the record (never `value`): the same evaluations fed from two coordinate sets generated beforehand, i.e. nothing but
-        # force evaluations on the stream.  The coordinate-update kernel of the main region stands where an integrator would; each
-        # transition between a plain kernel and a replayed step graph costs ~17 us of idle GPU on this stack.
+        # force evaluations on the stream.  The coordinate-update kernel of the main region stands where an integrator would.
         ring = [pos0 + math.sin(0.37 * j) * jit for j in (1, 2)]
         n_res = max(20, min(args.steps, 100))
         for i in range(4):

@@ -1024,7 +1024,8 @@ public:
         // Forces-only steps replay a captured hipGraph (the ~14 small launches of a step are host-launch-bound otherwise:
         // 7-8 us of idle GPU between kernels).  Every 32nd step -- and every energy step -- is enqueued eagerly with HIP events
         // around the pair kernel and the reciprocal pipeline; those samples feed snb_stats' kernel timers.
-        const bool eager = energy || cfg.disable_graph || (execCount++ % 32 == 0);
+        static const bool noStepGraph = getenv("SNB_NO_STEP_GRAPH") != nullptr;      // measurement aid: every step as plain launches
+        const bool eager = energy || cfg.disable_graph || noStepGraph || (execCount++ % 32 == 0);
         if (eager) {
             EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
             if (ev.pending) harvest(ev);

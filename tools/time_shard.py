@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 snb = importlib.import_module("openmm-nonbonded-slicing_amd")
+torch.cuda.set_stream(torch.cuda.Stream())      # not the legacy default stream (see bench.py)
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 cfg = sys.argv[2] if len(sys.argv) > 2 else "c4"
 n_target, L, nsub, method, grid, dgrid, precision = bench.CONFIGS[cfg]
