@@ -1025,7 +1025,10 @@ public:
         // 7-8 us of idle GPU between kernels).  Every 32nd step -- and every energy step -- is enqueued eagerly with HIP events
         // around the pair kernel and the reciprocal pipeline; those samples feed snb_stats' kernel timers.
         static const bool noStepGraph = getenv("SNB_NO_STEP_GRAPH") != nullptr;      // measurement aid: every step as plain launches
-        const bool eager = energy || cfg.disable_graph || noStepGraph || (execCount++ % 32 == 0);
+        // (the step right after a rebuild goes out as plain launches: the GPU is idle at that point -- the rebuild ended with a host
+        // read-back -- and capturing + instantiating the step graph first would keep it idle for another ~50 us; the capture then happens
+        // at the next step, while this one is executing)
+        const bool eager = energy || cfg.disable_graph || noStepGraph || rebuilding || (execCount++ % 32 == 0);
         if (eager) {
             EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
             if (ev.pending) harvest(ev);
