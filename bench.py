@@ -148,7 +148,7 @@ CONFIGS = {
     "c3l": (300000, 14.42, 4, 5, 120, 60, "single"),     # c3 with LJPME (dispersion mesh 60^3)
 }
 # 1-GPU rates of this build on MI355X (bench.py --config <name>, round 1), quoted beside N > 1 results of the same workload
-ONE_GPU_NS_DAY = {"c4": 259.9, "c3": 361.5, "c2": 889.1}
+ONE_GPU_NS_DAY = {"c4": 259.9, "c3": 365.1, "c2": 889.1}
 ALPHA = 2.6283
 CUTOFF = 1.0
 
