@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
         } else { x.x = Real(3e9) + Real(1e6) * c; x.y = Real(-5e9); x.z = Real(7e9); x.w = 0; se.x = 0; se.y = 0; }
     };
     struct TileHead { int slice, maskIdx; };
-    auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x, v.y}; };      // (slice of the tile, mask index)
+    auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x & 0xFFFF, v.y}; };      // (slice of the tile [low 16 bits; the rest is the sub-tile occupancy of k_directSub], mask index)
     auto loadMask = [&](const TileHead& h) { return (h.maskIdx >= 0) ? p.masks[h.maskIdx * 32 + il] : 0u; };
     int jcode = p.tileJ[tBegin * 32 + stageJ];
     TileHead head = loadHead(tBegin);
@@ -380,18 +380,14 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
             for (int k = 9; k >= 0; k--) bt = bt * t + p.ewPoly[k];
             f = f * invR2 + qq * (invR2 * invR - bt);
             if (ENERGY) {
-                // the pair ENERGY keeps the A&S erfc (relative accuracy near the cutoff, where erfc ~ 4e-5 and most pairs sit): a polynomial
-                // for erf(ar)/r leaves a one-signed 1e-7 residue there that adds up over 6e7 pairs (measured: slice-energy error 9e-4 vs 4e-4)
-                const v2f ar = (r2 * invR) * p.alpha;
-                const v2f e2 = r2 * (-p.alpha2l2e);
-                const v2f ex = {__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
-                const v2f den = ar * 0.3275911f + 1.0f;
-                const v2f tt = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                v2f poly = tt * 1.061405429f + (-1.453152027f);
-                poly = poly * tt + 1.421413741f;
-                poly = poly * tt + (-0.284496736f);
-                poly = poly * tt + 0.254829592f;
-                eC = (qqRaw * invR) * (poly * tt * ex);
+                // pair ENERGY: qq (1/r - Et(r^2)), Et = erf(ar)/r a degree-13 polynomial in the same t.  The A&S erfc used before is good to
+                // 1.5e-7 absolute, but its error is one-signed over most of the range and qq erfc(ar)/r is summed over 6e7 pairs: +1.0 kJ/mol
+                // on the water-water slice of the 96k-atom box, whose direct (6.5e6) and reciprocal (-6.5e6) parts cancel to 788 -- 1.3e-3.
+                // Degree 13 leaves a tenth of that (tools/erfc_energy_check.py; degree 11 is worse than A&S, beyond 13 float coefficients limit it).
+                v2f et = t * p.ewPolyE[13] + p.ewPolyE[12];
+#pragma unroll
+                for (int k = 11; k >= 0; k--) et = et * t + p.ewPolyE[k];
+                eC = qqRaw * (invR - et);
             }
         } else if (MC == MC_EWALD || MC == MC_LJPME) {
             const v2f r = r2 * invR;
@@ -498,7 +494,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     auto requestList = [&](TileRegs& r, int t) {                    // list entry + header of tile t
         r.jcode = p.tileJ[t * 32 + stageJ];
         const int2 v = *reinterpret_cast<const int2*>(&p.tileInfo[t + vzero]);
-        r.slice = v.x; r.maskIdx = v.y;
+        r.slice = v.x & 0xFFFF; r.maskIdx = v.y;      // (bits 16.. of .x: sub-tile occupancy, used by k_directSub)
     };
     auto requestAtoms = [&](TileRegs& r) {                          // needs r.jcode / r.slice / r.maskIdx (requested a tile earlier)
         const int code = r.jcode;
@@ -700,13 +696,22 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
                 const Real ex = fexp(-ar * ar);
                 // energy evaluations use libm erf in double even in the single-precision engine: the raw slice energy is a
                 // small difference of large direct/reciprocal/exclusion sums and a 1e-7 bias in erf would show up in it.
-                const double erfv = ENERGY ? erf((double)ar) : erfOf(ar, ex);
+                // The exclusion-correction ENERGY of a solvated box is a huge sum (2e7 kJ/mol for 300k atoms of water: every O-H and H-H pair of
+                // every molecule) that the reciprocal-space energy cancels to a few thousand: it is formed in double from the stored
+                // coordinates, charges and the double alpha -- products like k*qO*qH rounded to float are off by the SAME 1e-7 for all
+                // 2e5 identical pairs, which alone was 0.8 kJ/mol (1.1e-3 of the water-water slice of the 96k-atom box).
+                double erfv, rd = 0, qqd = 0;
+                if (ENERGY) {
+                    rd = sqrt((double)dx * (double)dx + (double)dy * (double)dy + (double)dz * (double)dz);
+                    qqd = (double)xi.w * (double)xj.w * SNB_ONE_4PI_EPS0;
+                    erfv = erf(p.alpha64 * rd);
+                } else erfv = erfOf(ar, ex);
                 Real f = 0;
                 if (erfv > 1e-6) {
                     f = -lamC * qq * invR * invR * invR * (Real(erfv) - ar * ex * Real(1.1283791670955126));
-                    if (ENERGY) __hip_atomic_fetch_add(&s_sliceE[2 * slice], -0.5 * (double)qq * (double)invR * erfv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (ENERGY) __hip_atomic_fetch_add(&s_sliceE[2 * slice], -0.5 * qqd * erfv / rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else if (ENERGY)
-                    __hip_atomic_fetch_add(&s_sliceE[2 * slice], -0.5 * (double)p.alpha * 1.1283791670955126 * (double)qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_sliceE[2 * slice], -0.5 * p.alpha64 * 1.1283791670955126 * qqd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (p.ljpme) {
                     const auto sej = p.sigeps[b];
                     const Real c6 = c6i * (Real(8) * sej.x * sej.x * sej.x * sej.y);

@@ -297,7 +297,7 @@ public:
     // (12 packed FMAs replace v_exp + v_rcp + the A&S erfc polynomial), degree 20 to ~1e-13 in double (replaces libm erfc + exp).  Absolute force error per pair stays below that of the A&S path at short range and
     // below 2e-6 * qq near the cutoff (tools/ewald_poly_check.py).
     static constexpr int EW_DEG = sizeof(Real) == 4 ? 11 : 20;      // 1e-7 resp. ~1e-13 of Bt(0)
-    double ewPoly[EW_DEG + 1] = {0}; double ewR2Max = 1;
+    double ewPoly[EW_DEG + 1] = {0}; double ewPolyE[14] = {0}; double ewR2Max = 1;
     void buildEwaldPoly() {
         const double rmax = cfg.cutoff + std::max(cfg.neighbor_padding, 0.0) + 0.02, a = cfg.alpha;
         ewR2Max = rmax * rmax;
@@ -307,6 +307,13 @@ public:
             return (std::erf(z) - 2.0 * z / std::sqrt(SNB_PI) * std::exp(-z * z)) / (r2 * r);
         };
         chebyshevToMonomial(bt, EW_DEG, ewPoly);
+        // pair energies of the packed kernel: Et(r^2) = erf(a r)/r, entire in r^2 as well, Et(0) = 2a/sqrt(pi)
+        auto et = [&](double r2) {
+            const double r = std::sqrt(r2), z = a * r;
+            if (z < 1e-3) return a * (2.0 / std::sqrt(SNB_PI)) * (1.0 - z * z / 3.0 + z * z * z * z / 10.0);
+            return std::erf(z) / r;
+        };
+        chebyshevToMonomial(et, 13, ewPolyE);
     }
     // Chebyshev interpolant of f(r^2) over [0, ewR2Max] at 96 nodes, truncated at `deg`, as monomial coefficients in t = 2 r^2/ewR2Max - 1
     template <typename Fn> void chebyshevToMonomial(Fn f, int deg, double* out) {
@@ -843,6 +850,8 @@ public:
         p.slotOfSubset = dSlotOfSubset.p;
         p.wrapped = dWrapped.p; p.offsetU = dOffsetU.p; p.keysIn = dKeysIn.p; p.keysOut = dKeysOut.p; p.valsIn = dValsIn.p; p.valsOut = dValsOut.p;
         p.segKey = dValsIn.p; p.segStart = dScanA.p; p.padExtra = dScanB.p; p.padBefore = dScanA.p;   // valsIn is dead once the sort has run
+        p.slotMap = dScanB.p;      // (padExtra is dead once phase A has produced the padded count)
+        { static const bool noOrder = getenv("SNB_NO_BLOCK_ORDER") != nullptr; p.orderBlocks = noOrder ? 0 : 1; }
         dScanC.resize(N); p.blockWide = dScanC.p; p.blockWideOut = dScanC.p;
         for (int d = 0; d < 3; d++) p.maxHalfExtent[d] = (float)(0.45 * (box[4 * d] - 2.0 * R));   // extent <= 0.9 (L - 2R)
         p.userToSorted = dUserToSorted.p; p.colRange = colRange.p; p.zIndex = dZIndex.p; p.counters = dCounters.p;
@@ -1111,7 +1120,7 @@ public:
             q.periodic = exPeriodic ? 1 : 0; q.imageOffset = imageOffset.p;
             q.sigeps = sigeps.p; q.blockSubset = blockSubset.p; q.exclStart = exclStart.p; q.exclList = exclList.p; q.nSlices = S; q.sortedToUser = dSortedToUser.p; q.userToSorted = dUserToSorted.p;
             for (int i = 0; i < 9; i++) q.box[i] = (Real)box[i];
-            q.alpha = (Real)cfg.alpha; q.alphaD = (Real)cfg.alpha_d; q.ljpme = cfg.method == SNB_LJPME;
+            q.alpha = (Real)cfg.alpha; q.alpha64 = cfg.alpha; q.alphaD = (Real)cfg.alpha_d; q.ljpme = cfg.method == SNB_LJPME;
             q.pairs = pairs14.p; q.params = params14.p; q.n = n14;
             q.nExclAtoms = (ew && nExcl > 0) ? Npad : 0;
         }
@@ -1131,6 +1140,7 @@ public:
             p.alpha = (Real)cfg.alpha; p.alphaD = (Real)cfg.alpha_d; p.k4pe = (Real)SNB_ONE_4PI_EPS0;
             p.alpha2l2e = (Real)(cfg.alpha * cfg.alpha * 1.4426950408889634);
             for (int i = 0; i <= EW_DEG; i++) p.ewPoly[i] = (Real)ewPoly[i];
+            for (int i = 0; i < 14; i++) p.ewPolyE[i] = (Real)ewPolyE[i];
             p.ewScale = (Real)(2.0 / ewR2Max);
             { static const bool noPoly = getenv("SNB_EWALD_ERFC") != nullptr; p.ewUsePoly = noPoly ? 0 : 1; }
             const double ic2 = 1.0 / (cfg.cutoff * cfg.cutoff), ic6 = ic2 * ic2 * ic2;
@@ -1222,11 +1232,15 @@ public:
         if (recip && cfg.method >= SNB_Ewald) {
             if (!hostSumsValid) {      // O(N) sums over the particle parameters: recomputed only when the parameters change
                 subsetCharge.assign(nsub, 0.0); selfCoulomb.assign(nsub, 0.0); selfDispersion.assign(nsub, 0.0);
+                // from the parameters AS THE DEVICE HOLDS THEM (rounded to Real): the self energy cancels the self-interaction inside the
+                // reciprocal sum, which is quadratic in the stored charges -- with the unrounded doubles here a single-precision engine
+                // would be off by 2e-8 of 7e6 kJ/mol per 100k atoms of water
                 for (int i = 0; i < N; i++) {
                     const int s = subset[i];
-                    subsetCharge[s] += charge[i];
-                    selfCoulomb[s] -= SNB_ONE_4PI_EPS0 * charge[i] * charge[i] * cfg.alpha / std::sqrt(SNB_PI);
-                    if (cfg.method == SNB_LJPME) selfDispersion[s] += std::pow(cfg.alpha_d, 6.0) * 64.0 * std::pow(0.5 * sigma[i], 6.0) * std::pow(2.0 * std::sqrt(epsilon[i]), 2.0) / 12.0;
+                    const double q = (double)(Real)charge[i], hs = (double)(Real)(0.5 * sigma[i]), se = (double)(Real)(2.0 * std::sqrt(epsilon[i]));
+                    subsetCharge[s] += q;
+                    selfCoulomb[s] -= SNB_ONE_4PI_EPS0 * q * q * cfg.alpha / std::sqrt(SNB_PI);
+                    if (cfg.method == SNB_LJPME) selfDispersion[s] += std::pow(cfg.alpha_d, 6.0) * 64.0 * std::pow(hs, 6.0) * se * se / 12.0;
                 }
                 hostSumsValid = true;
             }

@@ -297,6 +297,14 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
         if (tid == 0) s_count = 0;
         __syncthreads();
     }
+    // Reading a point back.  Fixed point: the two halves of a 64-bit word were summed as ONE signed integer, hi * 2^32 + lo, so the upper
+    // word holds hi - 1 whenever the lower half's sum is negative: the borrow is returned here.  (Without it every odd-z point beside a
+    // negative even-z point was low by one unit, 1.2e-8 e: a uniform spurious charge of -1e-3 e per subset grid of c4, whose interaction
+    // with the boundary double layers of the OTHER water shells put -0.03 kJ/mol into every cross slice -- 3.6e-3 of an 8 kJ/mol slice.)
+    auto brickValue = [&](int i) -> Real {
+        if constexpr (FIXED) { const int v = (int)brick[i]; return (Real)((i & 1) ? v + (int)((unsigned)brick[i - 1] >> 31) : v); }
+        else return (Real)brick[i];
+    };
     if constexpr (FUSEZ) {
         // forward z FFT of the brick's own lines straight out of LDS (zSlabs == 1: the brick holds whole lines), two real lines per
         // complex transform as in k_fftZ; the real grid is never written and the separate z pass is skipped
@@ -309,8 +317,8 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
         const Real inv = FIXED ? p.fixInv : Real(1);
         for (int it = tid; it < nb * nz; it += NT) {
             const int c = dz.div(it), k = it - c * nz;
-            const Real a = (Real)brick[(2 * c) * nz + k] * inv;
-            const Real b = (2 * c + 1 < nl) ? (Real)brick[(2 * c + 1) * nz + k] * inv : Real(0);
+            const Real a = brickValue((2 * c) * nz + k) * inv;
+            const Real b = (2 * c + 1 < nl) ? brickValue((2 * c + 1) * nz + k) * inv : Real(0);
             A[k * BS + c] = {a, b};
         }
         Cx<Real>* R = fftLines<Real, 0, 0>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, NT);
@@ -333,7 +341,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
     for (int i = tid; i < npts; i += NT) {
         const int l = dsz.div(i), z = i - l * sz;
         const int lx = dcy.div(l), ly = l - lx * cy;
-        g[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z0 + z] = FIXED ? (Real)brick[i] * p.fixInv : (Real)brick[i];
+        g[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z0 + z] = FIXED ? brickValue(i) * p.fixInv : (Real)brick[i];
     }
 }
 

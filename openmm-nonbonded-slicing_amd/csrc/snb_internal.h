@@ -56,6 +56,7 @@ template <typename Real> struct DirectParams {
     int nsub;
     Real cutoff2, krf, crf, alpha, alphaD, k4pe;          // k4pe = ONE_4PI_EPS0
     Real alpha2l2e;                                        // alpha^2 * log2(e)
+    Real ewPolyE[14];                                      // energy steps of the packed kernel: erf(alpha r)/r ~ sum_k ewPolyE[k] t^k (degree 13, same t)
     Real ewPoly[21]; Real ewScale; int ewUsePoly;         // forces-only paths: Bt(r^2) ~ sum_k ewPoly[k] t^k, t = r^2 * ewScale - 1; degree 11 (float) / 20 (double), engine.hip buildEwaldPoly
     Real invCut6, multShift6;                              // LJPME potential shifts
     int useSwitch; Real switchDist, invSwitchWidth;
@@ -82,6 +83,7 @@ template <typename Real> struct PairListParams {  // 1-4 exceptions: one thread 
     const Real* imageOffset;  // [Npad*3] wrapped - user coordinates (to undo the wrap for non-periodic exceptions)
     Real box[9];
     Real alpha, alphaD;
+    double alpha64;           // the Ewald alpha unrounded (energy evaluations of the exclusion corrections run in double)
     int ljpme;
 };
 
@@ -149,6 +151,7 @@ template <typename Real> struct NbParams {
     const int* uExclStart; const int* uExclList;
     const int* slotOfSubset;
     int* blockSubset;
+    int* slotMap; int orderBlocks;   // [nAtoms] padded index of sorted rank t after the in-block octet ordering (k_nbBlockOrder; may alias padExtra, dead by then)
     int* segKey; int* segStart; int* padExtra; int* padBefore;   // block segmentation scratch (segStart and padBefore may alias)
     const int* blockWide; int* blockWideOut;                     // [nAtoms] flags of over-extended blocks of the first segmentation pass
     float maxHalfExtent[3];                                      // a block is over-extended when an atom is further than this from its first atom

@@ -52,6 +52,8 @@ def lib():
         L.orc_bspline_moduli.argtypes = [ctypes.c_int, ctypes.c_int, dp]
         L.orc_fft3d.argtypes = [dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.orc_last_pair_count.restype = ctypes.c_longlong
+        L.orc_cutoff_band_pairs.argtypes = [ctypes.POINTER(OrcConfig), dp, dp, dp, dp, dp, ip, ctypes.c_int, ip, dp, ctypes.c_double, ctypes.c_longlong, ip, dp]
+        L.orc_cutoff_band_pairs.restype = ctypes.c_longlong
         _LIB = L
     return _LIB
 

@@ -98,9 +98,9 @@ static void pl_push(pairlist_t* pl, int i, int j) {
     pl->ij[2 * pl->n] = i; pl->ij[2 * pl->n + 1] = j; pl->n++;
 }
 
-static void build_pairlist(int n, const double* pos, const double* box, int periodic, double cutoff, const excl_t* ex, pairlist_t* pl) {
+/* pairs with r2lo <= r^2 < r2hi (r2lo < 0: everything below r2hi); `cutoff` bounds the cell size and must be >= sqrt(r2hi) */
+static void build_pairlist_band(int n, const double* pos, const double* box, int periodic, double cutoff, double r2lo, double rc2, const excl_t* ex, pairlist_t* pl) {
     pl->ij = NULL; pl->n = 0; pl->cap = 0;
-    double rc2 = cutoff * cutoff;
     int rect = periodic && box[3] == 0 && box[6] == 0 && box[7] == 0;
     int nc[3] = {0, 0, 0};
     if (rect) for (int d = 0; d < 3; d++) { nc[d] = (int)floor(box[4 * d] / cutoff); }
@@ -109,7 +109,8 @@ static void build_pairlist(int n, const double* pos, const double* box, int peri
             for (int j = i + 1; j < n; j++) {
                 double d[3];
                 if (periodic) delta_periodic(pos + 3 * j, pos + 3 * i, box, d); else delta_plain(pos + 3 * j, pos + 3 * i, d);
-                if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2 && !is_excluded(ex, i, j)) pl_push(pl, i, j);
+                double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                if (r2 < rc2 && r2 >= r2lo && !is_excluded(ex, i, j)) pl_push(pl, i, j);
             }
         return;
     }
@@ -137,11 +138,15 @@ static void build_pairlist(int n, const double* pos, const double* box, int peri
                 if (j <= i) continue;
                 double d[3];
                 delta_periodic(pos + 3 * j, pos + 3 * i, box, d);
-                if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2 && !is_excluded(ex, i, j)) pl_push(pl, i, j);
+                double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                if (r2 < rc2 && r2 >= r2lo && !is_excluded(ex, i, j)) pl_push(pl, i, j);
             }
         }
     }
     free(head); free(next); free(cell);
+}
+static void build_pairlist(int n, const double* pos, const double* box, int periodic, double cutoff, const excl_t* ex, pairlist_t* pl) {
+    build_pairlist_band(n, pos, box, periodic, cutoff, -1.0, cutoff * cutoff, ex, pl);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -515,7 +520,7 @@ typedef struct {
 } ctx_t;
 
 /* ReferenceSlicedLJCoulombIxn.cpp:571-631 */
-static void one_ixn(const ctx_t* c, int ii, int jj, double* forces, double* sliceE) {
+static void one_pair(const ctx_t* c, int ii, int jj, double* fi, double* fj, double* sliceE) {
     const orc_config* cfg = c->cfg;
     int slice = slice_index(c->subset[ii], c->subset[jj]);
     double d[3];
@@ -542,7 +547,53 @@ static void one_ixn(const ctx_t* c, int ii, int jj, double* forces, double* slic
     sliceE[2 * slice + VDW] += energy;
     if (cutoff) sliceE[2 * slice + COUL] += qq * (inverseR + c->krf * r2 - c->crf); else sliceE[2 * slice + COUL] += qq * inverseR;
     double factor = c->lam[2 * slice + VDW] * dEdRvdW + c->lam[2 * slice + COUL] * dEdRCoul;
-    for (int k = 0; k < 3; k++) { double f = factor * d[k]; forces[3 * ii + k] += f; forces[3 * jj + k] -= f; }
+    for (int k = 0; k < 3; k++) { double f = factor * d[k]; fi[k] += f; fj[k] -= f; }
+}
+static void one_ixn(const ctx_t* c, int ii, int jj, double* forces, double* sliceE) { one_pair(c, ii, jj, forces + 3 * ii, forces + 3 * jj, sliceE); }
+
+/* one real-space Ewald / PME / LJPME pair (ReferenceSlicedLJCoulombIxn.cpp:367-445) */
+static void ewald_pair(const ctx_t* c, int ii, int jj, double* fi, double* fj, double* sliceE) {
+    const orc_config* cfg = c->cfg;
+    const int ljpme = cfg->method == ORC_LJPME;
+    const double alpha = cfg->alpha, alphaD = cfg->alpha_d, SQRT_PI = sqrt(ORC_PI);
+    const double invCut2 = 1.0 / (cfg->cutoff * cfg->cutoff), invCut6 = invCut2 * invCut2 * invCut2;
+    int slice = slice_index(c->subset[ii], c->subset[jj]);
+    double d[3];
+    delta_periodic(c->pos + 3 * jj, c->pos + 3 * ii, c->box, d);
+    double r = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), inverseR = 1.0 / r;
+    double switchValue = 1, switchDeriv = 0;
+    if (cfg->use_switch && r > cfg->switch_distance) {
+        double t = (r - cfg->switch_distance) / (cfg->cutoff - cfg->switch_distance);
+        switchValue = 1 + t * t * t * (-10 + t * (15 - t * 6));
+        switchDeriv = t * t * (-30 + t * (60 - t * 30)) / (cfg->cutoff - cfg->switch_distance);
+    }
+    double alphaR = alpha * r;
+    double qq = ORC_ONE_4PI_EPS0 * c->q[ii] * c->q[jj];
+    double dEdRCoul = qq * inverseR * inverseR * inverseR;
+    dEdRCoul *= erfc(alphaR) + 2 * alphaR * exp(-alphaR * alphaR) / SQRT_PI;
+    double sig = c->sig[ii] + c->sig[jj];
+    double sig2 = inverseR * sig; sig2 *= sig2;
+    double sig6 = sig2 * sig2 * sig2;
+    double eps = c->eps[ii] * c->eps[jj];
+    double dEdRvdW = switchValue * eps * (12.0 * sig6 - 6.0) * sig6 * inverseR * inverseR;
+    double vdwEnergy = eps * (sig6 - 1.0) * sig6;
+    if (ljpme) {
+        double dalphaR = alphaD * r, dar2 = dalphaR * dalphaR, dar4 = dar2 * dar2, dar6 = dar4 * dar2;
+        double inverseR2 = inverseR * inverseR;
+        double c6i = 8.0 * pow(c->sig[ii], 3.0) * c->eps[ii], c6j = 8.0 * pow(c->sig[jj], 3.0) * c->eps[jj];
+        double emult = c6i * c6j * inverseR2 * inverseR2 * inverseR2 * (1.0 - exp(-dar2) * (1.0 + dar2 + 0.5 * dar4));
+        dEdRvdW += 6.0 * c6i * c6j * inverseR2 * inverseR2 * inverseR2 * inverseR2 * (1.0 - exp(-dar2) * (1.0 + dar2 + 0.5 * dar4 + dar6 / 6.0));
+        sig2 = c->sig[ii] + c->sig[jj]; sig2 *= sig2; sig6 = sig2 * sig2 * sig2;
+        double potentialshift = eps * (1.0 - sig6 * invCut6) * sig6 * invCut6;
+        dalphaR = alphaD * cfg->cutoff; dar2 = dalphaR * dalphaR; dar4 = dar2 * dar2;
+        potentialshift -= c6i * c6j * invCut6 * (1.0 - exp(-dar2) * (1.0 + dar2 + 0.5 * dar4));
+        vdwEnergy += emult + potentialshift;
+    }
+    if (cfg->use_switch) { dEdRvdW -= vdwEnergy * switchDeriv * inverseR; vdwEnergy *= switchValue; }
+    double factor = c->lam[2 * slice + VDW] * dEdRvdW + c->lam[2 * slice + COUL] * dEdRCoul;
+    for (int k = 0; k < 3; k++) { double f = factor * d[k]; fi[k] += f; fj[k] -= f; }
+    sliceE[2 * slice + VDW] += vdwEnergy;
+    sliceE[2 * slice + COUL] += qq * inverseR * erfc(alphaR);
 }
 
 /* ReferenceSlicedLJCoulombIxn.cpp:179-507 */
@@ -644,46 +695,9 @@ static void ewald_ixn(const ctx_t* c, const excl_t* ex, const pairlist_t* pl, do
     if (!cfg->include_direct) return;
 
     /* real space (:367-445); the list already holds exactly the non-excluded pairs within the cutoff (Q5) */
-    double invCut2 = 1.0 / (cfg->cutoff * cfg->cutoff), invCut6 = invCut2 * invCut2 * invCut2;
     for (long long p = 0; p < pl->n; p++) {
         int ii = pl->ij[2 * p], jj = pl->ij[2 * p + 1];
-        int slice = slice_index(c->subset[ii], c->subset[jj]);
-        double d[3];
-        delta_periodic(c->pos + 3 * jj, c->pos + 3 * ii, c->box, d);
-        double r = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), inverseR = 1.0 / r;
-        double switchValue = 1, switchDeriv = 0;
-        if (cfg->use_switch && r > cfg->switch_distance) {
-            double t = (r - cfg->switch_distance) / (cfg->cutoff - cfg->switch_distance);
-            switchValue = 1 + t * t * t * (-10 + t * (15 - t * 6));
-            switchDeriv = t * t * (-30 + t * (60 - t * 30)) / (cfg->cutoff - cfg->switch_distance);
-        }
-        double alphaR = alpha * r;
-        double qq = ORC_ONE_4PI_EPS0 * c->q[ii] * c->q[jj];
-        double dEdRCoul = qq * inverseR * inverseR * inverseR;
-        dEdRCoul *= erfc(alphaR) + 2 * alphaR * exp(-alphaR * alphaR) / SQRT_PI;
-        double sig = c->sig[ii] + c->sig[jj];
-        double sig2 = inverseR * sig; sig2 *= sig2;
-        double sig6 = sig2 * sig2 * sig2;
-        double eps = c->eps[ii] * c->eps[jj];
-        double dEdRvdW = switchValue * eps * (12.0 * sig6 - 6.0) * sig6 * inverseR * inverseR;
-        double vdwEnergy = eps * (sig6 - 1.0) * sig6;
-        if (ljpme) {
-            double dalphaR = alphaD * r, dar2 = dalphaR * dalphaR, dar4 = dar2 * dar2, dar6 = dar4 * dar2;
-            double inverseR2 = inverseR * inverseR;
-            double c6i = 8.0 * pow(c->sig[ii], 3.0) * c->eps[ii], c6j = 8.0 * pow(c->sig[jj], 3.0) * c->eps[jj];
-            double emult = c6i * c6j * inverseR2 * inverseR2 * inverseR2 * (1.0 - exp(-dar2) * (1.0 + dar2 + 0.5 * dar4));
-            dEdRvdW += 6.0 * c6i * c6j * inverseR2 * inverseR2 * inverseR2 * inverseR2 * (1.0 - exp(-dar2) * (1.0 + dar2 + 0.5 * dar4 + dar6 / 6.0));
-            sig2 = c->sig[ii] + c->sig[jj]; sig2 *= sig2; sig6 = sig2 * sig2 * sig2;
-            double potentialshift = eps * (1.0 - sig6 * invCut6) * sig6 * invCut6;
-            dalphaR = alphaD * cfg->cutoff; dar2 = dalphaR * dalphaR; dar4 = dar2 * dar2;
-            potentialshift -= c6i * c6j * invCut6 * (1.0 - exp(-dar2) * (1.0 + dar2 + 0.5 * dar4));
-            vdwEnergy += emult + potentialshift;
-        }
-        if (cfg->use_switch) { dEdRvdW -= vdwEnergy * switchDeriv * inverseR; vdwEnergy *= switchValue; }
-        double factor = c->lam[2 * slice + VDW] * dEdRvdW + c->lam[2 * slice + COUL] * dEdRCoul;
-        for (int k = 0; k < 3; k++) { double f = factor * d[k]; forces[3 * ii + k] += f; forces[3 * jj + k] -= f; }
-        sliceE[2 * slice + VDW] += vdwEnergy;
-        sliceE[2 * slice + COUL] += qq * inverseR * erfc(alphaR);
+        ewald_pair(c, ii, jj, forces + 3 * ii, forces + 3 * jj, sliceE);
     }
 
     /* exclusion correction (:449-506) */
@@ -808,6 +822,55 @@ int orc_evaluate(const orc_config* cfg, const double* pos, const double* box,
     }
     free(sig); free(eps); free_exclusions(&ex); free(pl.ij);
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * DIAGNOSTIC for the parity tests -- not part of the restated path.  The truncated pair potential is discontinuous at the cutoff
+ * (ReferenceSlicedLJCoulombIxn.cpp:367 takes every pair of the neighbour list, i.e. r < cutoff, at full strength), so an
+ * implementation that evaluates r^2 in single precision may put a pair whose r^2 lies within rounding of cutoff^2 on the other side.
+ * This lists those pairs:  | r^2 / cutoff^2 - 1 | < rel_eps,  non-excluded, with what each would contribute:
+ *   out_ij[2k], out_ij[2k+1] = the atoms;  out_vals[4k..4k+3] = r, |F| on either atom (lambda-scaled, as in the forces),
+ *   raw Coulomb energy, raw vdW energy of the pair (as added to the slice energies).
+ * Returns the number of band pairs (only the first max_out are stored), or a negative error code.
+ * ---------------------------------------------------------------------------------------------- */
+long long orc_cutoff_band_pairs(const orc_config* cfg, const double* pos, const double* box,
+                                const double* charge, const double* sigma, const double* epsilon, const int* subset,
+                                int n_exc, const int* exc_pairs, const double* lambdas, double rel_eps,
+                                long long max_out, int* out_ij, double* out_vals) {
+    int n = cfg->n_atoms, ns = cfg->n_subsets, S = ns * (ns + 1) / 2;
+    int method = cfg->method;
+    if (method == ORC_NoCutoff || n < 0 || rel_eps <= 0 || rel_eps > 0.1) return -2;
+    int anyPeriodic = method >= ORC_CutoffPeriodic;
+    double* sig = (double*)malloc(sizeof(double) * (size_t)(n + 1));
+    double* eps = (double*)malloc(sizeof(double) * (size_t)(n + 1));
+    for (int i = 0; i < n; i++) { sig[i] = 0.5 * sigma[i]; eps[i] = 2.0 * sqrt(epsilon[i]); }
+    excl_t ex; build_exclusions(n, n_exc, exc_pairs, &ex);
+    pairlist_t pl = {NULL, 0, 0};
+    const double rc2 = cfg->cutoff * cfg->cutoff;
+    build_pairlist_band(n, pos, box, anyPeriodic, cfg->cutoff * sqrt(1.0 + rel_eps) * (1.0 + 1e-12), rc2 * (1.0 - rel_eps), rc2 * (1.0 + rel_eps), &ex, &pl);
+    ctx_t c;
+    orc_config local = *cfg;
+    if (method == ORC_LJPME || method == ORC_NoCutoff) local.use_switch = 0;
+    c.cfg = &local; c.pos = pos; c.box = box; c.subset = subset; c.sig = sig; c.eps = eps; c.q = charge; c.lam = lambdas;
+    c.periodic = method == ORC_CutoffPeriodic;
+    c.krf = pow(cfg->cutoff, -3.0) * (cfg->rf_dielectric - 1.0) / (2.0 * cfg->rf_dielectric + 1.0);
+    c.crf = (1.0 / cfg->cutoff) * (3.0 * cfg->rf_dielectric) / (2.0 * cfg->rf_dielectric + 1.0);
+    double* sliceE = (double*)malloc(sizeof(double) * 2 * (size_t)S);
+    for (long long p = 0; p < pl.n && p < max_out; p++) {
+        int ii = pl.ij[2 * p], jj = pl.ij[2 * p + 1];
+        double fi[3] = {0, 0, 0}, fj[3] = {0, 0, 0}, d[3];
+        for (int s = 0; s < 2 * S; s++) sliceE[s] = 0;
+        if (method >= ORC_Ewald) ewald_pair(&c, ii, jj, fi, fj, sliceE); else one_pair(&c, ii, jj, fi, fj, sliceE);
+        if (anyPeriodic) delta_periodic(pos + 3 * jj, pos + 3 * ii, box, d); else delta_plain(pos + 3 * jj, pos + 3 * ii, d);
+        int slice = slice_index(subset[ii], subset[jj]);
+        out_ij[2 * p] = ii; out_ij[2 * p + 1] = jj;
+        out_vals[4 * p] = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        out_vals[4 * p + 1] = sqrt(fi[0] * fi[0] + fi[1] * fi[1] + fi[2] * fi[2]);
+        out_vals[4 * p + 2] = sliceE[2 * slice + COUL]; out_vals[4 * p + 3] = sliceE[2 * slice + VDW];
+    }
+    long long count = pl.n;
+    free(sliceE); free(sig); free(eps); free_exclusions(&ex); free(pl.ij);
+    return count;
 }
 
 /* number of OpenMP threads the PME sections of the oracle use (the pair loop is serial, like the reference's) */

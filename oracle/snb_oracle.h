@@ -80,6 +80,14 @@ void orc_bspline_moduli(int n, int order, double* out);
 /* Unnormalised complex 3D FFT in place, data[nx][ny][nz] interleaved re/im. sign=-1 forward, +1 backward. */
 void orc_fft3d(double* data, int nx, int ny, int nz, int sign);
 
+/* DIAGNOSTIC for the parity tests (not part of the restated path): the non-excluded pairs with |r^2/cutoff^2 - 1| < rel_eps, i.e.
+ * the pairs a single-precision evaluation of r^2 may put on the other side of the (discontinuous) truncation.  out_ij[max_out][2],
+ * out_vals[max_out][4] = r, |F| the pair puts on either atom, raw Coulomb energy, raw vdW energy.  Returns the pair count. */
+long long orc_cutoff_band_pairs(const orc_config* cfg, const double* pos, const double* box,
+                                const double* charge, const double* sigma, const double* epsilon, const int* subset,
+                                int n_exc, const int* exc_pairs, const double* lambdas, double rel_eps,
+                                long long max_out, int* out_ij, double* out_vals);
+
 /* Number of within-cutoff, non-excluded pairs found by the last orc_evaluate() in this thread's process. */
 long long orc_last_pair_count(void);
 

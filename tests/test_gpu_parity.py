@@ -57,20 +57,21 @@ def test_native_library_loaded(snb):
                                   "testPeriodicExceptions", "testTriclinic", "testDispersionCorrection", "testTwoForces",
                                   "testParameterOffsets", "testEwaldExceptions", "testDirectAndReciprocal"])
 def test_reference_kat(case, snb, F, prec):
-    tol = 1e-3 if prec == "single" else K.TOL
-    kw = {}
+    """The reference's closed-form known answers at the reference's own tolerance, TOL = 1e-4 on every platform and precision
+    (tests/TestSlicedNonbondedForce.h:27, 106-108, 132-134, 254-259, 388-391, 487-489); testEwaldExceptions is 1e-3 on a
+    single-precision GPU platform there too (:620-622)."""
+    tol = K.TOL
+    if case == "testEwaldExceptions" and prec == "single":
+        tol = 1e-3
+    kw = dict(tol=tol)
     if case == "testTriclinic":
-        kw = dict(tol=1e-3 if prec == "single" else 1e-4, iterations=12)
-    elif case in ("testEwaldExceptions", "testDirectAndReciprocal", "testParameterOffsets"):
-        kw = dict(tol=tol)
-    else:
-        kw = dict(tol=tol)
+        kw["iterations"] = 12
     getattr(K, case)(make_ev(snb, prec), F, **kw)
 
 
 def test_switching_function(snb, F, prec):
-    tol = 1e-3 if prec == "single" else K.TOL
-    K.testSwitchingFunction(make_ev(snb, prec), F, 1, tol=tol, fd_tol=3e-3 if prec == "single" else 1e-3)
+    tol = K.TOL                                       # TestSlicedNonbondedForce.h:800 (TOL) and :811 (finite difference, 1e-3), all platforms
+    K.testSwitchingFunction(make_ev(snb, prec), F, 1, tol=tol, fd_tol=1e-3)
     if prec == "double":
         K.testSwitchingFunction(make_ev(snb, prec), F, 4, pme=(2.0, 30, 30, 30), tol=tol)
 
@@ -84,7 +85,7 @@ def test_nonbonded_slicing(method, exceptions, lj, snb, F, prec):
     if method == 3:   # classic Ewald: explicit alpha and kmax (auto-selection is OpenMM's calcEwaldParameters, unpinned)
         def Fm(nsub):
             f = F(nsub); f.ewaldKmax = (8, 8, 8); return f
-    K.testNonbondedSlicing(make_ev(snb, prec), Fm, method, exceptions, lj, tol=2e-3 if prec == "single" else K.TOL,
+    K.testNonbondedSlicing(make_ev(snb, prec), Fm, method, exceptions, lj, tol=1e-3 if prec == "single" else K.TOL,      # TestSlicedNonbondedForce.h:1039
                            pme=(1.0, n, n, n) if method in (4, 5) else ((1.0, 0, 0, 0) if method == 3 else None), ljpme=(1.0, n, n, n) if method == 5 else None)
 
 
@@ -271,7 +272,7 @@ def test_force_output_inside_the_step_graph(snb):
 
 @pytest.mark.parametrize("method", [0, 1, 2, 4, 5])
 def test_instantiate_from_nonbonded_force(method, snb, F, prec):
-    K.testInstantiateFromNonbondedForce(make_ev(snb, prec), F, method, pme=(1.0, 20, 20, 20) if method >= 4 else None, tol=1e-3 if prec == "single" else K.TOL)
+    K.testInstantiateFromNonbondedForce(make_ev(snb, prec), F, method, pme=(1.0, 20, 20, 20) if method >= 4 else None, tol=K.TOL)      # TestSlicedNonbondedForce.h:76-84
 
 
 @pytest.mark.parametrize("method", [2, 4, 5])
