@@ -129,8 +129,11 @@ snb_status snb_set_positions(snb_handle h, const void* pos, int32_t is_device, i
 snb_status snb_rebuild_neighbors(snb_handle h);             /* force a tile rebuild at the next execute */
 
 /* -- the hot path ------------------------------------------------------------------------------ */
-/* Enqueues one evaluation.  energy (may be NULL) receives sum_slices lambda*E when include_energy != 0
- * (this synchronises the stream); forces stay on the device until snb_get_forces. */
+/* Enqueues one evaluation; forces stay on the device until snb_get_forces.  include_energy != 0: the raw per-slice energies are
+ * accumulated as well (the step of every force with energy-parameter derivatives: the reference adds dE/dlambda on every execute,
+ * CommonNonbondedSlicingKernels.cpp:712-718) and summed ON THE DEVICE as the step's last kernel.  With energy == NULL nothing is read
+ * back and nothing synchronises -- such a step replays a captured graph like a forces-only one; snb_get_slice_energies fetches the
+ * sums when the caller needs them.  With energy != NULL it receives sum_slices lambda*E (this synchronises the stream). */
 snb_status snb_execute(snb_handle h, int32_t include_forces, int32_t include_energy, int32_t include_direct,
                        int32_t include_reciprocal, double* energy);
 /* out: [N][3] in the type selected by is_double; accumulate != 0 adds to what is there (the reference

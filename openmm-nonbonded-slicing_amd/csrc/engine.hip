@@ -182,6 +182,7 @@ public:
     // ring of per-execute event sets, harvested lazily into cumulative kernel times (no per-step host sync)
     static constexpr int RING = 32;
     hipEvent_t evRebuild[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t evStepDone[2] = {nullptr, nullptr}; long long stepCounter = 0;      // displacement-triggered rebuilds: end-of-execute events
     hipStream_t stream2 = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;
     // measured on c3: serial 0.80 ms/step, forked 0.87 (default priority) / 1.32 (high or low priority): the graph's cross-stream
     // dependencies cost more than the overlap returns, so the fork is opt-in
@@ -200,8 +201,30 @@ public:
     int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0, shardTiles = 0; bool wrapMode = false;
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
-    struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // six views of forceBuf: one memset clears them all
-    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC, dAtomCell, dExtent;
+    struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // views of forceBuf (7 Npad values, cleared by the position-gather pass)
+    int fstride = 1;      // direct-space accumulators: 1 = three arrays (fx | fy | fz | -), 4 = one (x, y, z, -) record per atom
+    // The sub-tile pair kernel scatters a j-atom's three components from three adjacent lanes: with one record per atom they fall into
+    // one 16-byte slot, i.e. ONE atomic request per j-atom wherever it lies; three separate arrays cost three, and the gathered j-atoms
+    // of a signature-ordered tile are not neighbours in memory (measured: 0.35 ms against 0.25 with the unordered list).
+    // The sub-tile pair kernel (direct.hip, k_directSub) and the list order it needs are an EXPERIMENT kept behind SNB_SUBTILES (1: octet
+    // order + signature-ordered j entries, 2: octet order only): measured on c3 it evaluates 28 % fewer pair slots with 30 % fewer VALU
+    // instructions than k_directPacked and is still slower, 0.258 ms against 0.205 -- its gathers and j-force atomics lose the locality
+    // of the column-ordered list and it becomes bound by the memory pipeline.
+    static int subTileMode() {
+        static const int mode = [] { const char* e = getenv("SNB_SUBTILES"); const int v = e ? atoi(e) : 0; return v == 1 ? 3 : (v == 2 ? 1 : 0); }();
+        return mode;
+    }
+    bool recordForces() const {
+        static const bool soa = getenv("SNB_FORCE_SOA") != nullptr;
+        return sizeof(Real) == 4 && cfg.method != SNB_NoCutoff && !cfg.host_neighbor_build && subTileMode() != 0 && !soa;
+    }
+    void layoutForces() {
+        forceBuf.resize((size_t)7 * Npad);
+        fstride = recordForces() ? 4 : 1;
+        fx.p = forceBuf.p; fy.p = fx.p + (fstride == 4 ? 1 : Npad); fz.p = fx.p + (fstride == 4 ? 2 : 2 * (size_t)Npad);
+        fpx.p = forceBuf.p + 4 * (size_t)Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
+    }
+    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC, dAtomCell, dExtent, dPermOf;
     double tileCell[9] = {0};      // the cell the tile image codes refer to (the box; an enclosing cell for CutoffNonPeriodic)
     DevBuf<long long> dNbTrace, dPmeTrace;
     bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
@@ -213,7 +236,8 @@ public:
     std::vector<int> hSubsetStart, hSubsetPaddedStart, staticBlkSubset; int staticNpad = 0; size_t tileCap = 0; bool staticDirty = true, gpuBuilt = false;
     DevBuf<int2> pairs14, pairsExcl, colRange; DevBuf<int4> tileInfo, workItems, workItemsStage, workItemsPartial; int numWorkItems = 0; int colCells[2] = {0, 0}; DevBuf<unsigned> masks;
     DevBuf<T4> params14, paramsExcl; int n14 = 0, nExcl = 0;
-    DevBuf<double> sliceE;
+    DevBuf<double> sliceE, sliceTotal;      // 64 partitioned copies of the raw [S][2] energies, and their sum (last kernel of an energy step)
+    bool energyPending = false, pendDirect = false, pendRecip = false;      // the last energy step's sums are still on the device
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
@@ -232,8 +256,8 @@ public:
     bool hostSumsValid = false; std::vector<double> subsetCharge, selfCoulomb, selfDispersion;   // per-subset sums behind the closed-form energy terms
     std::vector<int3> hKvec; DevBuf<int3> dKvec; DevBuf<Real> dCosSin;
     struct GraphKey {
-        const void* pos; int isDouble, stride4; bool direct, recip; void* out; int outDouble, outAcc;
-        bool operator==(const GraphKey& o) const { return pos == o.pos && isDouble == o.isDouble && stride4 == o.stride4 && direct == o.direct && recip == o.recip && out == o.out && outDouble == o.outDouble && outAcc == o.outAcc; }
+        const void* pos; int isDouble, stride4; bool direct, recip, energy; void* out; int outDouble, outAcc;
+        bool operator==(const GraphKey& o) const { return pos == o.pos && isDouble == o.isDouble && stride4 == o.stride4 && direct == o.direct && recip == o.recip && energy == o.energy && out == o.out && outDouble == o.outDouble && outAcc == o.outAcc; }
     };
     void* outPtr = nullptr; int outIsDouble = 0, outAccumulate = 0; bool outputWritten = false;   // snb_set_force_output
     // captured step graphs, a few at a time: a caller that alternates between position (or output) buffers keeps one graph per buffer
@@ -254,7 +278,7 @@ public:
         for (auto& r : ring) for (int k = 0; k < 5; k++) HIPCHECK(hipEventCreate(&r.e[k]));
         charge.assign(N, 0.0); sigma.assign(N, 1.0); epsilon.assign(N, 0.0); subset.assign(N, 0);
         lambdas.assign((size_t)S * 2, 1.0); dispCoef.assign(S, 0.0); hostSliceE.assign((size_t)S * 2, 0.0);
-        sliceE.resize((size_t)S * 2 * SNB_SLICE_E_PARTS);
+        sliceE.resize((size_t)S * 2 * SNB_SLICE_E_PARTS); sliceTotal.resize((size_t)S * 2);
         if (cfg.shard_count < 1) cfg.shard_count = 1;
         shardBegin = cfg.shard_count > 1 ? cfg.shard_rank : 0; shardEnd = shardBegin + 1; shardPeriod = cfg.shard_count;
         // tabulated Ewald force factor: opt-in.  Measured on MI355X it only trades 4 % of the VALU instructions for LDS gathers (the packed
@@ -286,6 +310,7 @@ public:
         if (sortGraphExec) { (void)hipGraphExecDestroy(sortGraphExec); sortGraphExec = nullptr; }
         for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
         for (int k = 0; k < 3; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
+        for (int k = 0; k < 2; k++) if (evStepDone[k]) (void)hipEventDestroy(evStepDone[k]);
         if (hDispFlags) (void)hipHostFree(hDispFlags);
         if (stream2) { (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); (void)hipStreamDestroy(stream2); }
         if (ownStream) (void)hipStreamDestroy(stream);
@@ -702,8 +727,7 @@ public:
         blockSubset.upload(blkSubset, stream); workItems.upload(hWork, stream);
         tileJ.upload(hTileJ, stream); tileInfo.upload(hTileInfo, stream); masks.upload(hMasks, stream);
         atomSubset.upload(hAtomSubset, stream); atomGrid.upload(hAtomGrid, stream);
-        forceBuf.resize((size_t)6 * Npad);
-        fx.p = forceBuf.p; fy.p = fx.p + Npad; fz.p = fy.p + Npad; fpx.p = fz.p + Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
+        layoutForces();
         HIPCHECK(hipStreamSynchronize(stream));
         needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;
         stats.n_rebuilds++; stats.n_host_rebuilds++;
@@ -851,7 +875,7 @@ public:
         p.wrapped = dWrapped.p; p.offsetU = dOffsetU.p; p.keysIn = dKeysIn.p; p.keysOut = dKeysOut.p; p.valsIn = dValsIn.p; p.valsOut = dValsOut.p;
         p.segKey = dValsIn.p; p.segStart = dScanA.p; p.padExtra = dScanB.p; p.padBefore = dScanA.p;   // valsIn is dead once the sort has run
         p.slotMap = dScanB.p;      // (padExtra is dead once phase A has produced the padded count)
-        { static const bool noOrder = getenv("SNB_NO_BLOCK_ORDER") != nullptr; p.orderBlocks = noOrder ? 0 : 1; }
+        p.orderBlocks = subTileMode();      // bit 0: octet order inside blocks, bit 1: j entries ordered by octet signature (0: neither, the default)
         dScanC.resize(N); p.blockWide = dScanC.p; p.blockWideOut = dScanC.p;
         for (int d = 0; d < 3; d++) p.maxHalfExtent[d] = (float)(0.45 * (box[4 * d] - 2.0 * R));   // extent <= 0.9 (L - 2R)
         p.userToSorted = dUserToSorted.p; p.colRange = colRange.p; p.zIndex = dZIndex.p; p.counters = dCounters.p;
@@ -872,8 +896,11 @@ public:
                     if (sortGraphExec) { (void)hipGraphExecDestroy(sortGraphExec); sortGraphExec = nullptr; }
                     hipGraph_t graph = nullptr;
                     if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                        launchNeighborSort<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream);
-                        const hipError_t endErr = hipStreamEndCapture(stream, &graph);
+                        bool threw = false;
+                        try { launchNeighborSort<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream); }
+                        catch (...) { threw = true; }      // never leave the caller's stream in capture mode
+                        hipError_t endErr = hipStreamEndCapture(stream, &graph);
+                        if (threw) { endErr = hipErrorUnknown; (void)hipGetLastError(); }
                         if (endErr == hipSuccess && graph && hipGraphInstantiate(&sortGraphExec, graph, nullptr, nullptr, 0) == hipSuccess) {
                             sortGraphKey.assign(reinterpret_cast<const unsigned char*>(&key), reinterpret_cast<const unsigned char*>(&key) + sizeof(key));
                         } else { sortGraphExec = nullptr; sortGraphBroken = true; (void)hipGetLastError(); }
@@ -894,8 +921,7 @@ public:
         // outputs / scratch sized by the padded count
         posq.resize(Npad); sigeps.resize(Npad); imageOffset.resize((size_t)3 * Npad);
         dSortedToUser.resize(Npad); atomSubset.resize(Npad); atomGrid.resize(Npad); blockSubset.resize(numBlocks);
-        forceBuf.resize((size_t)6 * Npad);
-        fx.p = forceBuf.p; fy.p = fx.p + Npad; fz.p = fy.p + Npad; fpx.p = fz.p + Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
+        layoutForces();
         dBlockCenter.resize((size_t)3 * numBlocks); dBlockHalf.resize((size_t)3 * numBlocks);
         if (tileCap < (size_t)numBlocks * 40) tileCap = (size_t)numBlocks * 40;
         if (tileCap < 64 * 128) tileCap = 64 * 128;      // 64 allocation partitions, each with room for a few blocks' worth of tiles
@@ -911,6 +937,7 @@ public:
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;
             dAtomCell.resize(Npad); p.atomCell = dAtomCell.p;
+            dPermOf.resize(Npad); p.permOf = dPermOf.p;
             static const bool nbTrace = getenv("SNB_NB_TRACE") != nullptr;
             if (nbTrace) { dNbTrace.resize((size_t)4 * numBlocks); p.dbgOut = dNbTrace.p; }
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.workItems = workItems.p; p.workItemsStage = workItemsStage.p; p.workItemsPartial = workItemsPartial.p; p.counters = dCounters.p;
@@ -1022,6 +1049,14 @@ public:
         // 0.8 * skin/2 since the last rebuild (the flag lives in mapped host memory: no synchronisation; it is read one execute late,
         // hence the margin), and after -rebuild_interval executes at the latest
         const bool autoMode = cfg.rebuild_interval < 0;
+        // ... stream-ordered: the flag is read only after the execute before the previous one has COMPLETED on the GPU (an event recorded at
+        // the end of every execute, two slots), so the host can never run far ahead of the watch -- a forces-only step is an asynchronous
+        // graph launch.  The decision therefore sees every displacement up to two executes ago; the 0.8 factor leaves 0.2 * skin/2 for
+        // those two steps.
+        if (autoMode && cfg.neighbor_padding > 0) {
+            hipEvent_t& ev = evStepDone[stepCounter & 1];
+            if (ev) HIPCHECK(hipEventSynchronize(ev));
+        }
         const bool due = autoMode ? (hDispFlags[0] != 0 || stepsSinceRebuild >= -cfg.rebuild_interval) : (cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval);
         const bool rebuilding = needRebuild || paramsDirty || due || cfg.neighbor_padding <= 0;
         if ((valuesDirty || excValuesDirty) && !staticDirty && !rebuilding) refreshValues();
@@ -1037,14 +1072,16 @@ public:
         // (the step right after a rebuild goes out as plain launches: the GPU is idle at that point -- the rebuild ended with a host
         // read-back -- and capturing + instantiating the step graph first would keep it idle for another ~50 us; the capture then happens
         // at the next step, while this one is executing)
-        const bool eager = energy || cfg.disable_graph || noStepGraph || rebuilding || (execCount++ % 32 == 0);
+        // Energy steps (per-slice energies, the step of every force with energy-parameter derivatives, Q4) are graph steps like any other:
+        // they end with the device-side sum of the slice-energy partitions and leave the result there until it is asked for.
+        const bool eager = cfg.disable_graph || noStepGraph || rebuilding || (execCount++ % 32 == 0);
         if (eager) {
             EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
             if (ev.pending) harvest(ev);
             enqueueStep(energy, includeDirect != 0, includeRecip != 0, &ev);
             ev.pending = true;
         } else {
-            GraphKey key{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0, outPtr, outIsDouble, outAccumulate};
+            GraphKey key{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0, energy, outPtr, outIsDouble, outAccumulate};
             hipGraphExec_t graphExec = nullptr;
             for (auto& g : graphs) if (g.key == key) { graphExec = g.exec; break; }
             if (!graphExec) {
@@ -1056,7 +1093,7 @@ public:
                 }
                 hipGraph_t graph = nullptr;
                 HIPCHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-                try { enqueueStep(false, includeDirect != 0, includeRecip != 0, nullptr); }
+                try { enqueueStep(energy, includeDirect != 0, includeRecip != 0, nullptr); }
                 catch (...) { (void)hipStreamEndCapture(stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
                 HIPCHECK(hipStreamEndCapture(stream, &graph));
                 HIPCHECK(hipGraphInstantiate(&graphExec, graph, nullptr, nullptr, 0));
@@ -1066,15 +1103,27 @@ public:
             }
             HIPCHECK(hipGraphLaunch(graphExec, stream));
         }
+        if (autoMode && cfg.neighbor_padding > 0) {
+            hipEvent_t& ev = evStepDone[stepCounter & 1];
+            if (!ev) HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(ev, stream));
+        }
+        stepCounter++;
         if (energy) {
-            std::vector<double> dev((size_t)S * 2 * SNB_SLICE_E_PARTS);
-            HIPCHECK(hipMemcpyAsync(dev.data(), sliceE.p, sizeof(double) * dev.size(), hipMemcpyDeviceToHost, stream));
-            HIPCHECK(hipStreamSynchronize(stream));
-            hostSliceE.assign((size_t)S * 2, 0.0);
-            for (int part = 0; part < SNB_SLICE_E_PARTS; part++) for (int i = 0; i < 2 * S; i++) hostSliceE[i] += dev[(size_t)part * 2 * S + i];
-            addHostTerms(includeDirect != 0, includeRecip != 0);
-            if (energyOut) { double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }
+            energyPending = true; pendDirect = includeDirect != 0; pendRecip = includeRecip != 0;
+            if (energyOut) { fetchSliceEnergies(); double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }      // (synchronises)
         } else if (energyOut) *energyOut = 0.0;
+    }
+
+    // The raw slice energies of the last energy step, read back on demand (the only synchronisation of an energy / derivative step)
+    void fetchSliceEnergies() {
+        if (!energyPending) return;
+        std::vector<double> dev((size_t)S * 2);
+        HIPCHECK(hipMemcpyAsync(dev.data(), sliceTotal.p, sizeof(double) * dev.size(), hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+        hostSliceE = dev;
+        addHostTerms(pendDirect, pendRecip);
+        energyPending = false;
     }
 
     void enqueueStep(bool energy, bool includeDirect, bool includeRecip, EvSet* ev) {
@@ -1115,7 +1164,7 @@ public:
         // O(N) pair lists: one rank only when sharded -- the LAST one, which carries no PME grid once there are more ranks than grids
         const bool haveLists = includeDirect && cfg.shard_rank == cfg.shard_count - 1;
         if (haveLists) {
-            q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.sliceE = sliceE.p; q.lambdas = dLambdas.p;
+            q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.fs = fstride; q.sliceE = sliceE.p; q.lambdas = dLambdas.p;
             const bool exPeriodic = (cfg.method == SNB_NoCutoff || cfg.method == SNB_CutoffNonPeriodic) ? false : cfg.exceptions_periodic != 0;
             q.periodic = exPeriodic ? 1 : 0; q.imageOffset = imageOffset.p;
             q.sigeps = sigeps.p; q.blockSubset = blockSubset.p; q.exclStart = exclStart.p; q.exclList = exclList.p; q.nSlices = S; q.sortedToUser = dSortedToUser.p; q.userToSorted = dUserToSorted.p;
@@ -1129,9 +1178,10 @@ public:
             DirectParams<Real> p;
             std::memset(&p, 0, sizeof(p));
             p.posq = posq.p; p.sigeps = sigeps.p; p.blockSubset = blockSubset.p; p.workItems = workItems.p;
-            p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.sliceE = sliceE.p; p.lambdas = dLambdas.p;
+            p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.fs = fstride; p.sliceE = sliceE.p; p.lambdas = dLambdas.p;
             const int r = cfg.shard_rank, c = cfg.shard_count;
             (void)r; (void)c;
+            p.subTiles = (gpuBuilt && !wrapMode && subTileMode() != 0) ? 1 : 0;
             p.workStart = 0; p.workStride = 1; p.numWork = numWorkItems;      // the lists hold only the i-blocks this engine owns (block % shard_count == shard_rank)
             p.nsub = nsub;
             p.cutoff2 = (Real)(cfg.cutoff * cfg.cutoff);
@@ -1175,8 +1225,9 @@ public:
         if (includeRecip && cfg.method == SNB_Ewald && cfg.shard_rank == 0) runEwald(energy);
         if (outPtr) {   // the step's last kernel: user-order forces into the caller's buffer (part of the graph)
             const bool recipDone = includeRecip && (isPme() || cfg.method == SNB_Ewald);
-            launchFinishForces<Real>(fx.p, fy.p, fz.p, recipDone ? fpx.p : nullptr, fpy.p, fpz.p, dUserToSorted.p, N, outPtr, outIsDouble, outAccumulate, stream);
+            launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, recipDone ? fpx.p : nullptr, fpy.p, fpz.p, dUserToSorted.p, N, outPtr, outIsDouble, outAccumulate, stream);
         }
+        if (energy) launchSumSliceParts(sliceE.p, sliceTotal.p, 2 * S, stream);
         if (ev) HIPCHECK(hipEventRecord(ev->e[4], stream));
     }
 
@@ -1258,14 +1309,14 @@ public:
         if (isDevice && out == outPtr && isDouble == outIsDouble && outputWritten) return;   // the last execute already delivered them there
         const size_t bytes = (size_t)N * 3 * (isDouble ? 8 : 4);
         const Real* px = lastRecip ? fpx.p : nullptr;
-        if (isDevice) { launchFinishForces<Real>(fx.p, fy.p, fz.p, px, fpy.p, fpz.p, dUserToSorted.p, N, out, isDouble, accumulate, stream); return; }
+        if (isDevice) { launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, px, fpy.p, fpz.p, dUserToSorted.p, N, out, isDouble, accumulate, stream); return; }
         DevBuf<unsigned char> tmp; tmp.resize(bytes);
         if (accumulate) HIPCHECK(hipMemcpyAsync(tmp.p, out, bytes, hipMemcpyHostToDevice, stream));
-        launchFinishForces<Real>(fx.p, fy.p, fz.p, px, fpy.p, fpz.p, dUserToSorted.p, N, tmp.p, isDouble, accumulate, stream);
+        launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, px, fpy.p, fpz.p, dUserToSorted.p, N, tmp.p, isDouble, accumulate, stream);
         HIPCHECK(hipMemcpyAsync(out, tmp.p, bytes, hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
     }
-    void getSliceEnergies(double* out) override { std::memcpy(out, hostSliceE.data(), sizeof(double) * S * 2); }
+    void getSliceEnergies(double* out) override { fetchSliceEnergies(); std::memcpy(out, hostSliceE.data(), sizeof(double) * S * 2); }
     void getStats(snb_stats* o) override {
         HIPCHECK(hipStreamSynchronize(stream));
         stats.n_tiles = 0;
@@ -1318,8 +1369,17 @@ using namespace snb;
 
 struct snb_engine { EngineBase* impl; };
 
+// Every entry point runs on the engine's own device and leaves the caller's current device as it found it (a process that drives
+// several GPUs -- torch, OpenMM with several contexts -- switches the current device between calls).
+struct DeviceScope {
+    int prev = -1; bool switched = false;
+    explicit DeviceScope(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess; }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+
 template <typename F> static snb_status guard(snb_handle h, F&& f) {
     if (!h || !h->impl) return SNB_ERR_INVALID_ARGUMENT;
+    DeviceScope scope(h->impl->cfg.device);
     try { f(); return SNB_OK; }
     catch (HipError& e) { h->impl->err = e.msg; return e.msg.find("hip") == 0 ? SNB_ERR_HIP : SNB_ERR_INVALID_ARGUMENT; }
     catch (int code) { return (snb_status)code; }
@@ -1343,10 +1403,15 @@ snb_status snb_create(const snb_config* cfg, snb_handle* out) {
     if ((cfg->method == SNB_PME || cfg->method == SNB_LJPME) && (cfg->grid[0] < 1 || cfg->grid[1] < 1 || cfg->grid[2] < 1)) { g_createError = "PME grid must be given explicitly"; return SNB_ERR_INVALID_ARGUMENT; }
     if (cfg->method == SNB_LJPME && (!(cfg->alpha_d > 0) || cfg->dgrid[0] < 1 || cfg->dgrid[1] < 1 || cfg->dgrid[2] < 1)) { g_createError = "LJPME dispersion alpha/grid must be given explicitly"; return SNB_ERR_INVALID_ARGUMENT; }
     if (cfg->shard_count > 1 && (cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_count)) { g_createError = "invalid shard_rank"; return SNB_ERR_INVALID_ARGUMENT; }
+    // every shard must re-sort and rebuild on the SAME execute (sorted order, padded count and block ownership are per-rebuild facts all ranks share);
+    // the displacement-triggered mode decides from a flag each rank sees at its own time, so sharded engines take a fixed interval (or
+    // the caller agrees on the step itself and calls snb_rebuild_neighbors on every rank)
+    if (cfg->shard_count > 1 && cfg->rebuild_interval < 0) { g_createError = "rebuild_interval < 0 (displacement-triggered rebuilds) is not available with shard_count > 1"; return SNB_ERR_UNSUPPORTED; }
     try {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_createError = "hip: no HIP device available (the engine has no CPU fallback)"; return SNB_ERR_HIP; }
         if (cfg->device < 0 || cfg->device >= ndev) { g_createError = "invalid device ordinal"; return SNB_ERR_INVALID_ARGUMENT; }
+        DeviceScope scope(cfg->device);
         EngineBase* e = cfg->precision == SNB_DOUBLE ? (EngineBase*)new Engine<double>(*cfg) : (EngineBase*)new Engine<float>(*cfg);
         *out = new snb_engine{e};
         return SNB_OK;
@@ -1354,7 +1419,7 @@ snb_status snb_create(const snb_config* cfg, snb_handle* out) {
     catch (std::exception& e) { g_createError = e.what(); return SNB_ERR_INVALID_ARGUMENT; }
 }
 
-void snb_destroy(snb_handle h) { if (h) { delete h->impl; delete h; } }
+void snb_destroy(snb_handle h) { if (h) { if (h->impl) { DeviceScope scope(h->impl->cfg.device); delete h->impl; } delete h; } }
 const char* snb_last_error(snb_handle h) { return h && h->impl ? h->impl->err.c_str() : g_createError.c_str(); }
 
 snb_status snb_set_particles(snb_handle h, const double* q, const double* s, const double* e, const int32_t* sub) {

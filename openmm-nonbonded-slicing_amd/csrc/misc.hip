@@ -15,7 +15,7 @@ __global__ void k_gatherPositions(const In* __restrict__ userPos, int stride, co
     if (s >= nPadded) return;
     if (forces) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) forces[(size_t)k * nPadded + s] = Real(0);
+        for (int k = 0; k < 7; k++) forces[(size_t)k * nPadded + s] = Real(0);      // 4 n direct-space (either layout) + 3 n reciprocal
     }
     const int u = sortedToUser[s];
     if (u < 0) { if (gc.cells) gc.cells[s] = -1; return; }
@@ -72,30 +72,44 @@ template void launchRefreshParams<float>(const int*, const float*, const Vec<flo
 template void launchRefreshParams<double>(const int*, const double*, const Vec<double>::T2*, Vec<double>::T4*, Vec<double>::T2*, int, hipStream_t);
 
 template <typename Real, typename Out>
-__global__ void k_finishForces(const Real* __restrict__ fx, const Real* __restrict__ fy, const Real* __restrict__ fz,
+__global__ void k_finishForces(const Real* __restrict__ fx, const Real* __restrict__ fy, const Real* __restrict__ fz, int fs,
                                const Real* __restrict__ fpx, const Real* __restrict__ fpy, const Real* __restrict__ fpz,
                                const int* __restrict__ userToSorted, int nAtoms, Out* __restrict__ out, int accumulate) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nAtoms) return;
     const int s = userToSorted[u];
-    Out x = (Out)fx[s], y = (Out)fy[s], z = (Out)fz[s];
+    Out x = (Out)fx[(size_t)s * fs], y = (Out)fy[(size_t)s * fs], z = (Out)fz[(size_t)s * fs];
     if (fpx) { x += (Out)fpx[s]; y += (Out)fpy[s]; z += (Out)fpz[s]; }
     if (accumulate) { x += out[3 * (size_t)u]; y += out[3 * (size_t)u + 1]; z += out[3 * (size_t)u + 2]; }
     out[3 * (size_t)u] = x; out[3 * (size_t)u + 1] = y; out[3 * (size_t)u + 2] = z;
 }
 
 template <typename Real>
-void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, const Real* fpx, const Real* fpy, const Real* fpz,
+void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, int fs, const Real* fpx, const Real* fpy, const Real* fpz,
                         const int* userToSorted, int nAtoms, void* out, int isDouble, int accumulate, hipStream_t s) {
     if (nAtoms <= 0) return;
     dim3 grid((nAtoms + 255) / 256), block(256);
-    if (isDouble) hipLaunchKernelGGL((k_finishForces<Real, double>), grid, block, 0, s, fx, fy, fz, fpx, fpy, fpz, userToSorted, nAtoms, (double*)out, accumulate);
-    else hipLaunchKernelGGL((k_finishForces<Real, float>), grid, block, 0, s, fx, fy, fz, fpx, fpy, fpz, userToSorted, nAtoms, (float*)out, accumulate);
+    if (isDouble) hipLaunchKernelGGL((k_finishForces<Real, double>), grid, block, 0, s, fx, fy, fz, fs, fpx, fpy, fpz, userToSorted, nAtoms, (double*)out, accumulate);
+    else hipLaunchKernelGGL((k_finishForces<Real, float>), grid, block, 0, s, fx, fy, fz, fs, fpx, fpy, fpz, userToSorted, nAtoms, (float*)out, accumulate);
+}
+
+// Raw slice energies: the kernels of an energy step add into SNB_SLICE_E_PARTS copies of the [S][2] table (chosen by work-group);
+// this sums the copies on the device, as the last kernel of the step, so that an energy / derivative step needs no host
+// synchronisation of its own and can be replayed from a graph -- the host reads the 2 S doubles when the caller asks for them.
+__global__ void k_sumSliceParts(const double* __restrict__ parts, double* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0;
+    for (int part = 0; part < SNB_SLICE_E_PARTS; part++) acc += parts[(size_t)part * n + i];
+    out[i] = acc;
+}
+void launchSumSliceParts(const double* parts, double* out, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_sumSliceParts, dim3((n + 63) / 64), dim3(64), 0, s, parts, out, n);
 }
 
 template void launchGatherPositions<float>(const void*, int, int, const int*, const float*, Vec<float>::T4*, int, float*, const GatherCells<float>&, hipStream_t);
 template void launchGatherPositions<double>(const void*, int, int, const int*, const double*, Vec<double>::T4*, int, double*, const GatherCells<double>&, hipStream_t);
-template void launchFinishForces<float>(const float*, const float*, const float*, const float*, const float*, const float*, const int*, int, void*, int, int, hipStream_t);
-template void launchFinishForces<double>(const double*, const double*, const double*, const double*, const double*, const double*, const int*, int, void*, int, int, hipStream_t);
+template void launchFinishForces<float>(const float*, const float*, const float*, int, const float*, const float*, const float*, const int*, int, void*, int, int, hipStream_t);
+template void launchFinishForces<double>(const double*, const double*, const double*, int, const double*, const double*, const double*, const int*, int, void*, int, int, hipStream_t);
 
 }  // namespace snb

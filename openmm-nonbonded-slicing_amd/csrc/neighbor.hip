@@ -203,7 +203,7 @@ template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     const int s = (int)(key >> (20 + p.colBits));
     const int serp = (int)((key >> 20) & ((1u << p.colBits) - 1u));
     const int si0 = t + p.padBefore[t];           // padded index in sorted order
-    const int si = p.slotMap[t];                  // ... and after the in-block octet ordering (same block)
+    const int si = p.orderBlocks ? p.slotMap[t] : si0;      // ... and after the in-block octet ordering (same block)
     if ((si0 & 31) == 0) p.blockSubset[si0 >> 5] = s;
     p.sortedToUser[si] = u; p.userToSorted[u] = si;
     typename Vec<Real>::T4 v; v.x = p.wrapped[3 * (size_t)u]; v.y = p.wrapped[3 * (size_t)u + 1]; v.z = p.wrapped[3 * (size_t)u + 2]; v.w = p.uCharge[u];
@@ -235,12 +235,18 @@ template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     const int col = cx * p.ncy + cy;
     // z-bucket index of the (subset, column) run: 64 buckets of the key's 20-bit z (already direction-flipped for odd columns, so every
     // run ascends in it).  zIndex[b] = first padded index (IN SORTED ORDER, si0) of the run with bucket >= b (k_nbZPrefix fills the empty
-    // buckets); positions, not counts, because segment padding may sit inside a run.  The octet ordering moves an atom inside its block
-    // only, so look-ups widen [zIndex[lo], zIndex[hi + 1]) to whole blocks and clip it to the run.
+    // buckets); positions, not counts, because segment padding may sit inside a run.  The candidate search walks intervals of the sorted
+    // order and finds the atoms through permOf[si0] = slot after the octet ordering.
+    p.permOf[si0] = si;
     atomicMin(&p.zIndex[((size_t)s * p.ncx * p.ncy + col) * 65 + (int)((key & 0xFFFFF) >> 14)], si0);
-    // the run's interval of the padded order: min / max over its atoms (a re-ordered block lies inside ONE run, so runs stay disjoint)
-    atomicMin(&p.colRange[(size_t)s * p.ncx * p.ncy + col].x, si);
-    atomicMax(&p.colRange[(size_t)s * p.ncx * p.ncy + col].y, si + 1);
+    // the run's interval of the padded order
+    if (p.orderBlocks) {      // min / max over its atoms (a re-ordered block lies inside ONE run, so runs stay disjoint)
+        atomicMin(&p.colRange[(size_t)s * p.ncx * p.ncy + col].x, si);
+        atomicMax(&p.colRange[(size_t)s * p.ncx * p.ncy + col].y, si + 1);
+    } else {                  // sorted order: the run's first and last atom
+        if ((t == 0) || ((p.keysOut[t - 1] >> 20) != (key >> 20))) p.colRange[(size_t)s * p.ncx * p.ncy + col].x = si;
+        if ((t == p.nAtoms - 1) || ((p.keysOut[t + 1] >> 20) != (key >> 20))) p.colRange[(size_t)s * p.ncx * p.ncy + col].y = si + 1;
+    }
 }
 
 template <typename Real> __global__ void k_nbZPrefix(const NbParams<Real> p) {
@@ -582,7 +588,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
                     int k = 0;     // last run whose exclusive prefix is <= v (empty runs are never queued)
 #pragma unroll
                     for (int st = 32; st > 0; st >>= 1) if (k + st < 64 && cmbPrefix[k + st] <= v) k += st;
-                    j = cmbStart[k] + (v - cmbPrefix[k]); code = cmbCode[k];
+                    j = cmbStart[k] + (v - cmbPrefix[k]); if (p.orderBlocks) j = p.permOf[j]; code = cmbCode[k];      // sorted padded index -> the atom's slot after the octet ordering (same block)
                     const int J = j >> 5;
                     ok = (J != I) && ownsPair(I, J);
                 }
@@ -634,9 +640,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
                         int blo = ((int)(fa * 1048575.0f) >> 14) - 1, bhi = ((int)(fb * 1048575.0f) >> 14) + 1;   // one bucket of slack for float rounding
                         blo = blo < 0 ? 0 : blo; bhi = bhi > 63 ? 63 : bhi;
                         const int* zi = zIndex + (size_t)col * 65;
-                        cStart = zi[blo] & ~31; if (cStart < rg.x) cStart = rg.x;      // whole blocks (octet ordering), clipped to the run
-                        int cEnd = (zi[bhi + 1] + 31) & ~31; if (cEnd > rg.y) cEnd = rg.y;
-                        cLen = cEnd - cStart;
+                        cStart = zi[blo]; cLen = zi[bhi + 1] - zi[blo];      // an interval of the SORTED padded order (see permOf below)
                     }
                 }
                 const unsigned long long mq = __ballot(cLen > 0);
@@ -651,27 +655,45 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         // Order the segment's entries by signature (counting sort, 16 bins): entries that reach the same octets end up in the same
         // 16-entry halves, so that whole (octet, half) sub-tiles come out empty -- 28 % of them on the bulk-water workload
         // (tools/sim_fill2.py) -- and the pair kernel skips them.
-        if (exact && !failed && p.orderBlocks && count - segStart > 16) {
+        if (exact && !failed && (p.orderBlocks & 2) && count - segStart > 16) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (lane < 16) hist[lane] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            int ent[NB_CAP / 64], where[NB_CAP / 64];
+            // STABLE (entries of one signature keep their order: they follow the sorted atom order, and the pair kernel's gathers of a
+            // tile stay within a few cache lines): pass 1 counts per signature, pass 2 ranks every entry inside its signature by ballots
+            int ent[NB_CAP / 64], sg[NB_CAP / 64];
 #pragma unroll
             for (int r = 0; r < NB_CAP / 64; r++) {
                 const int k = segStart + lane + 64 * r;
-                ent[r] = 0; where[r] = -1;
-                if (k < count) { ent[r] = list[k]; const int v = sig[k]; where[r] = (v << 16) | atomicAdd(&hist[v], 1); }
+                ent[r] = 0; sg[r] = -1;
+                if (k < count) { ent[r] = list[k]; sg[r] = sig[k]; atomicAdd(&hist[sg[r]], 1); }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) { int acc = 0; for (int v = 0; v < 16; v++) { const int c = hist[v]; hist[v] = acc; acc += c; } }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            int running = lane < 16 ? hist[lane] : 0;      // lane v < 16 keeps the next free position of signature v
+#pragma unroll
+            for (int r = 0; r < NB_CAP / 64; r++) {
+                unsigned long long todo = __ballot(sg[r] >= 0);
+                int dest = -1;
+                while (todo) {
+                    const int v = __shfl(sg[r], __builtin_ctzll(todo), 64);      // a signature still to be placed in this round
+                    const unsigned long long m = __ballot(sg[r] == v);
+                    const int basePos = __shfl(running, v, 64);
+                    if (sg[r] == v) dest = basePos + lanePrefix(m);
+                    if (lane == v) running += __popcll(m);
+                    todo &= ~m;
+                }
+                sg[r] = dest >= 0 ? ((sg[r] << 16) | dest) : -1;
+            }
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int r = 0; r < NB_CAP / 64; r++)
-                if (where[r] >= 0) { const int v = where[r] >> 16, o = segStart + hist[v] + (where[r] & 0xFFFF); list[o] = ent[r]; sig[o] = (unsigned char)v; }
+                if (sg[r] >= 0) { const int o = segStart + (sg[r] & 0xFFFF); list[o] = ent[r]; sig[o] = (unsigned char)(sg[r] >> 16); }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -694,7 +716,7 @@ template <typename Real> __global__ void k_nbClear(const NbParams<Real> p) {
     if (i < 7 || (i >= 32 && i < (size_t)32 * (1 + NB_PARTS))) p.counters[i] = 0;
     if (i < nCols) p.colRange[i] = make_int2(0x7FFFFFFF, 0);      // atomicMin / atomicMax targets of k_nbScatter; k_nbZPrefix turns empty runs into (0, 0)
     if (i < nCols * 65) p.zIndex[i] = 0x7F7F7F7F;
-    if (i < (size_t)p.nPadded) p.sortedToUser[i] = -1;
+    if (i < (size_t)p.nPadded) { p.sortedToUser[i] = -1; p.permOf[i] = (int)i; }
 }
 
 // ---- 5. work items of the 64 partitions -> one contiguous array, full (8-tile) items first; totals into counters[0..7] ------------
@@ -766,7 +788,7 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipSt
         hipLaunchKernelGGL((k_nbClear<Real>), dim3((unsigned)((most + 255) / 256)), block, 0, s, p);
     }
     if (n > 0) {
-        hipLaunchKernelGGL((k_nbBlockOrder<Real>), dim3((p.nBlocks + 7) / 8), block, 0, s, p);
+        if (p.orderBlocks) hipLaunchKernelGGL((k_nbBlockOrder<Real>), dim3((p.nBlocks + 7) / 8), block, 0, s, p);
         hipLaunchKernelGGL((k_nbScatter<Real>), gridN, block, 0, s, p);
         hipLaunchKernelGGL((k_nbPad<Real>), dim3((p.nPadded + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbZPrefix<Real>), dim3((p.nSubsets * p.ncx * p.ncy + 255) / 256), block, 0, s, p);

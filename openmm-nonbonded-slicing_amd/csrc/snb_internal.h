@@ -49,10 +49,11 @@ template <typename Real> struct DirectParams {
     const int* tileJ;         // [T*32]
     const int4* tileInfo;     // [T]
     const unsigned* masks;    // [M*32]
-    Real* fx; Real* fy; Real* fz;
+    Real* fx; Real* fy; Real* fz; int fs;   // direct-space force accumulators: component bases and the index stride of an atom (1: three arrays; 4: one (x,y,z,-) record per atom)
     double* sliceE;           // [S*2] raw energies
     const Real* lambdas;      // [S*2]
     int numWork, workStart, workStride;   // sharding: items workStart, workStart+workStride, ...
+    int subTiles;             // the lists carry octet-ordered blocks and sub-tile occupancies (GPU builder): k_directSub applies
     int nsub;
     Real cutoff2, krf, crf, alpha, alphaD, k4pe;          // k4pe = ONE_4PI_EPS0
     Real alpha2l2e;                                        // alpha^2 * log2(e)
@@ -76,7 +77,7 @@ template <typename Real> struct PairListParams {  // 1-4 exceptions: one thread 
     const typename Vec<Real>::T4* params;   // 1-4: (sigma, 4 eps, k*qq, slice bits) ; exclusion: (k*qi*qj, c6i*c6j, -, slice bits)
     int n;                    // number of 1-4 pairs
     int nExclAtoms;           // atoms visited by the exclusion-correction part (0: none)
-    Real* fx; Real* fy; Real* fz;
+    Real* fx; Real* fy; Real* fz; int fs;
     double* sliceE;
     const Real* lambdas;
     int periodic;
@@ -151,6 +152,7 @@ template <typename Real> struct NbParams {
     const int* uExclStart; const int* uExclList;
     const int* slotOfSubset;
     int* blockSubset;
+    int* permOf;                     // [nPadded] sorted padded index -> padded index after the octet ordering (identity for padding slots)
     int* slotMap; int orderBlocks;   // [nAtoms] padded index of sorted rank t after the in-block octet ordering (k_nbBlockOrder; may alias padExtra, dead by then)
     int* segKey; int* segStart; int* padExtra; int* padBefore;   // block segmentation scratch (segStart and padBefore may alias)
     const int* blockWide; int* blockWideOut;                     // [nAtoms] flags of over-extended blocks of the first segmentation pass
@@ -211,11 +213,13 @@ template <typename Real> struct GatherCells {
 };
 
 template <typename Real> void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
-                                                    typename Vec<Real>::T4* posq, int nPadded, Real* forces, const GatherCells<Real>& gc, hipStream_t s);
+                                                    typename Vec<Real>::T4* posq, int nPadded, Real* forces, const GatherCells<Real>& gc, hipStream_t s);      // forces: 7 * nPadded values cleared
 template <typename Real> void launchRefreshParams(const int* sortedToUser, const Real* uCharge, const typename Vec<Real>::T2* uSigEps, typename Vec<Real>::T4* posq,
                                                   typename Vec<Real>::T2* sigeps, int nPadded, hipStream_t s);
-template <typename Real> void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, const Real* fpx, const Real* fpy, const Real* fpz,
+template <typename Real> void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, int fs, const Real* fpx, const Real* fpy, const Real* fpz,
                                                  const int* userToSorted, int nAtoms, void* out, int isDouble, int accumulate, hipStream_t s);
+
+void launchSumSliceParts(const double* parts, double* out, int n, hipStream_t s);
 
 int legalGridSize(int n);
 bool factorize(int n, int* factors, int* nfactors);

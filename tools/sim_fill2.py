@@ -26,7 +26,7 @@ def split(p, ngroups):
             nxt += [o[:len(o) // 2], o[len(o) // 2:]]
         idx = nxt
     return np.concatenate(idx)
-for gi, gj in ((8, 8), (16, 8), (8, 16), (4, 16), (16, 16), (32, 8), (32, 4)):
+for gi, gj in ((8, 16),):
     ni = 32 // gi
     tot = 0; empty = 0; slots = 0; inrc = 0; inR = 0; ntiles = 0
     for I in rng.choice(nb, 120, replace=False):
@@ -41,7 +41,13 @@ for gi, gj in ((8, 8), (16, 8), (8, 16), (4, 16), (16, 16), (32, 8), (32, 4)):
         reach = np.stack([(d[g * gi:(g + 1) * gi] < R).any(0) for g in range(ni)], 0)      # [ni][nj]
         sig = (reach * (1 << np.arange(ni))[:, None]).sum(0)
         # order j by signature, then spatially (z) inside a signature
-        oj = np.lexsort((q[:, 2], sig))
+        mode = sys.argv[2] if len(sys.argv) > 2 else 'sig'
+        colj = (cand // 1)  # sorted index: column-major already
+        if mode == 'sig': oj = np.lexsort((q[:, 2], sig))
+        elif mode.startswith('win'):
+            W = int(mode[3:]); win = np.arange(len(cand)) // W      # windows of W consecutive candidates in memory order
+            oj = np.lexsort((np.arange(len(cand)), sig, win))
+        else: oj = np.arange(len(cand))
         d = d[:, oj]; reach = reach[:, oj]
         nj = len(oj); npad = (nj + 31) // 32 * 32
         ntiles += npad // 32
