@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SNB_ABI_VERSION 3
+#define SNB_ABI_VERSION 4
 
 typedef struct snb_engine* snb_handle;
 
@@ -112,6 +112,17 @@ snb_status snb_set_particles(snb_handle h, const double* charge, const double* s
  * ReferenceNonbondedSlicingKernels.cpp:99-112).  force14 may be NULL. */
 snb_status snb_set_exceptions(snb_handle h, int32_t m, const int32_t* pairs, const double* charge_prod, const double* sigma,
                               const double* epsilon, const int32_t* force14);
+/* Parameter offsets (SlicedNonbondedForce::addParticleParameterOffset / addExceptionParameterOffset), applied ON THE DEVICE as the
+ * reference does (platforms/common/src/kernels/nonbondedParameters.cc:4-179): snb_set_particles / snb_set_exceptions give the BASE
+ * values and   effective = base + sum_k global[k] * delta_k .   particle_delta[n][3] = (charge, sigma, epsilon) per unit of the global
+ * parameter particle_global[n]; exception_delta[n][3] = (chargeProd, sigma, epsilon); an exception that carries an offset counts as
+ * a 1-4 interaction whatever its base values (Q6).  Call after snb_set_exceptions; globals start at 0. */
+snb_status snb_set_parameter_offsets(snb_handle h, int32_t n_globals,
+                                     int32_t n_particle_offsets, const int32_t* particle, const int32_t* particle_global, const double* particle_delta,
+                                     int32_t n_exception_offsets, const int32_t* exception, const int32_t* exception_global, const double* exception_delta);
+/* New values of the global parameters the offsets refer to (Context::setParameter): the next snb_execute recomputes the effective
+ * parameters with two small kernels -- no re-sort, no tile rebuild, no graph re-capture, no host synchronisation. */
+snb_status snb_set_global_parameters(snb_handle h, int32_t n_globals, const double* values);
 /* lambdas[S][2] = (Coulomb, vdW) per slice, S = n(n+1)/2, slice(i,j) = max(max+1)/2+min (SlicedNonbondedForce.h:22). */
 snb_status snb_set_lambdas(snb_handle h, const double* lambdas);
 /* Per-slice dispersion-correction coefficients (SlicedNonbondedForceImpl.cpp:263-354); NULL = none. */
@@ -152,6 +163,11 @@ snb_status snb_set_force_output(snb_handle h, void* out, int32_t is_double, int3
 snb_status snb_set_shard_blocks(snb_handle h, int32_t begin, int32_t end, int32_t period);
 /* Raw (unscaled) energies of the last execute with include_energy: out[S][2] = (Coulomb, vdW). */
 snb_status snb_get_slice_energies(snb_handle h, double* out);
+/* Device address of those energies: double[S][2], complete (pair sums, reciprocal sums, self, background and dispersion-correction
+ * terms) once the last kernel of an energy step has run on the engine's stream.  For a caller that accumulates dE/dlambda on the
+ * device itself (OpenMM's energy-parameter-derivative buffer): no read-back, no synchronisation.  The address is fixed for the
+ * engine's lifetime. */
+snb_status snb_slice_energies_device(snb_handle h, const double** out);
 snb_status snb_synchronize(snb_handle h);
 
 /* -- queries ----------------------------------------------------------------------------------- */
@@ -159,6 +175,10 @@ snb_status snb_get_pme_parameters(snb_handle h, double* alpha, int32_t grid[3]);
 snb_status snb_get_ljpme_parameters(snb_handle h, double* alpha, int32_t grid[3]);
 snb_status snb_get_stats(snb_handle h, snb_stats* out);
 snb_status snb_reset_timers(snb_handle h);
+/* Every n-th execute is enqueued as plain launches with HIP-event stamps around the pair kernel and the reciprocal pipeline (the
+ * samples behind snb_stats' kernel timers); the others replay the captured step graph.  Default 32; a short measured region asks
+ * for more samples.  n <= 0: never (no timers). */
+snb_status snb_set_timing_interval(snb_handle h, int32_t n);
 /* Smallest FFT-legal mesh size >= n (radices 2,3,5,7). */
 int32_t    snb_legal_grid_size(int32_t n);
 int32_t    snb_abi_version(void);

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -44,6 +45,14 @@ __global__ void addForcesToContext(const Real* __restrict__ forces, const int* _
 
 // posq of the context (float4 or double4 per context slot; mixed precision adds posqCorrection, ignored here as the reference's own
 // single-precision kernels do) -> positions[N][4] in user order
+// dE/dlambda on the device: raw slice energies (double[S][2], snb_slice_energies_device) -> OpenMM's energy-parameter-derivative buffer
+// (one slot per derivative in the first thread's row).  binding[k] = derivative slot of (slice, term) k, or -1.
+template <typename Mixed>
+__global__ void addDerivativesToContext(const double* __restrict__ sliceEnergies, const int* __restrict__ binding, int n, Mixed* __restrict__ derivBuffer) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && binding[k] >= 0) atomicAdd(&derivBuffer[binding[k]], (Mixed)sliceEnergies[k]);
+}
+
 template <typename Real4>
 __global__ void gatherUserPositions(const Real4* __restrict__ posq, const int* __restrict__ atomIndex, Real4* __restrict__ userPos, int numAtoms) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,11 +63,12 @@ __global__ void gatherUserPositions(const Real4* __restrict__ posq, const int* _
 class HipCalcSlicedNonbondedForceKernel : public CalcSlicedNonbondedForceKernel {
 public:
     HipCalcSlicedNonbondedForceKernel(std::string name, const Platform& platform, HipContext& cu, const System& system)
-        : CalcSlicedNonbondedForceKernel(name, platform), cu(cu), engine(nullptr), userPos(nullptr), userForces(nullptr) {}
+        : CalcSlicedNonbondedForceKernel(name, platform), cu(cu), engine(nullptr), userPos(nullptr), userForces(nullptr), derivBinding(nullptr) {}
     ~HipCalcSlicedNonbondedForceKernel() {
         snb_destroy(engine);
         if (userPos) (void)hipFree(userPos);
         if (userForces) (void)hipFree(userForces);
+        if (derivBinding) (void)hipFree(derivBinding);
     }
 
     void initialize(const System& system, const SlicedNonbondedForce& force) override {
@@ -77,7 +87,13 @@ public:
         cfg.cutoff = force.getCutoffDistance();  cfg.rf_dielectric = force.getReactionFieldDielectric();
         cfg.exceptions_periodic = force.getExceptionsUsePeriodicBoundaryConditions();
         cfg.device = cu.getDeviceIndex();  cfg.stream = cu.getCurrentStream();
-        cfg.shard_count = 1;  cfg.neighbor_padding = 0.1;  cfg.rebuild_interval = 20;
+        // Neighbour list: a skin and displacement-triggered rebuilds (rebuild_interval < 0: the engine watches every atom's displacement since
+        // the last rebuild on the device and rebuilds when one has moved 0.8 * skin / 2, stream-ordered; at the latest after that many
+        // steps) -- like OpenMM's own padded list, it never loses a pair however fast the atoms move.  SNB_NEIGHBOR_PADDING (nm) and
+        // SNB_REBUILD_INTERVAL override (a positive interval fixes the cadence; snb_stats.n_list_overruns then reports skins outrun).
+        cfg.shard_count = 1;
+        cfg.neighbor_padding = getenv("SNB_NEIGHBOR_PADDING") ? atof(getenv("SNB_NEIGHBOR_PADDING")) : 0.1;
+        cfg.rebuild_interval = getenv("SNB_REBUILD_INTERVAL") ? atoi(getenv("SNB_REBUILD_INTERVAL")) : -100;
         if (method == SlicedNonbondedForce::PME || method == SlicedNonbondedForce::LJPME) {
             int nx, ny, nz;
             SlicedNonbondedForceImpl::calcPMEParameters(system, force, cfg.alpha, nx, ny, nz, false);
@@ -109,6 +125,14 @@ public:
             if (hasDeriv) hasDerivatives = true;
         }
         for (auto& d : derivs) cu.addEnergyParameterDerivative(d);
+        {   // device-side derivative accumulation: (slice, term) -> slot of the derivative in the context's buffer
+            const std::vector<std::string>& all = cu.getEnergyParamDerivNames();
+            std::vector<int> slot(bindings.size(), -1);
+            for (size_t k = 0; k < bindings.size(); k++)
+                if (bindings[k].hasDerivative) slot[k] = (int) (std::find(all.begin(), all.end(), bindings[k].name) - all.begin());
+            check(hipMalloc(&derivBinding, sizeof(int) * std::max<size_t>(slot.size(), 1)) == hipSuccess ? SNB_OK : SNB_ERR_HIP, nullptr);
+            check(hipMemcpy(derivBinding, slot.data(), sizeof(int) * slot.size(), hipMemcpyHostToDevice) == hipSuccess ? SNB_OK : SNB_ERR_HIP, nullptr);
+        }
 
         readDefinition(system, force);
         check(hipMalloc(&userPos, (size_t) numParticles * 4 * (useDouble ? 8 : 4)) == hipSuccess ? SNB_OK : SNB_ERR_HIP, nullptr);
@@ -133,18 +157,21 @@ public:
 
         double energy = 0;
         const bool wantE = includeEnergy || hasDerivatives;          // Q4: derivatives accumulate whether or not the energy is requested
-        check(snb_execute(engine, includeForces, wantE, includeDirect, includeReciprocal, &energy), engine);
+        // energy == NULL: the step stays asynchronous (a replayed graph); the slice energies are summed on the device
+        check(snb_execute(engine, includeForces, wantE, includeDirect, includeReciprocal, includeEnergy ? &energy : nullptr), engine);
         if (includeForces) {
             unsigned long long* forceBuffers = (unsigned long long*) cu.getLongForceBuffer().getDevicePointer();
             if (useDouble) hipLaunchKernelGGL(addForcesToContext<double>, dim3(blocks), dim3(256), 0, stream, (const double*) userForces, atomIndex, forceBuffers, numParticles, cu.getPaddedNumAtoms());
             else hipLaunchKernelGGL(addForcesToContext<float>, dim3(blocks), dim3(256), 0, stream, (const float*) userForces, atomIndex, forceBuffers, numParticles, cu.getPaddedNumAtoms());
         }
-        if (wantE) {
-            std::vector<double> sliceE(2 * (size_t) numSlices);
-            check(snb_get_slice_energies(engine, sliceE.data()), engine);
-            std::map<std::string, double>& derivs = cu.getEnergyParamDerivWorkspace();
-            for (size_t k = 0; k < bindings.size(); k++)
-                if (bindings[k].hasDerivative) derivs[bindings[k].name] += sliceE[k];
+        if (hasDerivatives) {      // dE/dlambda_k += E_raw[slice][term], added on the device: no read-back on the MD path
+            const double* sliceE = nullptr;
+            check(snb_slice_energies_device(engine, &sliceE), engine);
+            const int n = 2 * numSlices;
+            if (cu.getUseDoublePrecision() || cu.getUseMixedPrecision())
+                hipLaunchKernelGGL(addDerivativesToContext<double>, dim3((n + 63) / 64), dim3(64), 0, stream, sliceE, derivBinding, n, (double*) cu.getEnergyParamDerivBuffer().getDevicePointer());
+            else
+                hipLaunchKernelGGL(addDerivativesToContext<float>, dim3((n + 63) / 64), dim3(64), 0, stream, sliceE, derivBinding, n, (float*) cu.getEnergyParamDerivBuffer().getDevicePointer());
         }
         return includeEnergy ? energy : 0.0;
     }
@@ -190,29 +217,39 @@ private:
             check(snb_set_dispersion_coefficients(engine, nullptr), engine);
     }
 
-    // global parameters -> lambdas and effective particle / exception parameters (computeParameters, :339-391); uploads only on change
+    // global parameters -> lambdas and the values the parameter offsets refer to.  The effective particle / exception parameters are
+    // formed ON THE DEVICE (snb_set_parameter_offsets + snb_set_global_parameters; the reference: nonbondedParameters.cc:4-179): a changed
+    // global parameter costs two small kernels ahead of the step -- no re-sort, no tile rebuild, no graph re-capture, no synchronisation.
     void pushParameters(ContextImpl& context) {
         std::vector<double> lambdas(2 * (size_t) numSlices, 1.0);
         for (size_t k = 0; k < bindings.size(); k++) if (!bindings[k].name.empty()) lambdas[k] = context.getParameter(bindings[k].name);
         if (lambdas != lastLambdas) { check(snb_set_lambdas(engine, lambdas.data()), engine); lastLambdas = lambdas; }
-        std::vector<double> offsetValues;
-        for (auto& o : particleOffsets) offsetValues.push_back(context.getParameter(o.param));
-        for (auto& o : exceptionOffsets) offsetValues.push_back(context.getParameter(o.param));
-        if (!paramsDirty && offsetValues == lastOffsetValues) return;
-        std::vector<double> q = baseQ, sg = baseSigma, ep = baseEps;
-        size_t v = 0;
-        for (auto& o : particleOffsets) { const double x = offsetValues[v++]; q[o.index] += x * o.dq; sg[o.index] += x * o.dsigma; ep[o.index] += x * o.deps; }
-        check(snb_set_particles(engine, q.data(), sg.data(), ep.data(), subsets.data()), engine);
-        std::vector<double> qq = excQQ, es = excSigma, ee = excEps;
-        for (auto& o : exceptionOffsets) { const double x = offsetValues[v++]; qq[o.index] += x * o.dq; es[o.index] += x * o.dsigma; ee[o.index] += x * o.deps; }
-        check(snb_set_exceptions(engine, (int32_t) excQQ.size(), excPairs.data(), qq.data(), es.data(), ee.data(), excForce14.data()), engine);
-        lastOffsetValues = offsetValues;
-        paramsDirty = false;
+        if (paramsDirty) {      // base values, exceptions and offsets (initialize / copyParametersToContext)
+            check(snb_set_particles(engine, baseQ.data(), baseSigma.data(), baseEps.data(), subsets.data()), engine);
+            check(snb_set_exceptions(engine, (int32_t) excQQ.size(), excPairs.data(), excQQ.data(), excSigma.data(), excEps.data(), excForce14.data()), engine);
+            offsetGlobals.clear();
+            auto slotOf = [&](const std::string& name) {
+                auto it = std::find(offsetGlobals.begin(), offsetGlobals.end(), name);
+                if (it == offsetGlobals.end()) { offsetGlobals.push_back(name); return (int32_t) offsetGlobals.size() - 1; }
+                return (int32_t) (it - offsetGlobals.begin());
+            };
+            std::vector<int32_t> pi, pg, ei, eg; std::vector<double> pd, ed;
+            for (auto& o : particleOffsets) { pi.push_back(o.index); pg.push_back(slotOf(o.param)); pd.push_back(o.dq); pd.push_back(o.dsigma); pd.push_back(o.deps); }
+            for (auto& o : exceptionOffsets) { ei.push_back(o.index); eg.push_back(slotOf(o.param)); ed.push_back(o.dq); ed.push_back(o.dsigma); ed.push_back(o.deps); }
+            check(snb_set_parameter_offsets(engine, (int32_t) offsetGlobals.size(), (int32_t) pi.size(), pi.data(), pg.data(), pd.data(),
+                                            (int32_t) ei.size(), ei.data(), eg.data(), ed.data()), engine);
+            lastOffsetValues.clear();
+            paramsDirty = false;
+        }
+        std::vector<double> values;
+        for (auto& name : offsetGlobals) values.push_back(context.getParameter(name));
+        if (values != lastOffsetValues) { check(snb_set_global_parameters(engine, (int32_t) values.size(), values.data()), engine); lastOffsetValues = values; }
     }
 
     HipContext& cu;
     snb_handle engine;
-    void* userPos;  void* userForces;
+    void* userPos;  void* userForces;  int* derivBinding;
+    std::vector<std::string> offsetGlobals;
     int numParticles = 0, numSubsets = 0, numSlices = 0, method = 0;
     bool useDouble = false, hasDerivatives = false, paramsDirty = true;
     size_t exceptionIs14Count = 0;

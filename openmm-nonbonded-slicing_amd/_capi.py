@@ -11,14 +11,14 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsnb_hip.so")
-SNB_ABI_VERSION = 3
+SNB_ABI_VERSION = 4
 
 # every symbol include/snb.h declares (tests check the library exports each one)
 SYMBOLS = [
-    "snb_create", "snb_destroy", "snb_last_error", "snb_set_particles", "snb_set_exceptions", "snb_set_lambdas",
+    "snb_create", "snb_destroy", "snb_last_error", "snb_set_particles", "snb_set_exceptions", "snb_set_parameter_offsets", "snb_set_global_parameters", "snb_set_lambdas",
     "snb_set_dispersion_coefficients", "snb_compute_dispersion_coefficients", "snb_set_box", "snb_set_positions",
-    "snb_rebuild_neighbors", "snb_execute", "snb_get_forces", "snb_set_force_output", "snb_set_shard_blocks", "snb_get_slice_energies", "snb_synchronize",
-    "snb_get_pme_parameters", "snb_get_ljpme_parameters", "snb_get_stats", "snb_reset_timers", "snb_legal_grid_size", "snb_abi_version",
+    "snb_rebuild_neighbors", "snb_execute", "snb_get_forces", "snb_set_force_output", "snb_set_shard_blocks", "snb_get_slice_energies", "snb_slice_energies_device", "snb_synchronize",
+    "snb_get_pme_parameters", "snb_get_ljpme_parameters", "snb_get_stats", "snb_reset_timers", "snb_set_timing_interval", "snb_legal_grid_size", "snb_abi_version",
     "snb_test_fft3d",
 ]
 
@@ -74,6 +74,8 @@ def lib():
     L.snb_set_particles.argtypes = [vp, dp, dp, dp, ip]
     L.snb_set_exceptions.argtypes = [vp, i32, ip, dp, dp, dp, ip]
     L.snb_set_lambdas.argtypes = [vp, dp]
+    L.snb_set_parameter_offsets.argtypes = [vp, i32, i32, ip, ip, dp, i32, ip, ip, dp]
+    L.snb_set_global_parameters.argtypes = [vp, i32, dp]
     L.snb_set_dispersion_coefficients.argtypes = [vp, dp]
     L.snb_compute_dispersion_coefficients.argtypes = [i32, i32, dp, dp, ip, ctypes.c_double, i32, ctypes.c_double, dp]
     L.snb_set_box.argtypes = [vp, dp]
@@ -85,10 +87,12 @@ def lib():
     L.snb_set_shard_blocks.argtypes = [vp, i32, i32, i32]
     L.snb_get_slice_energies.argtypes = [vp, dp]
     L.snb_synchronize.argtypes = [vp]
+    L.snb_slice_energies_device.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p)]
     L.snb_get_pme_parameters.argtypes = [vp, dp, ip]
     L.snb_get_ljpme_parameters.argtypes = [vp, dp, ip]
     L.snb_get_stats.argtypes = [vp, ctypes.POINTER(SnbStats)]
     L.snb_reset_timers.argtypes = [vp]
+    L.snb_set_timing_interval.argtypes = [vp, i32]
     L.snb_legal_grid_size.argtypes = [i32]; L.snb_legal_grid_size.restype = i32
     L.snb_abi_version.restype = i32
     L.snb_test_fft3d.argtypes = [i32, i32, i32, i32, i32, i32, dp, dp, dp]

@@ -156,11 +156,11 @@ class HipCalcSlicedNonbondedForceKernel:
             if incC: self._binding[(s, 0)] = (name, name in derivs)
             if incLJ: self._binding[(s, 1)] = (name, name in derivs)
         self._derivNames = derivs
-        self._lastParams = None
         self._lastLambdas = None
         # dispersion-correction coefficients at DEFAULT parameter values (SlicedNonbondedForceImpl.cpp:281-291)
         defaults = {force.getGlobalParameterName(i): force.getGlobalParameterDefaultValue(i) for i in range(force.getNumGlobalParameters())}
         self._set_dispersion(force, defaults)
+        self._push_definition()
 
     def _effective(self, params):
         p = self._base.copy()
@@ -185,19 +185,37 @@ class HipCalcSlicedNonbondedForceKernel:
         self._dispCoef = coef
         self._check(self._lib.snb_set_dispersion_coefficients(self._h, _dp(coef)))
 
+    def _push_definition(self):
+        """Base parameters, exceptions and parameter offsets to the engine (once per initialize / copyParametersToContext): the
+        effective values base + sum global * offset are formed ON THE DEVICE (include/snb.h, snb_set_parameter_offsets), as the
+        reference does in platforms/common/src/kernels/nonbondedParameters.cc:4-179."""
+        p = self._base
+        q = np.ascontiguousarray(p[:, 0]); sg = np.ascontiguousarray(p[:, 1]); ep = np.ascontiguousarray(p[:, 2])
+        self._check(self._lib.snb_set_particles(self._h, _dp(q), _dp(sg), _dp(ep), _ip(self._subset)))
+        m = self._excPairs.shape[0]
+        if m > 0:
+            e = self._excBase
+            qq = np.ascontiguousarray(e[:, 0]); es = np.ascontiguousarray(e[:, 1]); ee = np.ascontiguousarray(e[:, 2])
+            self._check(self._lib.snb_set_exceptions(self._h, m, _ip(self._excPairs), _dp(qq), _dp(es), _dp(ee), _ip(self._force14)))
+        else:
+            self._check(self._lib.snb_set_exceptions(self._h, 0, None, None, None, None, None))
+        names = sorted(set(o[0] for o in self._particleOffsets) | set(o[0] for o in self._exceptionOffsets))
+        self._offsetGlobals = names
+        index = {n: k for k, n in enumerate(names)}
+        pi = np.array([o[1] for o in self._particleOffsets], dtype=np.int32); pg = np.array([index[o[0]] for o in self._particleOffsets], dtype=np.int32)
+        pd = np.ascontiguousarray(np.array([[o[2], o[3], o[4]] for o in self._particleOffsets], dtype=np.float64).reshape(-1, 3))
+        ei = np.array([o[1] for o in self._exceptionOffsets], dtype=np.int32); eg = np.array([index[o[0]] for o in self._exceptionOffsets], dtype=np.int32)
+        ed = np.ascontiguousarray(np.array([[o[2], o[3], o[4]] for o in self._exceptionOffsets], dtype=np.float64).reshape(-1, 3))
+        self._check(self._lib.snb_set_parameter_offsets(self._h, len(names), len(pi), _ip(pi) if len(pi) else None, _ip(pg) if len(pi) else None, _dp(pd) if len(pi) else None,
+                                                        len(ei), _ip(ei) if len(ei) else None, _ip(eg) if len(ei) else None, _dp(ed) if len(ei) else None))
+        self._lastGlobals = None
+
     def _push_parameters(self, params):
-        key = tuple(sorted(params.items()))
-        if key != self._lastParams:
-            p, e = self._effective(params)
-            q = np.ascontiguousarray(p[:, 0]); sg = np.ascontiguousarray(p[:, 1]); ep = np.ascontiguousarray(p[:, 2])
-            self._check(self._lib.snb_set_particles(self._h, _dp(q), _dp(sg), _dp(ep), _ip(self._subset)))
-            m = self._excPairs.shape[0]
-            if m > 0:
-                qq = np.ascontiguousarray(e[:, 0]); es = np.ascontiguousarray(e[:, 1]); ee = np.ascontiguousarray(e[:, 2])
-                self._check(self._lib.snb_set_exceptions(self._h, m, _ip(self._excPairs), _dp(qq), _dp(es), _dp(ee), _ip(self._force14)))
-            else:
-                self._check(self._lib.snb_set_exceptions(self._h, 0, None, None, None, None, None))
-            self._lastParams = key
+        if self._offsetGlobals:
+            vals = np.array([params[n] for n in self._offsetGlobals], dtype=np.float64)
+            if self._lastGlobals is None or not np.array_equal(vals, self._lastGlobals):
+                self._check(self._lib.snb_set_global_parameters(self._h, len(vals), _dp(vals)))
+                self._lastGlobals = vals
         lam = np.ones((self.numSlices, 2))
         for (s, t), (name, _) in self._binding.items():
             lam[s, t] = params[name]

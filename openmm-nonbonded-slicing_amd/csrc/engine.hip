@@ -53,6 +53,8 @@ struct EngineBase {
     virtual void setParticles(const double*, const double*, const double*, const int32_t*) = 0;
     virtual void setExceptions(int32_t, const int32_t*, const double*, const double*, const double*, const int32_t*) = 0;
     virtual void setLambdas(const double*) = 0;
+    virtual void setParameterOffsets(int, int, const int32_t*, const int32_t*, const double*, int, const int32_t*, const int32_t*, const double*) = 0;
+    virtual void setGlobalParameters(int, const double*) = 0;
     virtual void setDispersion(const double*) = 0;
     virtual void setBox(const double*) = 0;
     virtual void setPositions(const void*, int, int, int) = 0;
@@ -62,9 +64,11 @@ struct EngineBase {
     virtual void setForceOutput(void*, int, int) = 0;
     virtual void setShardBlocks(int, int, int) = 0;
     virtual void getSliceEnergies(double*) = 0;
+    virtual const double* sliceEnergiesDevice() = 0;
     virtual void sync() = 0;
     virtual void getStats(snb_stats*) = 0;
     virtual void resetTimers() = 0;
+    virtual void setTimingInterval(int) = 0;
     virtual void getPme(double*, int32_t*, bool dispersion) = 0;
 };
 
@@ -192,7 +196,7 @@ public:
     // host-side definition
     std::vector<double> charge, sigma, epsilon; std::vector<int32_t> subset;
     std::vector<int32_t> excPairs; std::vector<double> excQQ, excSigma, excEps; std::vector<int32_t> excForce14;
-    std::vector<double> lambdas, dispCoef;
+    std::vector<double> lambdas, dispCoef; std::vector<Real> hLambdas;
     double box[9] = {0}; bool haveBox = false, haveParticles = false;
     // positions
     const void* devUserPos = nullptr; int posIsDouble = 1, posStride4 = 0; bool havePositions = false;
@@ -228,7 +232,16 @@ public:
     double tileCell[9] = {0};      // the cell the tile image codes refer to (the box; an enclosing cell for CutoffNonPeriodic)
     DevBuf<long long> dNbTrace, dPmeTrace;
     bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
-    double maxAbsQ = 0, maxAbsC6 = 0;
+    // Parameter offsets on the device (the reference: platforms/common/src/kernels/nonbondedParameters.cc:4-179).  charge/sigma/epsilon
+    // and the exception arrays above hold the BASE values; effective = base + sum_k global[k] * delta is formed by k_particleParams /
+    // k_exceptionParams whenever a base value, an offset or a global parameter changes -- no re-sort, no tile rebuild, no graph re-capture,
+    // no host synchronisation.  The same pass reduces what the closed-form energy terms and the spreader's fixed-point scale need.
+    struct Offset { int target, global; double d[3]; };
+    std::vector<Offset> offP, offE; std::vector<double> gValues; int nGlobals = 0;
+    bool basePDirty = true, baseEDirty = true, offsetsDirty = true, globalsDirty = true;
+    DevBuf<double> dBaseP, dOffPDelta, dBase14, dOff14Delta, dGlobals, dParamSums;      // dParamSums: [3 nsub] (sum q, sum q^2, sum c6^2) + 2 ordered-int maxima
+    DevBuf<int> dOffPStart, dOffPGlobal, dOff14Start, dOff14Global, dSlice14;
+    DevBuf<Real> dFixScale;      // [4]: fixed-point scale and its inverse of the charge mesh, then of the dispersion mesh
     DevBuf<int> dSortedToUser, dUserToSorted, blockSubset, tileJ, atomSubset, atomGrid, gridSubset, exclStart, exclList;
     // GPU neighbour build: static user-order data and scratch
     DevBuf<int> dUSubset, dSubsetStart, dSubsetPaddedStart, dSlotOfSubset, dValsIn, dValsOut, dCounters; DevBuf<Real> dUCharge, dWrapped, dOffsetU; DevBuf<T2> dUSigEps;
@@ -236,8 +249,8 @@ public:
     std::vector<int> hSubsetStart, hSubsetPaddedStart, staticBlkSubset; int staticNpad = 0; size_t tileCap = 0; bool staticDirty = true, gpuBuilt = false;
     DevBuf<int2> pairs14, pairsExcl, colRange; DevBuf<int4> tileInfo, workItems, workItemsStage, workItemsPartial; int numWorkItems = 0; int colCells[2] = {0, 0}; DevBuf<unsigned> masks;
     DevBuf<T4> params14, paramsExcl; int n14 = 0, nExcl = 0;
-    DevBuf<double> sliceE, sliceTotal;      // 64 partitioned copies of the raw [S][2] energies, and their sum (last kernel of an energy step)
-    bool energyPending = false, pendDirect = false, pendRecip = false;      // the last energy step's sums are still on the device
+    DevBuf<double> dDispCoef, sliceE, sliceTotal;      // 64 partitioned copies of the raw [S][2] energies, and their sum (last kernel of an energy step)
+    bool energyPending = false;      // the last energy step's sums are still on the device
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
@@ -253,7 +266,6 @@ public:
     bool valuesDirty = false, excValuesDirty = false, haveExceptions = false;   // parameter values changed, structure did not
     // displacement watch: reference positions of the last rebuild and two flags in mapped host memory (read without synchronising)
     DevBuf<T4> posRef; int* hDispFlags = nullptr; int* dDispFlags = nullptr; int64_t listOverruns = 0;
-    bool hostSumsValid = false; std::vector<double> subsetCharge, selfCoulomb, selfDispersion;   // per-subset sums behind the closed-form energy terms
     std::vector<int3> hKvec; DevBuf<int3> dKvec; DevBuf<Real> dCosSin;
     struct GraphKey {
         const void* pos; int isDouble, stride4; bool direct, recip, energy; void* out; int outDouble, outAcc;
@@ -264,6 +276,8 @@ public:
     struct CachedGraph { GraphKey key; hipGraphExec_t exec; };
     std::vector<CachedGraph> graphs; size_t graphVictim = 0; long long execCount = 0;
     static constexpr size_t MAX_GRAPHS = 4;
+    int timingInterval = 32;
+    void setTimingInterval(int n) override { timingInterval = n; execCount = 0; }
     hipGraphExec_t sortGraphExec = nullptr; std::vector<unsigned char> sortGraphKey; bool sortGraphBroken = false;      // phase A of the neighbour rebuild
     void dropGraph() { for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); graphs.clear(); graphVictim = 0; }
     bool lastRecip = false;
@@ -279,6 +293,7 @@ public:
         charge.assign(N, 0.0); sigma.assign(N, 1.0); epsilon.assign(N, 0.0); subset.assign(N, 0);
         lambdas.assign((size_t)S * 2, 1.0); dispCoef.assign(S, 0.0); hostSliceE.assign((size_t)S * 2, 0.0);
         sliceE.resize((size_t)S * 2 * SNB_SLICE_E_PARTS); sliceTotal.resize((size_t)S * 2);
+        dDispCoef.upload(dispCoef, stream);
         if (cfg.shard_count < 1) cfg.shard_count = 1;
         shardBegin = cfg.shard_count > 1 ? cfg.shard_rank : 0; shardEnd = shardBegin + 1; shardPeriod = cfg.shard_count;
         // tabulated Ewald force factor: opt-in.  Measured on MI355X it only trades 4 % of the VALU instructions for LDS gathers (the packed
@@ -371,13 +386,8 @@ public:
             if (subset[i] != sub[i]) subsetsChanged = true;      // subsets decide the sorted order and the block layout
         }
         charge.assign(q, q + N); sigma.assign(sg, sg + N); epsilon.assign(ep, ep + N); subset.assign(sub, sub + N);
-        maxAbsQ = 0; maxAbsC6 = 0;   // bounds for the fixed-point LDS accumulation of the single-precision brick spreader
-        for (int i = 0; i < N; i++) {
-            maxAbsQ = std::max(maxAbsQ, std::fabs(q[i]));
-            const double hs = 0.5 * sg[i];
-            maxAbsC6 = std::max(maxAbsC6, std::fabs(8.0 * hs * hs * hs * 2.0 * std::sqrt(ep[i])));
-        }
-        haveParticles = true; hostSumsValid = false;
+        basePDirty = true;
+        haveParticles = true;
         // new charges / sigmas / epsilons alone (parameter offsets, updateParametersInContext) do not touch the neighbour structure:
         // they are refreshed in place (refreshValues) instead of going through a rebuild
         if (subsetsChanged) { needRebuild = true; paramsDirty = true; staticDirty = true; } else valuesDirty = true;
@@ -390,15 +400,52 @@ public:
         excPairs.swap(np); excQQ.assign(qq, qq + m); excSigma.assign(sg, sg + m); excEps.assign(ep, ep + m);
         if (f14) excForce14.assign(f14, f14 + m); else excForce14.assign(m, 0);
         haveExceptions = true;
+        baseEDirty = true;
         if (pairsChanged) { needRebuild = true; paramsDirty = true; staticDirty = true; } else excValuesDirty = true;
+    }
+    void setParameterOffsets(int nGlob, int nP, const int32_t* pIdx, const int32_t* pGlob, const double* pDelta, int nE, const int32_t* eIdx, const int32_t* eGlob, const double* eDelta) override {
+        if (nGlob < 0 || nP < 0 || nE < 0) throw HipError{"snb_set_parameter_offsets: negative count"};
+        const int m = (int)(excPairs.size() / 2);
+        for (int k = 0; k < nP; k++) if (pIdx[k] < 0 || pIdx[k] >= N || pGlob[k] < 0 || pGlob[k] >= nGlob) throw HipError{"snb_set_parameter_offsets: particle offset out of range"};
+        for (int k = 0; k < nE; k++) if (eIdx[k] < 0 || eIdx[k] >= m || eGlob[k] < 0 || eGlob[k] >= nGlob) throw HipError{"snb_set_parameter_offsets: exception offset out of range (set the exceptions first)"};
+        std::vector<Offset> nP_(nP), nE_(nE);
+        for (int k = 0; k < nP; k++) nP_[k] = Offset{pIdx[k], pGlob[k], {pDelta[3 * k], pDelta[3 * k + 1], pDelta[3 * k + 2]}};
+        for (int k = 0; k < nE; k++) nE_[k] = Offset{eIdx[k], eGlob[k], {eDelta[3 * k], eDelta[3 * k + 1], eDelta[3 * k + 2]}};
+        auto same = [](const std::vector<Offset>& a, const std::vector<Offset>& b, bool structureOnly) {
+            if (a.size() != b.size()) return false;
+            for (size_t k = 0; k < a.size(); k++) {
+                if (a[k].target != b[k].target || a[k].global != b[k].global) return false;
+                if (!structureOnly && (a[k].d[0] != b[k].d[0] || a[k].d[1] != b[k].d[1] || a[k].d[2] != b[k].d[2])) return false;
+            }
+            return true;
+        };
+        if (nGlob == nGlobals && same(offP, nP_, false) && same(offE, nE_, false)) return;      // unchanged (copyParametersToContext re-sends everything)
+        // an exception that carries an offset is a 1-4 interaction whatever its base values (Q6): a different set of them changes the 1-4 list
+        const bool structure = nGlob != nGlobals || !same(offE, nE_, true) || !same(offP, nP_, true);
+        offP.swap(nP_); offE.swap(nE_);
+        if (nGlob != nGlobals) { nGlobals = nGlob; gValues.assign(nGlob, 0.0); globalsDirty = true; }
+        offsetsDirty = true;
+        if (structure) { needRebuild = true; paramsDirty = true; staticDirty = true; } else { valuesDirty = true; excValuesDirty = true; }
+    }
+    void setGlobalParameters(int n, const double* v) override {
+        if (n != nGlobals) throw HipError{"snb_set_global_parameters: count differs from snb_set_parameter_offsets"};
+        bool changed = false;
+        for (int k = 0; k < n; k++) if (gValues[k] != v[k]) { gValues[k] = v[k]; changed = true; }
+        if (!changed) return;
+        globalsDirty = true;
+        if (!offP.empty()) valuesDirty = true;
+        if (!offE.empty()) excValuesDirty = true;
     }
     void setLambdas(const double* l) override {
         lambdas.assign(l, l + (size_t)S * 2);
-        std::vector<Real> h(lambdas.begin(), lambdas.end());
-        dLambdas.upload(h, stream);
-        HIPCHECK(hipStreamSynchronize(stream));
+        hLambdas.assign(lambdas.begin(), lambdas.end());      // (a member: the staging array outlives the asynchronous copy; no synchronisation per lambda change)
+        dLambdas.upload(hLambdas, stream);
     }
-    void setDispersion(const double* c) override { if (c) dispCoef.assign(c, c + S); else dispCoef.assign(S, 0.0); }
+    void setDispersion(const double* c) override {
+        if (c) dispCoef.assign(c, c + S); else dispCoef.assign(S, 0.0);
+        dDispCoef.upload(dispCoef, stream);      // (a member: outlives the copy); read by the last kernel of an energy step
+        dropGraph();
+    }
     void setBox(const double* b) override {
         if (b[1] != 0 || b[2] != 0 || b[5] != 0) throw HipError{"box vectors must be in reduced (lower triangular) form"};
         bool changed = !haveBox;
@@ -535,7 +582,9 @@ public:
             colRange.upload(hRange, stream);
         }
         if (Npad >= (1 << SNB_JSHIFT_BITS) - 1) throw HipError{"too many atoms for the 25-bit tile index"};
-        // 4. sorted parameter arrays
+        // 4. sorted parameter arrays (effective parameter values: formed on the device, fetched for this host-side path)
+        std::vector<Real> effQ(N); std::vector<T2> effSE(N);
+        if (N > 0) { HIPCHECK(hipMemcpy(effQ.data(), dUCharge.p, sizeof(Real) * N, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(effSE.data(), dUSigEps.p, sizeof(T2) * N, hipMemcpyDeviceToHost)); }
         std::vector<T4> hPosq(Npad); std::vector<T2> hSigeps(Npad); std::vector<Real> hOff((size_t)Npad * 3, Real(0));
         std::vector<int> hAtomSubset(Npad, -1), hAtomGrid(Npad, -1);
         std::vector<int> slotOfSubset(nsub, -1);
@@ -544,8 +593,8 @@ public:
         for (int s = 0; s < Npad; s++) {
             int u = sortedToUser[s];
             if (u >= 0) {
-                hPosq[s].x = (Real)wp[3 * (size_t)u]; hPosq[s].y = (Real)wp[3 * (size_t)u + 1]; hPosq[s].z = (Real)wp[3 * (size_t)u + 2]; hPosq[s].w = (Real)charge[u];
-                hSigeps[s].x = (Real)(0.5 * sigma[u]); hSigeps[s].y = (Real)(2.0 * std::sqrt(epsilon[u]));
+                hPosq[s].x = (Real)wp[3 * (size_t)u]; hPosq[s].y = (Real)wp[3 * (size_t)u + 1]; hPosq[s].z = (Real)wp[3 * (size_t)u + 2]; hPosq[s].w = effQ[u];
+                hSigeps[s] = effSE[u];
                 for (int d = 0; d < 3; d++) hOff[3 * (size_t)s + d] = (Real)off[3 * (size_t)u + d];
                 hAtomSubset[s] = subset[u]; hAtomGrid[s] = slotOfSubset[subset[u]];
             } else {   // parked padding atom: zero parameters, far away, distinct
@@ -736,40 +785,70 @@ public:
 
     // Static (sort-independent) device data: 1-4 list and exclusion CSR in USER indices (Q6:
     // ReferenceNonbondedSlicingKernels.cpp:99-112, 129-131), per-atom parameters in user order, the padded subset layout.
-    // 1-4 list (exceptions with non-zero parameters, Q6) in user order: pairs + (sigma, 4 eps, k qq, slice)
+    // 1-4 list in user order: the exceptions with non-zero base parameters, or flagged by the caller, or carrying a parameter offset (Q6).
+    // Structure only (pairs, slices, base values, offsets in CSR per 1-4 entry); the values are formed on the device (syncParameters).
     void upload14() {
         const size_t m = excPairs.size() / 2;
-        std::vector<int2> p14; std::vector<T4> q14;
+        std::vector<char> hasOffset(m, 0);
+        for (auto& o : offE) hasOffset[o.target] = 1;
+        std::vector<int2> p14; std::vector<double> b14; std::vector<int> sl14, where(m, -1);
         auto sl = [](int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; };
         for (size_t k = 0; k < m; k++) {
             const int a = excPairs[2 * k], b = excPairs[2 * k + 1];
-            if (excQQ[k] != 0.0 || excEps[k] != 0.0 || excForce14[k]) {
+            if (excQQ[k] != 0.0 || excEps[k] != 0.0 || excForce14[k] || hasOffset[k]) {
+                where[k] = (int)p14.size();
                 p14.push_back(make_int2(a, b));
-                T4 v; v.x = (Real)excSigma[k]; v.y = (Real)(4.0 * excEps[k]); v.z = (Real)(SNB_ONE_4PI_EPS0 * excQQ[k]); v.w = (Real)sl(subset[a], subset[b]);
-                q14.push_back(v);
+                b14.push_back(excQQ[k]); b14.push_back(excSigma[k]); b14.push_back(excEps[k]);
+                sl14.push_back(sl(subset[a], subset[b]));
             }
         }
         n14 = (int)p14.size(); nExcl = (int)m;
-        pairs14.upload(p14, stream); params14.upload(q14, stream);
+        std::vector<int> start(n14 + 1, 0), glob(offE.size()); std::vector<double> delta(3 * offE.size());
+        for (auto& o : offE) start[where[o.target] + 1]++;
+        for (int k = 0; k < n14; k++) start[k + 1] += start[k];
+        { std::vector<int> fill(n14, 0); for (auto& o : offE) { const int e = where[o.target], at = start[e] + fill[e]++; glob[at] = o.global; for (int d = 0; d < 3; d++) delta[3 * (size_t)at + d] = o.d[d]; } }
+        pairs14.upload(p14, stream); dBase14.upload(b14, stream); dSlice14.upload(sl14, stream);
+        dOff14Start.upload(start, stream); dOff14Global.upload(glob, stream); dOff14Delta.upload(delta, stream);
+        params14.resize(n14);
         stats.n_14 = n14; stats.n_exclusions = nExcl;
+        HIPCHECK(hipStreamSynchronize(stream));      // (host staging vectors go out of scope)
+        baseEDirty = false;
     }
-    void uploadParticleValues() {
-        std::vector<Real> hq(N); std::vector<T2> hse(N);
-        for (int i = 0; i < N; i++) { hq[i] = (Real)charge[i]; hse[i].x = (Real)(0.5 * sigma[i]); hse[i].y = (Real)(2.0 * std::sqrt(epsilon[i])); }
-        dUCharge.upload(hq, stream); dUSigEps.upload(hse, stream);
+    void uploadParticleBase() {
+        std::vector<double> hb(3 * (size_t)N);
+        for (int i = 0; i < N; i++) { hb[3 * (size_t)i] = charge[i]; hb[3 * (size_t)i + 1] = sigma[i]; hb[3 * (size_t)i + 2] = epsilon[i]; }
+        std::vector<int> start((size_t)N + 1, 0), glob(offP.size()); std::vector<double> delta(3 * offP.size());
+        for (auto& o : offP) start[o.target + 1]++;
+        for (int i = 0; i < N; i++) start[i + 1] += start[i];
+        { std::vector<int> fill(N, 0); for (auto& o : offP) { const int at = start[o.target] + fill[o.target]++; glob[at] = o.global; for (int d = 0; d < 3; d++) delta[3 * (size_t)at + d] = o.d[d]; } }
+        dBaseP.upload(hb, stream); dOffPStart.upload(start, stream); dOffPGlobal.upload(glob, stream); dOffPDelta.upload(delta, stream);
+        dUCharge.resize(N); dUSigEps.resize(N); dParamSums.resize(3 * (size_t)nsub + 1); dFixScale.resize(4);
+        HIPCHECK(hipStreamSynchronize(stream));
+        basePDirty = false;
+    }
+    // Effective parameters on the device, from whatever changed: base values / offsets (re-uploaded), global parameter values (a few
+    // doubles).  Enqueued on the engine's stream ahead of the step; nothing here waits for the GPU unless a base array was re-uploaded.
+    void syncParameters(bool particles, bool exceptions) {
+        if (offsetsDirty) { basePDirty = true; baseEDirty = true; offsetsDirty = false; }
+        if (basePDirty) { uploadParticleBase(); particles = true; }
+        if (baseEDirty) { upload14(); exceptions = true; }
+        if (globalsDirty) {
+            dGlobals.resize(std::max(nGlobals, 1));
+            if (nGlobals > 0) HIPCHECK(hipMemcpyAsync(dGlobals.p, gValues.data(), sizeof(double) * nGlobals, hipMemcpyHostToDevice, stream));      // (gValues is a member: it outlives the copy)
+            globalsDirty = false;
+        }
+        if (particles) launchParticleParams<Real>(N, nsub, dBaseP.p, offP.empty() ? nullptr : dOffPStart.p, dOffPGlobal.p, dOffPDelta.p, dGlobals.p, dUSubset.p, dUCharge.p, dUSigEps.p,
+                                                  dParamSums.p, dFixScale.p, stream);
+        if (exceptions) launchExceptionParams<Real>(n14, dBase14.p, offE.empty() ? nullptr : dOff14Start.p, dOff14Global.p, dOff14Delta.p, dGlobals.p, dSlice14.p, params14.p, stream);
     }
     // New parameter VALUES with the same subsets / exception pairs (copyParametersToContext, parameter offsets: the reference recomputes
-    // them on the device per changed global parameter, nonbondedParameters.cc:4-179): the sorted per-atom arrays are rewritten in place
-    // from the user-order values -- no re-sort, no tile rebuild.  The captured step graph is dropped because kernel arguments derived
-    // from the values (number of 1-4 pairs, fixed-point scale of the spreader) are baked into it.
+    // them on the device per changed global parameter, nonbondedParameters.cc:4-179): effective values on the device, then the sorted
+    // per-atom arrays are rewritten in place -- no re-sort, no tile rebuild, no host synchronisation, and the captured step graphs stay
+    // valid (nothing derived from the values is baked into them: the spreader reads its fixed-point scale from device memory).
     void refreshValues() {
-        if (excValuesDirty) upload14();
-        if (valuesDirty) {
-            uploadParticleValues();
-            launchRefreshParams<Real>(dSortedToUser.p, dUCharge.p, dUSigEps.p, posq.p, sigeps.p, Npad, stream);
-        }
-        HIPCHECK(hipStreamSynchronize(stream));      // the host staging vectors above go out of scope
-        dropGraph();
+        const bool particles = valuesDirty;
+        syncParameters(valuesDirty, excValuesDirty);
+        if (particles) launchRefreshParams<Real>(dSortedToUser.p, dUCharge.p, dUSigEps.p, posq.p, sigeps.p, Npad, stream);
         valuesDirty = excValuesDirty = false;
     }
 
@@ -780,13 +859,14 @@ public:
             const int a = excPairs[2 * k], b = excPairs[2 * k + 1];
             hStart[a + 1]++; hStart[b + 1]++;
         }
-        upload14();
         for (int i = 0; i < N; i++) hStart[i + 1] += hStart[i];
         { std::vector<int> fill(N, 0); for (size_t k = 0; k < m; k++) { const int a = excPairs[2 * k], b = excPairs[2 * k + 1]; hList[hStart[a] + fill[a]++] = b; hList[hStart[b] + fill[b]++] = a; } }
         exclStart.upload(hStart, stream); exclList.upload(hList, stream);
-        // user-order parameters
-        uploadParticleValues();
+        // user-order parameters: formed on the device from base values, offsets and global parameters
         dUSubset.upload(std::vector<int>(subset.begin(), subset.end()), stream);
+        HIPCHECK(hipStreamSynchronize(stream));
+        basePDirty = baseEDirty = true;
+        syncParameters(true, true);
         // padded subset layout (depends on subset populations only)
         std::vector<int> cnt(nsub, 0);
         for (int i = 0; i < N; i++) cnt[subset[i]]++;
@@ -999,10 +1079,7 @@ public:
         p.cells = pmeCells.p;
         { static const bool tr = getenv("SNB_PME_TRACE") != nullptr; if (tr) { if (!dPmeTrace.p) { dPmeTrace.resize(4); HIPCHECK(hipMemset(dPmeTrace.p, 0, 32)); } p.trace = dPmeTrace.p; } }
         p.cellsReady = (!plan.dispersion && cellsFromGather) ? 1 : 0;
-        {   // fixed point: 16 x the largest per-atom charge fits 31 bits (a grid point collects at most a few atoms' weights, each <= 1)
-            const double m = std::max(plan.dispersion ? maxAbsC6 : maxAbsQ, 1e-30);
-            p.fixScale = (Real)(std::ldexp(1.0, 30) / (16.0 * m)); p.fixInv = (Real)(1.0 / (double)p.fixScale);
-        }
+        p.fixDev = dFixScale.p ? dFixScale.p + (plan.dispersion ? 2 : 0) : nullptr;      // (k_fixScale keeps it in step with the parameters)
         p.gridReal = plan.gridReal.p; p.gridCplx = plan.gridCplx.p; p.twx = plan.twx.p; p.twy = plan.twy.p; p.twz = plan.twz.p;
         p.modx = plan.modx.p; p.mody = plan.mody.p; p.modz = plan.modz.p;
         const double det = box[0] * box[4] * box[8], sc = 1.0 / det;
@@ -1074,7 +1151,7 @@ public:
         // at the next step, while this one is executing)
         // Energy steps (per-slice energies, the step of every force with energy-parameter derivatives, Q4) are graph steps like any other:
         // they end with the device-side sum of the slice-energy partitions and leave the result there until it is asked for.
-        const bool eager = cfg.disable_graph || noStepGraph || rebuilding || (execCount++ % 32 == 0);
+        const bool eager = cfg.disable_graph || noStepGraph || rebuilding || (timingInterval > 0 && execCount++ % timingInterval == 0);
         if (eager) {
             EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
             if (ev.pending) harvest(ev);
@@ -1110,7 +1187,7 @@ public:
         }
         stepCounter++;
         if (energy) {
-            energyPending = true; pendDirect = includeDirect != 0; pendRecip = includeRecip != 0;
+            energyPending = true;
             if (energyOut) { fetchSliceEnergies(); double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }      // (synchronises)
         } else if (energyOut) *energyOut = 0.0;
     }
@@ -1122,7 +1199,6 @@ public:
         HIPCHECK(hipMemcpyAsync(dev.data(), sliceTotal.p, sizeof(double) * dev.size(), hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
         hostSliceE = dev;
-        addHostTerms(pendDirect, pendRecip);
         energyPending = false;
     }
 
@@ -1227,7 +1303,22 @@ public:
             const bool recipDone = includeRecip && (isPme() || cfg.method == SNB_Ewald);
             launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, recipDone ? fpx.p : nullptr, fpy.p, fpz.p, dUserToSorted.p, N, outPtr, outIsDouble, outAccumulate, stream);
         }
-        if (energy) launchSumSliceParts(sliceE.p, sliceTotal.p, 2 * S, stream);
+        if (energy) {
+            // closed-form terms on the device (rank 0 only when sharded), as the reference GPU path keeps them next to its kernels
+            // (CommonNonbondedSlicingKernels.cpp:618-638, 1129-1139)
+            SliceFinish f; std::memset(&f, 0, sizeof(f));
+            if (cfg.shard_rank == 0) {
+                const double volume = box[0] * box[4] * box[8];
+                if (includeRecip && cfg.method >= SNB_Ewald) {
+                    f.sums = dParamSums.p;
+                    f.selfCoulomb = -SNB_ONE_4PI_EPS0 * cfg.alpha / std::sqrt(SNB_PI);
+                    f.selfDispersion = cfg.method == SNB_LJPME ? std::pow(cfg.alpha_d, 6.0) / 12.0 : 0.0;
+                    f.background = (-1.0 / (4 * cfg.alpha * cfg.alpha)) / (2 * SNB_EPSILON0 * volume);
+                }
+                if (includeDirect && (cfg.method == SNB_CutoffPeriodic || cfg.method == SNB_Ewald || cfg.method == SNB_PME)) { f.dispCoef = dDispCoef.p; f.invVolume = 1.0 / volume; }
+            }
+            launchFinishSliceEnergies(sliceE.p, sliceTotal.p, 2 * S, f, stream);
+        }
         if (ev) HIPCHECK(hipEventRecord(ev->e[4], stream));
     }
 
@@ -1274,36 +1365,6 @@ public:
         launchPmeInterpolate<Real>(pp, st);
     }
 
-    // Self energy, neutralising background (ReferenceSlicedLJCoulombIxn.cpp:203-222) and dispersion correction
-    // (ReferenceNonbondedSlicingKernels.cpp:244-249): closed-form host scalars, as the reference GPU path keeps them
-    // (CommonNonbondedSlicingKernels.cpp:618-638, 1129-1139).  When sharded only rank 0 adds them.
-    void addHostTerms(bool direct, bool recip) {
-        if (cfg.shard_rank != 0) return;
-        const double volume = box[0] * box[4] * box[8];
-        if (recip && cfg.method >= SNB_Ewald) {
-            if (!hostSumsValid) {      // O(N) sums over the particle parameters: recomputed only when the parameters change
-                subsetCharge.assign(nsub, 0.0); selfCoulomb.assign(nsub, 0.0); selfDispersion.assign(nsub, 0.0);
-                // from the parameters AS THE DEVICE HOLDS THEM (rounded to Real): the self energy cancels the self-interaction inside the
-                // reciprocal sum, which is quadratic in the stored charges -- with the unrounded doubles here a single-precision engine
-                // would be off by 2e-8 of 7e6 kJ/mol per 100k atoms of water
-                for (int i = 0; i < N; i++) {
-                    const int s = subset[i];
-                    const double q = (double)(Real)charge[i], hs = (double)(Real)(0.5 * sigma[i]), se = (double)(Real)(2.0 * std::sqrt(epsilon[i]));
-                    subsetCharge[s] += q;
-                    selfCoulomb[s] -= SNB_ONE_4PI_EPS0 * q * q * cfg.alpha / std::sqrt(SNB_PI);
-                    if (cfg.method == SNB_LJPME) selfDispersion[s] += std::pow(cfg.alpha_d, 6.0) * 64.0 * std::pow(hs, 6.0) * se * se / 12.0;
-                }
-                hostSumsValid = true;
-            }
-            for (int s = 0; s < nsub; s++) { hostSliceE[2 * (s * (s + 3) / 2)] += selfCoulomb[s]; hostSliceE[2 * (s * (s + 3) / 2) + 1] += selfDispersion[s]; }
-            const std::vector<double>& Q = subsetCharge;
-            const double factor = (-1.0 / (4 * cfg.alpha * cfg.alpha)) / (2 * SNB_EPSILON0 * volume);
-            for (int i = 0; i < nsub; i++) for (int j = i; j < nsub; j++) hostSliceE[2 * (j * (j + 1) / 2 + i)] += (i == j ? 1 : 2) * Q[i] * Q[j] * factor;
-        }
-        if (direct && (cfg.method == SNB_CutoffPeriodic || cfg.method == SNB_Ewald || cfg.method == SNB_PME))
-            for (int s = 0; s < S; s++) hostSliceE[2 * s + 1] += dispCoef[s] / volume;
-    }
-
     void setForceOutput(void* out, int isDouble, int accumulate) override { outPtr = out; outIsDouble = isDouble; outAccumulate = accumulate; outputWritten = false; }
     void getForces(void* out, int isDevice, int isDouble, int accumulate) override {
         if (isDevice && out == outPtr && isDouble == outIsDouble && outputWritten) return;   // the last execute already delivered them there
@@ -1316,6 +1377,7 @@ public:
         HIPCHECK(hipMemcpyAsync(out, tmp.p, bytes, hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
     }
+    const double* sliceEnergiesDevice() override { return sliceTotal.p; }
     void getSliceEnergies(double* out) override { fetchSliceEnergies(); std::memcpy(out, hostSliceE.data(), sizeof(double) * S * 2); }
     void getStats(snb_stats* o) override {
         HIPCHECK(hipStreamSynchronize(stream));
@@ -1430,6 +1492,15 @@ snb_status snb_set_exceptions(snb_handle h, int32_t m, const int32_t* pairs, con
     if (m < 0 || (m > 0 && (!pairs || !qq || !s || !e))) return SNB_ERR_INVALID_ARGUMENT;
     return guard(h, [&] { h->impl->setExceptions(m, pairs, qq, s, e, f14); });
 }
+snb_status snb_set_parameter_offsets(snb_handle h, int32_t nGlobals, int32_t nP, const int32_t* particle, const int32_t* pGlobal, const double* pDelta,
+                                     int32_t nE, const int32_t* exception, const int32_t* eGlobal, const double* eDelta) {
+    if ((nP > 0 && (!particle || !pGlobal || !pDelta)) || (nE > 0 && (!exception || !eGlobal || !eDelta))) return SNB_ERR_INVALID_ARGUMENT;
+    return guard(h, [&] { h->impl->setParameterOffsets(nGlobals, nP, particle, pGlobal, pDelta, nE, exception, eGlobal, eDelta); });
+}
+snb_status snb_set_global_parameters(snb_handle h, int32_t n, const double* values) {
+    if (n < 0 || (n > 0 && !values)) return SNB_ERR_INVALID_ARGUMENT;
+    return guard(h, [&] { h->impl->setGlobalParameters(n, values); });
+}
 snb_status snb_set_lambdas(snb_handle h, const double* l) { if (!l) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->setLambdas(l); }); }
 snb_status snb_set_dispersion_coefficients(snb_handle h, const double* c) { return guard(h, [&] { h->impl->setDispersion(c); }); }
 snb_status snb_compute_dispersion_coefficients(int32_t n, int32_t nsub, const double* sigma, const double* epsilon, const int32_t* subset, double cutoff,
@@ -1452,6 +1523,7 @@ snb_status snb_get_forces(snb_handle h, void* out, int32_t isDevice, int32_t isD
 snb_status snb_set_shard_blocks(snb_handle h, int32_t begin, int32_t end, int32_t period) { return guard(h, [&] { h->impl->setShardBlocks(begin, end, period); }); }
 snb_status snb_set_force_output(snb_handle h, void* out, int32_t isDouble, int32_t acc) { return guard(h, [&] { h->impl->setForceOutput(out, isDouble, acc); }); }
 snb_status snb_get_slice_energies(snb_handle h, double* out) { if (!out) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->getSliceEnergies(out); }); }
+snb_status snb_slice_energies_device(snb_handle h, const double** out) { if (!out) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { *out = h->impl->sliceEnergiesDevice(); }); }
 snb_status snb_synchronize(snb_handle h) { return guard(h, [&] { h->impl->sync(); }); }
 snb_status snb_get_pme_parameters(snb_handle h, double* alpha, int32_t grid[3]) {
     if (!h || !h->impl || !alpha || !grid) return SNB_ERR_INVALID_ARGUMENT;
@@ -1464,6 +1536,7 @@ snb_status snb_get_ljpme_parameters(snb_handle h, double* alpha, int32_t grid[3]
     return guard(h, [&] { h->impl->getPme(alpha, grid, true); });
 }
 snb_status snb_reset_timers(snb_handle h) { return guard(h, [&] { h->impl->resetTimers(); }); }
+snb_status snb_set_timing_interval(snb_handle h, int32_t n) { return guard(h, [&] { h->impl->setTimingInterval(n); }); }
 snb_status snb_get_stats(snb_handle h, snb_stats* out) { if (!out) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->getStats(out); }); }
 
 snb_status snb_test_fft3d(int32_t precision, int32_t device, int32_t batch, int32_t nx, int32_t ny, int32_t nz, const double* in, double* spectrum, double* roundtrip) {

@@ -1,6 +1,7 @@
 // misc.hip -- per-step data movement kernels of the engine: positions user order -> sorted posq, forces sorted
 // accumulators -> user order.  Pure HBM streaming (16 B/lane where the layout allows).
 #include "snb_internal.h"
+#include <algorithm>
 
 namespace snb {
 
@@ -93,18 +94,123 @@ void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, int fs, 
     else hipLaunchKernelGGL((k_finishForces<Real, float>), grid, block, 0, s, fx, fy, fz, fs, fpx, fpy, fpz, userToSorted, nAtoms, (float*)out, accumulate);
 }
 
-// Raw slice energies: the kernels of an energy step add into SNB_SLICE_E_PARTS copies of the [S][2] table (chosen by work-group);
-// this sums the copies on the device, as the last kernel of the step, so that an energy / derivative step needs no host
-// synchronisation of its own and can be replayed from a graph -- the host reads the 2 S doubles when the caller asks for them.
-__global__ void k_sumSliceParts(const double* __restrict__ parts, double* __restrict__ out, int n) {
+// ---- effective parameters on the device (the reference: nonbondedParameters.cc computeParameters :4-137, computePlasmaCorrection :139-179) ----
+// One thread per particle: (q, sigma, eps) = base + sum over the particle's offsets of global[k] * delta, in double, then the engine's
+// working form (q ; sigma/2, 2 sqrt(eps)) in user order.  Offsets are CSR by particle.
+template <typename Real>
+__global__ void k_particleParams(int n, const double* __restrict__ base, const int* __restrict__ offStart, const int* __restrict__ offGlobal,
+                                 const double* __restrict__ offDelta, const double* __restrict__ globals, Real* __restrict__ uCharge,
+                                 typename Vec<Real>::T2* __restrict__ uSigEps) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    double q = base[3 * (size_t)u], sg = base[3 * (size_t)u + 1], ep = base[3 * (size_t)u + 2];
+    if (offStart) for (int o = offStart[u]; o < offStart[u + 1]; o++) {
+        const double v = globals[offGlobal[o]];
+        q += v * offDelta[3 * (size_t)o]; sg += v * offDelta[3 * (size_t)o + 1]; ep += v * offDelta[3 * (size_t)o + 2];
+    }
+    uCharge[u] = (Real)q;
+    typename Vec<Real>::T2 se; se.x = (Real)(0.5 * sg); se.y = (Real)(2.0 * sqrt(ep));
+    uSigEps[u] = se;
+}
+// One thread per 1-4 pair: (qq, sigma, eps) = base + offsets -> (sigma, 4 eps, qq / (4 pi eps0), slice)
+template <typename Real>
+__global__ void k_exceptionParams(int n, const double* __restrict__ base, const int* __restrict__ offStart, const int* __restrict__ offGlobal,
+                                  const double* __restrict__ offDelta, const double* __restrict__ globals, const int* __restrict__ slice,
+                                  typename Vec<Real>::T4* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double qq = base[3 * (size_t)k], sg = base[3 * (size_t)k + 1], ep = base[3 * (size_t)k + 2];
+    if (offStart) for (int o = offStart[k]; o < offStart[k + 1]; o++) {
+        const double v = globals[offGlobal[o]];
+        qq += v * offDelta[3 * (size_t)o]; sg += v * offDelta[3 * (size_t)o + 1]; ep += v * offDelta[3 * (size_t)o + 2];
+    }
+    typename Vec<Real>::T4 v; v.x = (Real)sg; v.y = (Real)(4.0 * ep); v.z = (Real)(SNB_ONE_4PI_EPS0 * qq); v.w = (Real)slice[k];
+    out[k] = v;
+}
+// What the closed-form energy terms and the spreader need from the effective parameters AS STORED (rounded to Real): per subset the sums
+// of q, q^2 and c6^2 (self energies, neutralising background: ReferenceSlicedLJCoulombIxn.cpp:203-222), and the largest |q| and |c6|
+// (fixed-point scale of the brick spreader).  sums: [3 nsub] doubles, then two ints holding the maxima as float bit patterns.
+template <typename Real>
+__global__ void k_paramSums(int n, int nsub, const Real* __restrict__ uCharge, const typename Vec<Real>::T2* __restrict__ uSigEps, const int* __restrict__ uSubset,
+                            double* __restrict__ sums) {
+    extern __shared__ double s_sums[];      // [3 nsub]
+    for (int i = threadIdx.x; i < 3 * nsub; i += blockDim.x) s_sums[i] = 0.0;
+    __syncthreads();
+    float mq = 0.f, mc = 0.f;
+    for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+        const double q = (double)uCharge[u], hs = (double)uSigEps[u].x, se = (double)uSigEps[u].y;
+        const double c6 = 8.0 * hs * hs * hs * se;
+        const int sb = uSubset[u];
+        __hip_atomic_fetch_add(&s_sums[3 * sb], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_sums[3 * sb + 1], q * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_sums[3 * sb + 2], c6 * c6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        mq = fmaxf(mq, fabsf((float)q)); mc = fmaxf(mc, fabsf((float)c6));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * nsub; i += blockDim.x) if (s_sums[i] != 0.0) atomicAdd(&sums[i], s_sums[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mq = fmaxf(mq, __shfl_xor(mq, o, 64)); mc = fmaxf(mc, __shfl_xor(mc, o, 64)); }
+    if ((threadIdx.x & 63) == 0) {      // non-negative floats order like their bit patterns
+        int* im = reinterpret_cast<int*>(sums + 3 * nsub);
+        atomicMax(&im[0], __float_as_int(mq)); atomicMax(&im[1], __float_as_int(mc));
+    }
+}
+// fixed point: 16 x the largest per-atom value fits 31 bits (a grid point collects at most a few atoms' weights, each <= 1)
+template <typename Real> __global__ void k_fixScale(const double* __restrict__ sums, int nsub, Real* __restrict__ fix) {
+    if (threadIdx.x < 2) {
+        const int* im = reinterpret_cast<const int*>(sums + 3 * nsub);
+        const double m = fmax((double)__int_as_float(im[threadIdx.x]), 1e-30);
+        const Real sc = (Real)(1073741824.0 / (16.0 * m));
+        fix[2 * threadIdx.x] = sc; fix[2 * threadIdx.x + 1] = (Real)(1.0 / (double)sc);
+    }
+}
+template <typename Real>
+void launchParticleParams(int n, int nsub, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals,
+                          const int* uSubset, Real* uCharge, typename Vec<Real>::T2* uSigEps, double* sums, Real* fix, hipStream_t s) {
+    (void)hipMemsetAsync(sums, 0, sizeof(double) * (3 * (size_t)nsub + 1), s);
+    if (n > 0) {
+        hipLaunchKernelGGL((k_particleParams<Real>), dim3((n + 255) / 256), dim3(256), 0, s, n, base, offStart, offGlobal, offDelta, globals, uCharge, uSigEps);
+        const int nb = std::min((n + 255) / 256, 512);
+        hipLaunchKernelGGL((k_paramSums<Real>), dim3(nb), dim3(256), sizeof(double) * 3 * nsub, s, n, nsub, uCharge, uSigEps, uSubset, sums);
+    }
+    hipLaunchKernelGGL((k_fixScale<Real>), dim3(1), dim3(64), 0, s, sums, nsub, fix);
+}
+template <typename Real>
+void launchExceptionParams(int n, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals, const int* slice,
+                           typename Vec<Real>::T4* out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL((k_exceptionParams<Real>), dim3((n + 255) / 256), dim3(256), 0, s, n, base, offStart, offGlobal, offDelta, globals, slice, out);
+}
+template void launchParticleParams<float>(int, int, const double*, const int*, const int*, const double*, const double*, const int*, float*, Vec<float>::T2*, double*, float*, hipStream_t);
+template void launchParticleParams<double>(int, int, const double*, const int*, const int*, const double*, const double*, const int*, double*, Vec<double>::T2*, double*, double*, hipStream_t);
+template void launchExceptionParams<float>(int, const double*, const int*, const int*, const double*, const double*, const int*, Vec<float>::T4*, hipStream_t);
+template void launchExceptionParams<double>(int, const double*, const int*, const int*, const double*, const double*, const int*, Vec<double>::T4*, hipStream_t);
+
+// Raw slice energies: the kernels of an energy step add into SNB_SLICE_E_PARTS copies of the [S][2] table (chosen by work-group).
+// This last kernel of the step sums the copies and adds the closed-form terms -- self energy and neutralising background
+// (ReferenceSlicedLJCoulombIxn.cpp:203-222) from the per-subset parameter sums k_paramSums keeps on the device, and the long-range
+// dispersion correction coef_s / V (ReferenceNonbondedSlicingKernels.cpp:244-249) -- so that an energy / derivative step needs no
+// host arithmetic and no synchronisation: the host (or the caller's own kernel, snb_slice_energies_device) reads 2 S doubles when
+// it wants them.
+__global__ void k_finishSliceEnergies(const double* __restrict__ parts, double* __restrict__ out, int n, SliceFinish f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double acc = 0;
     for (int part = 0; part < SNB_SLICE_E_PARTS; part++) acc += parts[(size_t)part * n + i];
+    const int slice = i >> 1, term = i & 1;
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= slice) a++;      // slice = a (a + 1) / 2 + b, b <= a
+    const int b = slice - a * (a + 1) / 2;
+    if (f.sums) {
+        if (term == 0) {
+            if (a == b) acc += f.selfCoulomb * f.sums[3 * a + 1];
+            acc += (a == b ? 1.0 : 2.0) * f.sums[3 * a] * f.sums[3 * b] * f.background;
+        } else if (a == b) acc += f.selfDispersion * f.sums[3 * a + 2];
+    }
+    if (term == 1 && f.dispCoef) acc += f.dispCoef[slice] * f.invVolume;
     out[i] = acc;
 }
-void launchSumSliceParts(const double* parts, double* out, int n, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_sumSliceParts, dim3((n + 63) / 64), dim3(64), 0, s, parts, out, n);
+void launchFinishSliceEnergies(const double* parts, double* out, int n, const SliceFinish& f, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_finishSliceEnergies, dim3((n + 63) / 64), dim3(64), 0, s, parts, out, n, f);
 }
 
 template void launchGatherPositions<float>(const void*, int, int, const int*, const float*, Vec<float>::T4*, int, float*, const GatherCells<float>&, hipStream_t);

@@ -153,6 +153,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
     __shared__ int s_count;
     __shared__ int s_rangeBegin[64], s_rangePrefix[65];
     const int tid = threadIdx.x;
+    const Real fixScale = FIXED ? p.fixDev[0] : Real(1), fixInv = FIXED ? p.fixDev[1] : Real(1);
     for (int i = tid; i < npts; i += NT) brick[i] = Acc(0);
     if (tid == 0) s_count = 0;
     const int2* ranges = p.colRange + (size_t)p.gridSubset[slot] * ncol;
@@ -260,7 +261,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
                     int z = (idx[2] & ~1) + 2 * j - z0; if (z >= nz) z -= nz; else if (z < 0) z += nz;
                     zp[j] = z < sz ? z : -1;
                 }
-                const Real wq = wx * p.fixScale;
+                const Real wq = wx * fixScale;
 #pragma unroll
                 for (int iy = 0; iy < 5; iy++) {
                     const int ly = ry + iy;
@@ -314,7 +315,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
         Cx<Real>* tw = B + (size_t)nz * BS;
         for (int k = tid; k < nz; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
         const FastDiv dz(nz), dzc(nzc), dcy2(cy);
-        const Real inv = FIXED ? p.fixInv : Real(1);
+        const Real inv = FIXED ? fixInv : Real(1);
         for (int it = tid; it < nb * nz; it += NT) {
             const int c = dz.div(it), k = it - c * nz;
             const Real a = brickValue((2 * c) * nz + k) * inv;
@@ -341,7 +342,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
     for (int i = tid; i < npts; i += NT) {
         const int l = dsz.div(i), z = i - l * sz;
         const int lx = dcy.div(l), ly = l - lx * cy;
-        g[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z0 + z] = FIXED ? brickValue(i) * p.fixInv : (Real)brick[i];
+        g[((size_t)(x0 + lx) * p.d.ny + (y0 + ly)) * nz + z0 + z] = FIXED ? brickValue(i) * fixInv : (Real)brick[i];
     }
 }
 

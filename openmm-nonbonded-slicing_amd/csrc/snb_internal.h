@@ -103,7 +103,7 @@ template <typename Real> struct PmeParams {
     const typename Vec<Real>::T2* sigeps;
     const int* atomSubset;    // [Npad] sorted
     const int* atomGrid;      // [Npad] grid slot of the atom's subset, or -1 (not owned / padding)
-    Real fixScale, fixInv;    // single-precision brick spreader: LDS accumulation in 32-bit fixed point (value * fixScale)
+    const Real* fixDev;       // single-precision brick spreader: LDS accumulation in 32-bit fixed point: [0] scale, [1] its inverse (device: follows the parameters)
     long long* trace;         // SNB_PME_TRACE: [0] summed load ticks, [1] summed compute ticks, [2] work-groups (interpolation bricks; 100 MHz ticks)
     int cellsReady;           // cells[] already hold this mesh's cells (written by the position-gather pass)
     int* cells;               // [Npad] scratch: packed mesh cell per atom (k_pmeCells), brick spreader only
@@ -219,7 +219,22 @@ template <typename Real> void launchRefreshParams(const int* sortedToUser, const
 template <typename Real> void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, int fs, const Real* fpx, const Real* fpy, const Real* fpz,
                                                  const int* userToSorted, int nAtoms, void* out, int isDouble, int accumulate, hipStream_t s);
 
-void launchSumSliceParts(const double* parts, double* out, int n, hipStream_t s);
+// closed-form terms of the raw slice energies (k_finishSliceEnergies); a null pointer / zero factor switches a term off
+struct SliceFinish {
+    const double* sums;       // [3 nsub] per-subset sum q, sum q^2, sum c6^2 (k_paramSums), or null
+    const double* dispCoef;   // [S] dispersion-correction coefficients, or null
+    double selfCoulomb;       // -ONE_4PI_EPS0 alpha / sqrt(pi)          (x sum q^2, diagonal slices)
+    double selfDispersion;    // alpha_d^6 / 12                           (x sum c6^2, LJPME)
+    double background;        // -1 / (4 alpha^2) / (2 eps0 V)            (x Q_a Q_b, x 2 off the diagonal)
+    double invVolume;         // 1 / V                                    (x dispersion coefficient)
+};
+void launchFinishSliceEnergies(const double* parts, double* out, int n, const SliceFinish& f, hipStream_t s);
+template <typename Real>
+void launchParticleParams(int n, int nsub, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals,
+                          const int* uSubset, Real* uCharge, typename Vec<Real>::T2* uSigEps, double* sums, Real* fix, hipStream_t s);
+template <typename Real>
+void launchExceptionParams(int n, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals, const int* slice,
+                           typename Vec<Real>::T4* out, hipStream_t s);
 
 int legalGridSize(int n);
 bool factorize(int n, int* factors, int* nfactors);

@@ -614,3 +614,91 @@ def test_sharded_engines_sum_to_unsharded(world, snb, oev):
         # sharded single-precision energies come from real-space interpolation of float potentials (not the k-space Gram sum):
         # raw slice energies are small differences of large sums, so allow 3e-3 there (forces keep the 1e-3 bar)
         assert ferr < tol and eerr < (3e-3 if prec == "single" else tol), (prec, world, ferr, eerr)
+
+
+def test_parameter_offsets_follow_global_parameters_on_the_device(snb, F, oev, prec):
+    """Parameter offsets (SlicedNonbondedForce::addParticleParameterOffset / addExceptionParameterOffset) are applied on the device
+    (snb_set_parameter_offsets + snb_set_global_parameters; the reference: platforms/common/src/kernels/nonbondedParameters.cc:4-179):
+    Context::setParameter between evaluations -- energy steps and replayed forces-only steps -- must give the oracle's answer for the
+    new effective charges / sigmas / epsilons / 1-4 parameters WITHOUT a neighbour rebuild.  An exception whose base parameters are all
+    zero but which carries an offset is a 1-4 interaction (Q6)."""
+    n, L = 13824, 6.0
+    force, pos, box = systems.random_box(F, n, 3, 4, L, 1.0, pme=(2.6283, 48, 48, 48))
+    force.addGlobalParameter("dq", 0.0); force.addGlobalParameter("dlj", 0.0)
+    rng = np.random.default_rng(5)
+    for i in rng.choice(n, 900, replace=False):
+        force.addParticleParameterOffset("dq", int(i), float(rng.uniform(-0.4, 0.4)), 0.0, 0.0)
+    for i in rng.choice(n, 700, replace=False):
+        force.addParticleParameterOffset("dlj", int(i), 0.0, float(rng.uniform(-0.03, 0.03)), float(rng.uniform(0.0, 0.5)))
+    zero_base = None
+    for k in range(0, force.getNumExceptions(), 7):
+        a, b, qq, sg, ep = force.getExceptionParameters(k)
+        if qq == 0.0 and ep == 0.0 and zero_base is None:
+            zero_base = k
+            force.addExceptionParameterOffset("dq", k, 0.05, 0.3, 0.2)          # excluded pair that becomes a 1-4 when dq != 0
+        elif qq != 0.0:
+            force.addExceptionParameterOffset("dlj", k, 0.3 * qq, 0.01, 0.1)
+    assert zero_base is not None
+    system = snb.System()
+    for _ in range(n):
+        system.addParticle(1.0)
+    system.setDefaultPeriodicBoxVectors(*box)
+    system.addForce(force)
+    ctx = snb.Context(system, precision=prec, neighbor_padding=0.1, rebuild_interval=1000)
+    ctx.setPositions(pos)
+    kern = ctx._kernelFor(force)
+    tol = TOLS[prec]
+    for step, (dq, dlj) in enumerate([(0.0, 0.0), (1.0, 0.0), (1.0, 1.0), (-0.5, 0.4), (0.25, 0.4)]):
+        ctx.setParameter("dq", dq); ctx.setParameter("dlj", dlj)
+        o = oev(force, pos, box, dict(ctx.getParameters()))
+        if step % 2 == 0:
+            st = ctx.getState(getEnergy=True, getForces=True, getParameterDerivatives=True)
+            K.assertEqualTo(o["energy"], st.getPotentialEnergy(), tol)
+            for name, v in o["derivatives"].items():
+                K.assertEqualTo(v, st.getEnergyParameterDerivatives()[name], tol)
+        else:
+            st = ctx.getState(getForces=True)
+        fo, fr = o["forces"], st.getForces()
+        err = np.linalg.norm(fo - fr, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)
+        assert err.max() <= tol, "step %d: max force error %g" % (step, err.max())
+    assert kern.getStats().n_rebuilds == 1, "global-parameter changes must not rebuild the neighbour structure"
+
+
+def test_changing_subsets_through_update_parameters(snb, F, oev, prec):
+    """updateParametersInContext after setParticleSubset: atoms move between subsets, so every per-slice quantity changes -- block
+    layout, tile slices, the slice of every 1-4 exception.  (The reference's GPU path attributes every 1-4 exception to slice 0 after
+    an update, CommonNonbondedSlicingKernels.cpp:1511 vs :741-743 -- SURVEY Appendix D2, invisible in its own tests, which update
+    with n = 1; here the slices are recomputed from the current subsets and the partner is the oracle on the updated force.)"""
+    n, L = 13824, 6.0
+    force, pos, box = systems.random_box(F, n, 3, 4, L, 1.0, pme=(2.6283, 48, 48, 48))
+    system = snb.System()
+    for _ in range(n):
+        system.addParticle(1.0)
+    system.setDefaultPeriodicBoxVectors(*box)
+    system.addForce(force)
+    ctx = snb.Context(system, precision=prec, neighbor_padding=0.1, rebuild_interval=1000)
+    ctx.setPositions(pos)
+    tol = TOLS[prec]
+
+    def check():
+        st = ctx.getState(getEnergy=True, getForces=True, getParameterDerivatives=True)
+        o = oev(force, pos, box, dict(ctx.getParameters()))
+        K.assertEqualTo(o["energy"], st.getPotentialEnergy(), tol)
+        kern = ctx._kernelFor(force)
+        for s in range(o["slice_energies"].shape[0]):
+            for t in range(2):
+                K.assertEqualTo(o["slice_energies"][s, t], kern.lastSliceEnergies[s, t], tol)
+        fo, fr = o["forces"], st.getForces()
+        err = np.linalg.norm(fo - fr, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)
+        assert err.max() <= tol, err.max()
+
+    check()
+    rng = np.random.default_rng(17)
+    d = np.asarray(pos) - 0.5 * L
+    inner = np.linalg.norm(d, axis=1) < 1.6                      # a sphere in the middle of the slab layout goes to subset 2 ...
+    for i in np.where(inner)[0]:
+        force.setParticleSubset(int(i), 2)
+    for i in rng.choice(n, 300, replace=False):                 # ... and scattered atoms (whole exception chains cross slices) to subset 1
+        force.setParticleSubset(int(i), 1)
+    force.updateParametersInContext(ctx)
+    check()
