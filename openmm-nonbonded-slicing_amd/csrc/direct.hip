@@ -19,11 +19,21 @@
 #include <cstring>
 #include <type_traits>
 
+#ifndef SNB_DIRECT_F64_WAVES
+#define SNB_DIRECT_F64_WAVES 2      // waves per SIMD the double-precision pair kernel is compiled for (256 VGPRs: no spills; measured on c5)
+#endif
 namespace snb {
 
 // ---- math helpers -------------------------------------------------------------------------------
 __device__ inline float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ inline double rsq(double x) { return 1.0 / sqrt(x); }
+// double: the hardware estimate (v_rsq_f64, ~2^-27) refined by two Newton steps -- about a third of the instructions of 1.0 / sqrt(x),
+// which runs its own refinements for the square root and again for the division; relative error < 1e-15 (tests hold 1e-12 on forces)
+__device__ inline double rsq(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
 __device__ inline float fexp(float x) { return __expf(x); }
 __device__ inline double fexp(double x) { return exp(x); }
 // erfc(ar) given e = exp(-ar^2).  Single precision: Abramowitz & Stegun 7.1.26 (max abs error 1.5e-7), the
@@ -111,7 +121,17 @@ __device__ __forceinline__ void tileSteps(const DirectParams<Real>& p, const typ
                 const Real es6 = epsiS * sj2.y * s6;
                 fLJ = es6 * (Real(12) * s6 - Real(6));
             }
-            if (MC == MC_LJPME) {
+            if (MC == MC_LJPME && !ENERGY && std::is_same<Real, double>::value) {
+                // forces only, double: 6 c6 [1 - e^{-x}(1 + x + x^2/2 + x^3/6)] / r^6 = 6 c6 r^2 Gd(r^2), x = (alpha_d r)^2, with
+                // Gd(r^2) = alpha_d^8 e^{-x} sum_k x^k / (k+4)!  an entire function of r^2: a degree-20 polynomial in the same t as the
+                // Ewald factor (~1e-13) instead of a double-precision exp and its pre-factors (engine.hip buildEwaldPoly)
+                const Real t = r2 * p.ewScale - Real(1);
+                Real gd = p.dispPoly[20];
+#pragma unroll
+                for (int k = 19; k >= 0; k--) gd = gd * t + p.dispPoly[k];
+                const Real c6 = c6i * (Real(8) * sj2.x * sj2.x * sj2.x * sj2.y);
+                fLJ += Real(6) * c6 * gd * r2 * lamL;
+            } else if (MC == MC_LJPME) {
                 // multiplicative grid term + potential shifts (:398-426)
                 const Real dar2 = p.alphaD * p.alphaD * r2;
                 const Real dar4 = dar2 * dar2, dar6 = dar4 * dar2;
@@ -188,7 +208,7 @@ __device__ inline float rowRor8(float v) { return __builtin_bit_cast(float, __bu
 // so after 16 steps lane c holds the force on j-slot c.  j-atom data is read from LDS (staged once per tile, each
 // 16-atom half stored twice so the rotated index c+16-s needs no wrap).
 template <typename Real, int MC, bool WRAP, bool ENERGY>
-__global__ __launch_bounds__(256, 4) void k_direct(const DirectParams<Real> p) {
+__global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)) void k_direct(const DirectParams<Real> p) {
     double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
     using T4 = typename Vec<Real>::T4;
     using T2 = typename Vec<Real>::T2;

@@ -337,7 +337,7 @@ public:
     // (12 packed FMAs replace v_exp + v_rcp + the A&S erfc polynomial), degree 20 to ~1e-13 in double (replaces libm erfc + exp).  Absolute force error per pair stays below that of the A&S path at short range and
     // below 2e-6 * qq near the cutoff (tools/ewald_poly_check.py).
     static constexpr int EW_DEG = sizeof(Real) == 4 ? 11 : 20;      // 1e-7 resp. ~1e-13 of Bt(0)
-    double ewPoly[EW_DEG + 1] = {0}; double ewPolyE[14] = {0}; double ewR2Max = 1;
+    double ewPoly[EW_DEG + 1] = {0}; double ewPolyE[14] = {0}; double dispPoly[21] = {0}; double ewR2Max = 1;
     void buildEwaldPoly() {
         const double rmax = cfg.cutoff + std::max(cfg.neighbor_padding, 0.0) + 0.02, a = cfg.alpha;
         ewR2Max = rmax * rmax;
@@ -354,6 +354,16 @@ public:
             return std::erf(z) / r;
         };
         chebyshevToMonomial(et, 13, ewPolyE);
+        if (cfg.method == SNB_LJPME) {      // dispersion force factor of the double-precision pair kernel
+            const double ad = cfg.alpha_d;
+            auto gd = [&](double r2) {
+                const double x = ad * ad * r2;
+                double sum = 0, term = 1.0 / 24.0;      // sum_k x^k / (k+4)!
+                for (int k = 0; k < 60; k++) { sum += term; term *= x / (k + 5); if (term < 1e-18 * sum) break; }
+                return std::pow(ad, 8.0) * std::exp(-x) * sum;
+            };
+            chebyshevToMonomial(gd, 20, dispPoly);
+        }
     }
     // Chebyshev interpolant of f(r^2) over [0, ewR2Max] at 96 nodes, truncated at `deg`, as monomial coefficients in t = 2 r^2/ewR2Max - 1
     template <typename Fn> void chebyshevToMonomial(Fn f, int deg, double* out) {
@@ -1267,6 +1277,7 @@ public:
             p.alpha2l2e = (Real)(cfg.alpha * cfg.alpha * 1.4426950408889634);
             for (int i = 0; i <= EW_DEG; i++) p.ewPoly[i] = (Real)ewPoly[i];
             for (int i = 0; i < 14; i++) p.ewPolyE[i] = (Real)ewPolyE[i];
+            for (int i = 0; i < 21; i++) p.dispPoly[i] = (Real)dispPoly[i];
             p.ewScale = (Real)(2.0 / ewR2Max);
             { static const bool noPoly = getenv("SNB_EWALD_ERFC") != nullptr; p.ewUsePoly = noPoly ? 0 : 1; }
             const double ic2 = 1.0 / (cfg.cutoff * cfg.cutoff), ic6 = ic2 * ic2 * ic2;

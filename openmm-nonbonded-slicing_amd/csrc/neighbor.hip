@@ -539,16 +539,29 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
                 const auto q = p.posq[e & SNB_JIDX_MASK];
                 px = (float)q.x + kx * Lt.ax + ky * Lt.bx + kz * Lt.cx; py = (float)q.y + ky * Lt.by + kz * Lt.cy; pz = (float)q.z + kz * Lt.cz;
             }
-            float best[4] = {3e38f, 3e38f, 3e38f, 3e38f};      // per octet of the block (atoms 8 g .. 8 g + 7 = pairs 4 g .. 4 g + 3)
             typedef float v2f __attribute__((ext_vector_type(2)));
+            int sgv;
+            if (p.orderBlocks) {      // (uniform) sub-tile experiment: which octets of the block the atom reaches
+                float best[4] = {3e38f, 3e38f, 3e38f, 3e38f};      // per octet of the block (atoms 8 g .. 8 g + 7 = pairs 4 g .. 4 g + 3)
 #pragma unroll
-            for (int a = 0; a < 16; a++) {                // two i-atoms per pass (packed fp32), LDS broadcast reads
-                const float4 xy = ipos[a]; const float2 zz = iposZ[a];
-                const v2f ddx = v2f{xy.x, xy.y} - px, ddy = v2f{xy.z, xy.w} - py, ddz = v2f{zz.x, zz.y} - pz;
-                const v2f d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-                best[a >> 2] = fminf(best[a >> 2], fminf(d2.x, d2.y));
+                for (int a = 0; a < 16; a++) {                // two i-atoms per pass (packed fp32), LDS broadcast reads
+                    const float4 xy = ipos[a]; const float2 zz = iposZ[a];
+                    const v2f ddx = v2f{xy.x, xy.y} - px, ddy = v2f{xy.z, xy.w} - py, ddz = v2f{zz.x, zz.y} - pz;
+                    const v2f d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                    best[a >> 2] = fminf(best[a >> 2], fminf(d2.x, d2.y));
+                }
+                sgv = (best[0] < R2 ? 1 : 0) | (best[1] < R2 ? 2 : 0) | (best[2] < R2 ? 4 : 0) | (best[3] < R2 ? 8 : 0);
+            } else {
+                float best = 3e38f;
+#pragma unroll 8
+                for (int a = 0; a < 16; a++) {
+                    const float4 xy = ipos[a]; const float2 zz = iposZ[a];
+                    const v2f ddx = v2f{xy.x, xy.y} - px, ddy = v2f{xy.z, xy.w} - py, ddz = v2f{zz.x, zz.y} - pz;
+                    const v2f d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                    best = fminf(best, fminf(d2.x, d2.y));
+                }
+                sgv = best < R2 ? 0xF : 0;
             }
-            const int sgv = (best[0] < R2 ? 1 : 0) | (best[1] < R2 ? 2 : 0) | (best[2] < R2 ? 4 : 0) | (best[3] < R2 ? 8 : 0);
             keep = keep && sgv != 0;
             __builtin_amdgcn_wave_barrier();             // every lane has read its entry before the slots below it are rewritten
             const unsigned long long m = __ballot(keep);

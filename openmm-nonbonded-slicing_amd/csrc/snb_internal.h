@@ -57,6 +57,7 @@ template <typename Real> struct DirectParams {
     int nsub;
     Real cutoff2, krf, crf, alpha, alphaD, k4pe;          // k4pe = ONE_4PI_EPS0
     Real alpha2l2e;                                        // alpha^2 * log2(e)
+    Real dispPoly[21];                                     // LJPME, double, forces only: alpha_d^8 e^{-x} sum x^k/(k+4)!, x = (alpha_d r)^2, degree 20 in the same t
     Real ewPolyE[14];                                      // energy steps of the packed kernel: erf(alpha r)/r ~ sum_k ewPolyE[k] t^k (degree 13, same t)
     Real ewPoly[21]; Real ewScale; int ewUsePoly;         // forces-only paths: Bt(r^2) ~ sum_k ewPoly[k] t^k, t = r^2 * ewScale - 1; degree 11 (float) / 20 (double), engine.hip buildEwaldPoly
     Real invCut6, multShift6;                              // LJPME potential shifts
