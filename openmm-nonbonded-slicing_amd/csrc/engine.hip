@@ -1259,7 +1259,7 @@ public:
             q.pairs = pairs14.p; q.params = params14.p; q.n = n14;
             q.nExclAtoms = (ew && nExcl > 0) ? Npad : 0;
         }
-        bool listsDone = !haveLists, kernelTimed = false;
+        bool listsDone = !haveLists, kernelTimed = false, finished = false;
         if (includeDirect) {
             DirectParams<Real> p;
             std::memset(&p, 0, sizeof(p));
@@ -1303,14 +1303,22 @@ public:
             if (nGrids > 0) {
                 PmeParams<Real> pp;
                 std::memset(&pp, 0, sizeof(pp));
-                fillPme(pp, pme, energy);
-                runPme(pp, pmeStream);
-                if (cfg.method == SNB_LJPME) { fillPme(pp, dpme, energy); runPme(pp, pmeStream); }
+                // the interpolation of the step's last mesh also writes the user-order force (no k_finishForces launch): unsharded, brick path,
+                // reciprocal work on the step's own stream (the pair kernel's accumulators are complete by then)
+                static const bool noFuse = getenv("SNB_NO_FUSED_FINISH") != nullptr;
+                const bool canFinish = outPtr && !fork && !noFuse && cfg.shard_count == 1;
+                auto withOutput = [&](PmeParams<Real>& q, bool last) {
+                    q.outForces = (canFinish && last) ? outPtr : nullptr; q.outIsDouble = outIsDouble; q.outAccumulate = outAccumulate;
+                    q.dfx = fx.p; q.dfy = fy.p; q.dfz = fz.p; q.dfs = fstride; q.sortedToUser = dSortedToUser.p;
+                };
+                fillPme(pp, pme, energy); withOutput(pp, cfg.method != SNB_LJPME);
+                finished = runPme(pp, pmeStream);
+                if (cfg.method == SNB_LJPME) { fillPme(pp, dpme, energy); withOutput(pp, true); finished = runPme(pp, pmeStream); }
             }
         }
         if (fork) { HIPCHECK(hipEventRecord(evJoin, stream2)); HIPCHECK(hipStreamWaitEvent(stream, evJoin, 0)); }
         if (includeRecip && cfg.method == SNB_Ewald && cfg.shard_rank == 0) runEwald(energy);
-        if (outPtr) {   // the step's last kernel: user-order forces into the caller's buffer (part of the graph)
+        if (outPtr && !finished) {   // the step's last kernel: user-order forces into the caller's buffer (part of the graph)
             const bool recipDone = includeRecip && (isPme() || cfg.method == SNB_Ewald);
             launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, recipDone ? fpx.p : nullptr, fpy.p, fpz.p, dUserToSorted.p, N, outPtr, outIsDouble, outAccumulate, stream);
         }
@@ -1368,12 +1376,12 @@ public:
     // (also restarts the eager-step cadence: the first step after a reset is a timed one, so even a short measured region has a sample)
     void resetTimers() override { for (auto& r : ring) if (r.pending) harvest(r); stats.sum_direct_ms = stats.sum_recip_ms = stats.sum_total_ms = 0; stats.n_timed = 0; execCount = 0; }
 
-    void runPme(PmeParams<Real>& pp, hipStream_t st) {
+    bool runPme(PmeParams<Real>& pp, hipStream_t st) {      // true: its interpolation kernel delivered the user-order forces (pp.outForces)
         const bool zDone = launchPmeSpread<Real>(pp, st);
         launchPmeForwardFFT<Real>(pp, st, zDone);
         launchPmeConvolution<Real>(pp, st);
         launchPmeInverseFFT<Real>(pp, st);
-        launchPmeInterpolate<Real>(pp, st);
+        return launchPmeInterpolate<Real>(pp, st);
     }
 
     void setForceOutput(void* out, int isDouble, int accumulate) override { outPtr = out; outIsDouble = isDouble; outAccumulate = accumulate; outputWritten = false; }

@@ -328,13 +328,13 @@ template <typename Real> __device__ inline int runLowerBound(const NbParams<Real
     return lo;
 }
 
-template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(const NbParams<Real> p) {
+template <typename Real, bool SUB> __global__ __launch_bounds__(256) void k_nbBuildTiles(const NbParams<Real> p) {      // SUB: octet signatures / signature order / sub-tile occupancies (SNB_SUBTILES experiment)
     __shared__ int s_list[4][NB_CAP];
     __shared__ unsigned s_mask[4][NB_MAXT][32];
     __shared__ int s_tileSub[4][NB_MAXT];
-    __shared__ unsigned char s_sig[4][NB_CAP];      // per gathered entry: which of the block's four octets it reaches within R (bit g)
-    __shared__ unsigned char s_tileSm[4][NB_MAXT];  // per tile: occupancy of its 8 sub-tiles, bit 4 h + g = (j-half h, i-octet g)
-    __shared__ int s_hist[4][16];
+    __shared__ unsigned char s_sig[4][SUB ? NB_CAP : 4];      // (LDS decides how many work-groups share a CU: the default build carries none of this)      // per gathered entry: which of the block's four octets it reaches within R (bit g)
+    __shared__ unsigned char s_tileSm[4][SUB ? NB_MAXT : 4];  // per tile: occupancy of its 8 sub-tiles, bit 4 h + g = (j-half h, i-octet g)
+    __shared__ int s_hist[4][SUB ? 16 : 1];
     __shared__ int s_query[4][128];      // exclusion partners (sorted index) still to be located in the gathered list
     __shared__ int s_qrow[4][128];       // ... and the i-row each belongs to
     __shared__ int s_imgI[4][27][5]; __shared__ float s_imgF[4][27][2];      // surviving lattice images of the block (see below)
@@ -455,7 +455,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
             if (t < nT && ((anyBits >> t) & 1ull)) p.masks[(size_t)(mi0 + __popcll(anyBits & ((1ull << t) - 1ull))) * 32 + il] = mask[t][il];
         }
         // sub-tile occupancy of every tile: OR of the entries' octet signatures over each 16-entry half
-        for (int t2 = 0; t2 < nT; t2 += 2) {
+        if constexpr (SUB) for (int t2 = 0; t2 < nT; t2 += 2) {
             const int t = t2 + half;
             int x = (t < nT) ? (int)sig[t * 32 + il] : 0;
 #pragma unroll
@@ -467,7 +467,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         __builtin_amdgcn_wave_barrier();
         const int subIb = p.blockSubset[I];
         // tileInfo.x = slice | sub-tile occupancy << 16
-        for (int t = lane; t < nT; t += 64) p.tileInfo[first + t] = make_int4(nbSliceOf(subIb, tileSub[t]) | ((int)tileSm[t] << 16), ((anyBits >> t) & 1ull) ? mi0 + __popcll(anyBits & ((1ull << t) - 1ull)) : -1, tileSub[t], 0);
+        for (int t = lane; t < nT; t += 64) p.tileInfo[first + t] = make_int4(nbSliceOf(subIb, tileSub[t]) | (SUB ? ((int)tileSm[t] << 16) : 0), ((anyBits >> t) & 1ull) ? mi0 + __popcll(anyBits & ((1ull << t) - 1ull)) : -1, tileSub[t], 0);
         const int subI = p.blockSubset[I];      // carried in the work item: the pair kernel needs it before the block's atoms arrive
         for (int k = lane; k < nFull; k += 64) p.workItemsStage[w0 + k] = make_int4(I, first + CH * k, CH, subI);
         if (nPart && lane == 0) p.workItemsPartial[wp] = make_int4(I, first + CH * nFull, nT % CH, subI);
@@ -476,7 +476,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
 
     const long long tProlog = p.dbgOut ? (long long)wall_clock64() : 0;
     // diagonal tile
-    if (lane < 32) { list[lane] = (uI >= 0) ? ((I * 32 + lane) | (SNB_JCODE_CENTER << SNB_JSHIFT_BITS)) : -1; sig[lane] = 0xF; }
+    if (lane < 32) { list[lane] = (uI >= 0) ? ((I * 32 + lane) | (SNB_JCODE_CENTER << SNB_JSHIFT_BITS)) : -1; if constexpr (SUB) sig[lane] = 0xF; }
     if (lane == 0) tileSub[0] = p.blockSubset[I];
     int count = 32;
     bool hasDiag = true;
@@ -541,7 +541,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
             }
             typedef float v2f __attribute__((ext_vector_type(2)));
             int sgv;
-            if (p.orderBlocks) {      // (uniform) sub-tile experiment: which octets of the block the atom reaches
+            if constexpr (SUB) {      // sub-tile experiment: which octets of the block the atom reaches
                 float best[4] = {3e38f, 3e38f, 3e38f, 3e38f};      // per octet of the block (atoms 8 g .. 8 g + 7 = pairs 4 g .. 4 g + 3)
 #pragma unroll
                 for (int a = 0; a < 16; a++) {                // two i-atoms per pass (packed fp32), LDS broadcast reads
@@ -565,7 +565,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
             keep = keep && sgv != 0;
             __builtin_amdgcn_wave_barrier();             // every lane has read its entry before the slots below it are rewritten
             const unsigned long long m = __ballot(keep);
-            if (keep) { const int o = out + lanePrefix(m); list[o] = e; sig[o] = (unsigned char)sgv; }
+            if (keep) { const int o = out + lanePrefix(m); list[o] = e; if constexpr (SUB) sig[o] = (unsigned char)sgv; }
             out += __popcll(m);
         }
         count = out; filtered = out;
@@ -624,12 +624,12 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
                 if (count + nNew > NB_CAP - 32) {
                     // list full: close the current segment, publish this chunk and start a fresh list
                     const int padded = (count + 31) & ~31;
-                    for (int k = count + lane; k < padded; k += 64) { list[k] = -1; sig[k] = 0; }
+                    for (int k = count + lane; k < padded; k += 64) { list[k] = -1; if constexpr (SUB) sig[k] = 0; }
                     for (int t = (segStart >> 5) + lane; t < (padded >> 5); t += 64) tileSub[t] = s;
                     flush(padded, hasDiag);
                     hasDiag = false; count = 0; segStart = 0; filtered = 0;
                 }
-                if (ok) { const int o = count + lanePrefix(m); list[o] = j | (code << SNB_JSHIFT_BITS); sig[o] = 0xF; }      // (the exact filter narrows the signature)
+                if (ok) { const int o = count + lanePrefix(m); list[o] = j | (code << SNB_JSHIFT_BITS); if constexpr (SUB) sig[o] = 0xF; }      // (the exact filter narrows the signature)
                 count += nNew;
             }
             __builtin_amdgcn_wave_barrier();
@@ -668,7 +668,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         // Order the segment's entries by signature (counting sort, 16 bins): entries that reach the same octets end up in the same
         // 16-entry halves, so that whole (octet, half) sub-tiles come out empty -- 28 % of them on the bulk-water workload
         // (tools/sim_fill2.py) -- and the pair kernel skips them.
-        if (exact && !failed && (p.orderBlocks & 2) && count - segStart > 16) {
+        if (SUB && exact && !failed && (p.orderBlocks & 2) && count - segStart > 16) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (lane < 16) hist[lane] = 0;
@@ -712,7 +712,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
         }
         // close the subset segment: pad to a whole tile, record the tiles' subset
         const int padded = (count + 31) & ~31;
-        for (int k = count + lane; k < padded; k += 64) { list[k] = -1; sig[k] = 0; }
+        for (int k = count + lane; k < padded; k += 64) { list[k] = -1; if constexpr (SUB) sig[k] = 0; }
         for (int t = (segStart >> 5) + lane; t < (padded >> 5); t += 64) tileSub[t] = s;
         count = padded; filtered = padded;
     }
@@ -807,7 +807,10 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipSt
         hipLaunchKernelGGL((k_nbZPrefix<Real>), dim3((p.nSubsets * p.ncx * p.ncy + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbBounds<Real>), dim3((p.nBlocks + 7) / 8), block, 0, s, p);
         const int nOwned = (p.nBlocks / p.shardPeriod) * p.shardWidth + std::min(std::max(p.nBlocks % p.shardPeriod - p.shardBegin, 0), p.shardWidth);
-        if (nOwned > 0) hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((nOwned + 3) / 4), block, 0, s, p);
+        if (nOwned > 0) {
+            if (p.orderBlocks) hipLaunchKernelGGL((k_nbBuildTiles<Real, true>), dim3((nOwned + 3) / 4), block, 0, s, p);
+            else hipLaunchKernelGGL((k_nbBuildTiles<Real, false>), dim3((nOwned + 3) / 4), block, 0, s, p);
+        }
         hipLaunchKernelGGL((k_nbCompactWork<Real>), dim3(2 * NB_PARTS), block, 0, s, p);
     }
 }

@@ -1174,7 +1174,23 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
                     const int a = s_begin[r] + (v - s_pref[r]);
                     const int si = p.atomSubset[a];
                     const Real q = si >= 0 ? pmeCharge(p, a) : Real(0);
-                    if (q == Real(0)) continue;                // padding slots inside a run, uncharged atoms
+                    // the step's user-order force of this atom (fused k_finishForces): direct-space accumulator + reciprocal force
+                    auto deliver = [&](Real rx_, Real ry_, Real rz_) {
+                        const int u = p.sortedToUser[a];
+                        if (u < 0) return;
+                        const Real X = p.dfx[(size_t)a * p.dfs] + rx_, Y = p.dfy[(size_t)a * p.dfs] + ry_, Z = p.dfz[(size_t)a * p.dfs] + rz_;
+                        if (p.outIsDouble) {
+                            double* o = reinterpret_cast<double*>(p.outForces) + 3 * (size_t)u;
+                            if (p.outAccumulate) { o[0] += (double)X; o[1] += (double)Y; o[2] += (double)Z; } else { o[0] = (double)X; o[1] = (double)Y; o[2] = (double)Z; }
+                        } else {
+                            float* o = reinterpret_cast<float*>(p.outForces) + 3 * (size_t)u;
+                            if (p.outAccumulate) { o[0] += (float)X; o[1] += (float)Y; o[2] += (float)Z; } else { o[0] = (float)X; o[1] = (float)Y; o[2] = (float)Z; }
+                        }
+                    };
+                    if (q == Real(0)) {                        // padding slots inside a run, uncharged atoms
+                        if (p.outForces && si >= 0 && (zSlabs == 1 || zs == 0)) deliver(p.fpx[a], p.fpy[a], p.fpz[a]);
+                        continue;
+                    }
                     const int slice = si > gj ? si * (si + 1) / 2 + gj : gj * (gj + 1) / 2 + si;
                     const Real lam = p.mix ? Real(1) : p.lambdas[2 * slice + term];
                     const auto pos = p.posq[a];
@@ -1224,9 +1240,11 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
                     }
                     const Real nx = p.d.nx, ny = p.d.ny, nzr = p.d.nz;
                     const Real ql = -q * lam;
-                    p.fpx[a] += ql * (fx * nx * p.recip[0]);
-                    p.fpy[a] += ql * (fx * nx * p.recip[3] + fy * ny * p.recip[4]);
-                    p.fpz[a] += ql * (fx * nx * p.recip[6] + fy * ny * p.recip[7] + fz * nzr * p.recip[8]);
+                    const Real gx = p.fpx[a] + ql * (fx * nx * p.recip[0]);
+                    const Real gy = p.fpy[a] + ql * (fx * nx * p.recip[3] + fy * ny * p.recip[4]);
+                    const Real gz = p.fpz[a] + ql * (fx * nx * p.recip[6] + fy * ny * p.recip[7] + fz * nzr * p.recip[8]);
+                    if (p.outForces) deliver(gx, gy, gz);
+                    else { p.fpx[a] = gx; p.fpy[a] = gy; p.fpz[a] = gz; }
                     if (wantE) __hip_atomic_fetch_add(&sE[2 * slice + term], 0.5 * (double)q * (double)psi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -1240,7 +1258,8 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
     }
 }
 
-template <typename Real> static void launchInterpolateBricks(const PmeParams<Real>& p, hipStream_t s) {
+template <typename Real> static bool launchInterpolateBricks(const PmeParams<Real>& p0, hipStream_t s) {
+    PmeParams<Real> p = p0;
     {
         const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
         static const int zsEnv = getenv("SNB_INTERP_ZSLABS") ? atoi(getenv("SNB_INTERP_ZSLABS")) : 0;
@@ -1252,16 +1271,18 @@ template <typename Real> static void launchInterpolateBricks(const PmeParams<Rea
         if (lds <= 150 * 1024 && !noBrick && p.nsubTotal * p.groupX * p.groupY <= 256) {
             const int nblocks = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * zSlabs;
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBricks<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (!p.mix) p.outForces = nullptr;      // (sharded engines visit an atom once per held grid: the separate finish pass stays)
             hipLaunchKernelGGL((k_interpolateBricks<Real>), dim3(nblocks), dim3(1024), lds, s, p, zSlabs);
-            return;
+            return p.outForces != nullptr;
         }
     }
     const size_t lds = (!p.mix && p.wantEnergy) ? sizeof(double) * p.nsubTotal * (p.nsubTotal + 1) : 0;
     hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
+    return false;
 }
 
-template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s) {
-    if (p.natoms <= 0) return;
+template <typename Real> bool launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s) {
+    if (p.natoms <= 0) return false;
     if (p.sortNcx > 0 && p.colRange != nullptr) {
         // The kernel needs ~100 VGPRs, so one 1024-thread work-group occupies a CU: with more bricks than CUs the launch runs in rounds.
         // Wider bricks (2 x 1, 2 x 2 columns) cut the count below the CU count and the halo overhead with it, as long as LDS allows.
@@ -1280,6 +1301,7 @@ template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hip
     }
     const size_t lds = (!p.mix && p.wantEnergy) ? sizeof(double) * p.nsubTotal * (p.nsubTotal + 1) : 0;
     hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
+    return false;
 }
 
 template bool launchPmeSpread<float>(const PmeParams<float>&, hipStream_t);
@@ -1290,8 +1312,8 @@ template void launchPmeConvolution<float>(const PmeParams<float>&, hipStream_t);
 template void launchPmeConvolution<double>(const PmeParams<double>&, hipStream_t);
 template void launchPmeInverseFFT<float>(const PmeParams<float>&, hipStream_t);
 template void launchPmeInverseFFT<double>(const PmeParams<double>&, hipStream_t);
-template void launchPmeInterpolate<float>(const PmeParams<float>&, hipStream_t);
-template void launchPmeInterpolate<double>(const PmeParams<double>&, hipStream_t);
+template bool launchPmeInterpolate<float>(const PmeParams<float>&, hipStream_t);
+template bool launchPmeInterpolate<double>(const PmeParams<double>&, hipStream_t);
 
 // ---- host helpers ---------------------------------------------------------------------------------
 bool factorize(int n, int* factors, int* nf) {

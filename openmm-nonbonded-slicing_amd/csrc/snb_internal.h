@@ -126,6 +126,11 @@ template <typename Real> struct PmeParams {
     int groupX, groupY;        // sort columns per brick (brick = group * nx/sortNcx cells, at least 5)
     int zSlabs;                // bricks are also cut into this many slabs along z (nz % zSlabs == 0)
     const int2* colRange;      // [nsubTotal][ncx*ncy] sorted-atom range of every (subset, xy column)
+    // brick interpolation of the step's LAST mesh, unsharded: the atom's thread also writes the step's user-order force,
+    // direct-space accumulator + reciprocal force, into the caller's buffer (what k_finishForces does as a launch of its own)
+    void* outForces; int outIsDouble, outAccumulate;      // [N][3] in the caller's type, or null
+    const Real* dfx; const Real* dfy; const Real* dfz; int dfs;   // direct-space accumulators (component bases, atom stride)
+    const int* sortedToUser;
 };
 
 // classic Ewald reciprocal sum (ewald.hip)
@@ -189,7 +194,7 @@ template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipS
 template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hipStream_t s);   // fused x-FFT, energy, convolution, inverse x-FFT
 template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipStream_t s);
 template <typename Real> void launchPmeFFTX(const PmeParams<Real>& p, int sign, hipStream_t s);   // x axis alone (test hook)
-template <typename Real> void launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s);
+template <typename Real> bool launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s);   // true: the kernel also delivered the user-order forces (p.outForces)
 // fractional mesh coordinate of a position: cell index and offset inside the cell (ReferencePME.cpp:268-305); shared by the PME
 // kernels and the position-gather pass so that both always agree on an atom's cell
 template <typename Real> __device__ inline void gridCoord(const Real* recip, Real x, Real y, Real z, int nx, int ny, int nz, int* idx, Real* frac) {
