@@ -262,11 +262,15 @@ class Engine:
         """One evaluation.  energy: accumulate the raw per-slice energies too (the step of a force with energy-parameter derivatives);
         fetch=False leaves them on the device (no synchronisation: snb_get_slice_energies reads them when wanted)."""
         if energy and not fetch:
-            self.ok(self.L.snb_execute(self.h, 1, 1, 1, 1, None))
+            self.ok(self.L.snb_execute(self.h, 1, 2 if energy == 2 else 1, 1, 1, None))      # 2: derivative-only step (slices of set_energy_slices)
             return None
         e = ctypes.c_double(0.0)
         self.ok(self.L.snb_execute(self.h, 1, int(energy), 1, 1, ctypes.byref(e)))
         return e.value
+
+    def set_energy_slices(self, mask):
+        m = np.ascontiguousarray(mask, dtype=np.int32)
+        self.ok(self.L.snb_set_energy_slices(self.h, m.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
 
     def set_timing_interval(self, n):
         self.ok(self.L.snb_set_timing_interval(self.h, int(n)))
@@ -357,7 +361,7 @@ def main():
     def fenced_step(i, derivatives=False):
         move(i)
         eng.set_positions_device(pos.data_ptr(), is_double)
-        eng.execute(derivatives, fetch=False) if derivatives else eng.execute(False)
+        eng.execute(2, fetch=False) if derivatives else eng.execute(False)
         eng.forces_to(forces.data_ptr(), is_double)
         if world > 1:
             dist.all_reduce(forces)          # RCCL, ordered after the engine's kernels on the same stream
@@ -429,6 +433,9 @@ def main():
     # The step BASELINE.json config 3 names -- "with lambda_elec / lambda_vdW derivatives": a force that requests energy-parameter
     # derivatives accumulates the raw per-slice energies on EVERY step (the reference does, CommonNonbondedSlicingKernels.cpp:712-718).
     # Same walk, same rebuild cadence, K steps; the sums stay on the device (read once at the end, outside the region).
+    # derivatives are requested for the scaling parameters of the workload: the slices whose lambda differs from 1
+    deriv_slices = (np.abs(w["lam"] - 1.0).max(axis=1) > 0).astype(np.int32)
+    eng.set_energy_slices(deriv_slices)
     for i in range(4):
         fenced_step(args.warmup + args.steps + 1 + i, derivatives=True)
     eng.sync(); torch.cuda.synchronize()
@@ -488,7 +495,7 @@ def main():
                       len(w["exc_qq"]), args.padding),
                    "tiles_32x32": T, "blocks": int(st.n_blocks), "rebuild_interval": args.rebuild_interval, "rebuilds_in_timed_region": int(st.n_rebuilds) - rebuilds_before, "host_rebuilds": int(st.n_host_rebuilds), "neighbor_rebuild_ms": round(st.last_rebuild_ms, 2),
                    "ms_per_step_resident_coordinates": round(resident_ms, 4) if resident_ms is not None else None,
-                   "list_overruns": overruns, "preconditioning_steps": precondition, "allreduce_ms": round(allreduce_ms, 4) if allreduce_ms is not None else None,
+                   "derivative_slices": [int(i) for i in np.nonzero(deriv_slices)[0]], "list_overruns": overruns, "preconditioning_steps": precondition, "allreduce_ms": round(allreduce_ms, 4) if allreduce_ms is not None else None,
                    "first_call_ms": round(first_ms, 1), "energy_step_ms": round(energy_ms, 3), "energy_step_gpu_ms": round(eng.stats().last_total_ms, 3),
                    "gpu_ms_per_step": round(gpu_ms, 4), "direct_kernel_ms": round(direct_ms, 4), "reciprocal_ms": round(recip_ms, 4),
                    "parallelism": ("subset-grid + i-block sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},

@@ -123,6 +123,12 @@ snb_status snb_set_parameter_offsets(snb_handle h, int32_t n_globals,
 /* New values of the global parameters the offsets refer to (Context::setParameter): the next snb_execute recomputes the effective
  * parameters with two small kernels -- no re-sort, no tile rebuild, no graph re-capture, no host synchronisation. */
 snb_status snb_set_global_parameters(snb_handle h, int32_t n_globals, const double* values);
+/* mask[S]: the slices whose raw energies a DERIVATIVE-ONLY step (snb_execute with include_energy == 2) must produce -- the slices bound
+ * to a global parameter whose derivative was requested.  The reference adds dE/dlambda on every execute
+ * (CommonNonbondedSlicingKernels.cpp:712-718) but needs the energy of those slices only; here the pair kernel runs its forces-only
+ * arithmetic on the tiles of every other slice (on the 300k-atom box 95 % of the tiles are solvent-solvent), the reciprocal kernel
+ * skips their Gram sums.  Default: every slice.  The energies of slices outside the mask are unspecified after such a step. */
+snb_status snb_set_energy_slices(snb_handle h, const int32_t* mask);
 /* lambdas[S][2] = (Coulomb, vdW) per slice, S = n(n+1)/2, slice(i,j) = max(max+1)/2+min (SlicedNonbondedForce.h:22). */
 snb_status snb_set_lambdas(snb_handle h, const double* lambdas);
 /* Per-slice dispersion-correction coefficients (SlicedNonbondedForceImpl.cpp:263-354); NULL = none. */
@@ -144,7 +150,8 @@ snb_status snb_rebuild_neighbors(snb_handle h);             /* force a tile rebu
  * accumulated as well (the step of every force with energy-parameter derivatives: the reference adds dE/dlambda on every execute,
  * CommonNonbondedSlicingKernels.cpp:712-718) and summed ON THE DEVICE as the step's last kernel.  With energy == NULL nothing is read
  * back and nothing synchronises -- such a step replays a captured graph like a forces-only one; snb_get_slice_energies fetches the
- * sums when the caller needs them.  With energy != NULL it receives sum_slices lambda*E (this synchronises the stream). */
+ * sums when the caller needs them.  With energy != NULL it receives sum_slices lambda*E (this synchronises the stream).
+ * include_energy == 2: a derivative-only step -- as 1, restricted to the slices of snb_set_energy_slices (energy must be NULL). */
 snb_status snb_execute(snb_handle h, int32_t include_forces, int32_t include_energy, int32_t include_direct,
                        int32_t include_reciprocal, double* energy);
 /* out: [N][3] in the type selected by is_double; accumulate != 0 adds to what is there (the reference

@@ -15,7 +15,7 @@ SNB_ABI_VERSION = 4
 
 # every symbol include/snb.h declares (tests check the library exports each one)
 SYMBOLS = [
-    "snb_create", "snb_destroy", "snb_last_error", "snb_set_particles", "snb_set_exceptions", "snb_set_parameter_offsets", "snb_set_global_parameters", "snb_set_lambdas",
+    "snb_create", "snb_destroy", "snb_last_error", "snb_set_particles", "snb_set_exceptions", "snb_set_parameter_offsets", "snb_set_global_parameters", "snb_set_energy_slices", "snb_set_lambdas",
     "snb_set_dispersion_coefficients", "snb_compute_dispersion_coefficients", "snb_set_box", "snb_set_positions",
     "snb_rebuild_neighbors", "snb_execute", "snb_get_forces", "snb_set_force_output", "snb_set_shard_blocks", "snb_get_slice_energies", "snb_slice_energies_device", "snb_synchronize",
     "snb_get_pme_parameters", "snb_get_ljpme_parameters", "snb_get_stats", "snb_reset_timers", "snb_set_timing_interval", "snb_legal_grid_size", "snb_abi_version",
@@ -74,6 +74,7 @@ def lib():
     L.snb_set_particles.argtypes = [vp, dp, dp, dp, ip]
     L.snb_set_exceptions.argtypes = [vp, i32, ip, dp, dp, dp, ip]
     L.snb_set_lambdas.argtypes = [vp, dp]
+    L.snb_set_energy_slices.argtypes = [vp, ip]
     L.snb_set_parameter_offsets.argtypes = [vp, i32, i32, ip, ip, dp, i32, ip, ip, dp]
     L.snb_set_global_parameters.argtypes = [vp, i32, dp]
     L.snb_set_dispersion_coefficients.argtypes = [vp, dp]

@@ -161,6 +161,12 @@ class HipCalcSlicedNonbondedForceKernel:
         defaults = {force.getGlobalParameterName(i): force.getGlobalParameterDefaultValue(i) for i in range(force.getNumGlobalParameters())}
         self._set_dispersion(force, defaults)
         self._push_definition()
+        # slices whose raw energy a derivative-only step must produce: those bound to a parameter with a requested derivative
+        mask = np.zeros(self.numSlices, dtype=np.int32)
+        for (sl, _t), (_name, hasDeriv) in self._binding.items():
+            if hasDeriv:
+                mask[sl] = 1
+        self._check(self._lib.snb_set_energy_slices(self._h, _ip(mask)))
 
     def _effective(self, params):
         p = self._base.copy()
@@ -233,7 +239,9 @@ class HipCalcSlicedNonbondedForceKernel:
         self._check(self._lib.snb_set_positions(self._h, pos.ctypes.data_as(ctypes.c_void_p), 0, 1, 0))
         energy = ctypes.c_double(0.0)
         wantE = bool(includeEnergy) or bool(self._derivNames)
-        self._check(self._lib.snb_execute(self._h, int(includeForces), int(wantE), int(includeDirect), int(includeReciprocal), ctypes.byref(energy)))
+        # Q4: derivatives accumulate whether or not the energy is requested -- then only the slices they are bound to are evaluated (mode 2)
+        mode = 1 if includeEnergy else (2 if self._derivNames else 0)
+        self._check(self._lib.snb_execute(self._h, int(includeForces), mode, int(includeDirect), int(includeReciprocal), ctypes.byref(energy) if mode == 1 else None))
         if includeForces:
             self._check(self._lib.snb_get_forces(self._h, context._forces.ctypes.data_as(ctypes.c_void_p), 0, 1, 1))
         if wantE:

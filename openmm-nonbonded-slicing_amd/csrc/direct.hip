@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
         } else { x.x = Real(3e9) + Real(1e6) * c; x.y = Real(-5e9); x.z = Real(7e9); x.w = 0; se.x = 0; se.y = 0; }
     };
     struct TileHead { int slice, maskIdx; };
+    // energy steps: a tile whose slice is not wanted (p.sliceNeed) runs the forces-only arithmetic
     auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x & 0xFFFF, v.y}; };      // (slice of the tile [low 16 bits; the rest is the sub-tile occupancy of k_directSub], mask index)
     auto loadMask = [&](const TileHead& h) { return (h.maskIdx >= 0) ? p.masks[h.maskIdx * 32 + il] : 0u; };
     int jcode = p.tileJ[tBegin * 32 + stageJ];
@@ -300,13 +301,16 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
         const Real epsiS = sei.y * lamL;
         Real fjx = 0, fjy = 0, fjz = 0;
 
+        const bool tileE = ENERGY && p.sliceNeed[slice] != 0;      // (uniform)
+#define SNB_TILE_STEPS(E, M, SW) tileSteps<Real, MC, WRAP, E, M, SW>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj)
         if (p.useSwitch && MC != MC_LJPME && MC != MC_NOCUTOFF) {
-                if (hasMask) tileSteps<Real, MC, WRAP, ENERGY, true, true>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-                else tileSteps<Real, MC, WRAP, ENERGY, false, true>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-            } else {
-                if (hasMask) tileSteps<Real, MC, WRAP, ENERGY, true, false>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-                else tileSteps<Real, MC, WRAP, ENERGY, false, false>(p, rdPos, rdSe, pi, sei, qi, qiS, epsiS, c6i, lamC, lamL, maskWord, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-            }
+            if (tileE) { if (hasMask) SNB_TILE_STEPS(ENERGY, true, true); else SNB_TILE_STEPS(ENERGY, false, true); }
+            else { if (hasMask) SNB_TILE_STEPS(false, true, true); else SNB_TILE_STEPS(false, false, true); }
+        } else {
+            if (tileE) { if (hasMask) SNB_TILE_STEPS(ENERGY, true, false); else SNB_TILE_STEPS(ENERGY, false, false); }
+            else { if (hasMask) SNB_TILE_STEPS(false, true, false); else SNB_TILE_STEPS(false, false, false); }
+        }
+#undef SNB_TILE_STEPS
             // rotate-then-add leaves lane c holding slot c+1: one more rotation brings every slot home
         fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
         // add the two i-halves (rows r and r^1) and flush
@@ -450,9 +454,9 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
 // work that overlaps the VALU-bound tile work instead of trailing it as a launch of its own); the others loop over tile work items.
 template <int MC, bool POLY, bool ENERGY, bool SWITCH>
 __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<float> p, const PairListParams<float> q, const int nExclBlocks, const int nListBlocks) {
-    if ((int)blockIdx.x < nListBlocks) {
-        if ((int)blockIdx.x < nExclBlocks) { PairListParams<float> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<float, false>(qe, blockIdx.x); }
-        else exceptionsBody<float, false>(q, blockIdx.x - nExclBlocks);
+    if ((int)blockIdx.x < nListBlocks) {      // (energy steps: the list bodies reduce their slice energies in 2 S doubles of dynamic LDS)
+        if ((int)blockIdx.x < nExclBlocks) { PairListParams<float> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<float, ENERGY>(qe, blockIdx.x); }
+        else exceptionsBody<float, ENERGY>(q, blockIdx.x - nExclBlocks);
         return;
     }
     const int tileBlock = blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     // or converted before the trip in which it is consumed -- a copy (a loop-carried "next = loaded" move), the image shift added at
     // the load, or a uniform header moved to SGPRs behind its load each cost a full memory round trip per tile, atomics included,
     // because the wait counter is in-order.
-    struct TileRegs { int jcode, slice, maskIdx; float4 pj; float2 sej; float shx, shy, shz; unsigned mA, mB; float2 lam; };
+    struct TileRegs { int jcode, slice, maskIdx; float4 pj; float2 sej; float shx, shy, shz; unsigned mA, mB; float2 lam; int need; };
     TileRegs A, B;
     int vzero; asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));      // a zero the compiler cannot see through (keeps the header load in VGPRs)
     // (the j-force atomics of a tile are issued at the start of the NEXT trip: an atomic sits behind a conditional skip the wait-count
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     auto requestList = [&](TileRegs& r, int t) {                    // list entry + header of tile t
         r.jcode = p.tileJ[t * 32 + stageJ];
         const int2 v = *reinterpret_cast<const int2*>(&p.tileInfo[t + vzero]);
-        r.slice = v.x & 0xFFFF; r.maskIdx = v.y;      // (bits 16.. of .x: sub-tile occupancy, used by k_directSub)
+        r.slice = v.x; r.maskIdx = v.y;      // (bits 16.. of .x: sub-tile occupancy, used by k_directSub; masked off where the slice is consumed, never at the load)
     };
     auto requestAtoms = [&](TileRegs& r) {                          // needs r.jcode / r.slice / r.maskIdx (requested a tile earlier)
         const int code = r.jcode;
@@ -526,10 +530,11 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         r.shx = sh.x; r.shy = sh.y; r.shz = sh.z;
         const int mi = r.maskIdx < 0 ? 0 : r.maskIdx;              // unconditional loads: a conditionally loaded register is a phi with a copy
         r.mA = p.masks[mi * 32 + c]; r.mB = p.masks[mi * 32 + 16 + c];
-        r.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * r.slice]);      // (the slice index comes with the tile header, written by the builder)
+        r.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * (r.slice & 0xFFFF)]);      // (the slice index comes with the tile header, written by the builder)
+        if (ENERGY) r.need = p.sliceNeed[r.slice & 0xFFFF];      // energy steps: is this slice's energy wanted?
     };
     // what the staging of a tile leaves behind for its evaluation
-    struct Staged { int code; bool hasMask; unsigned maskA, maskB; float lamC, lamL; int slice; };
+    struct Staged { int code; bool hasMask; unsigned maskA, maskB; float lamC, lamL; int slice; bool needE; };
     auto stage = [&](TileRegs& R) {                                 // tile R -> LDS (the wait for its atoms sits here, in straight-line code)
         Staged st;
         __builtin_amdgcn_wave_barrier();
@@ -539,7 +544,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         st.hasMask = R.maskIdx >= 0;
         st.maskA = st.hasMask ? R.mA >> (8 * row) : 0u; st.maskB = st.hasMask ? R.mB >> (8 * row) : 0u;   // my j-quarter's 8 bits
         st.lamC = R.lam.x; st.lamL = R.lam.y;
-        st.slice = R.slice;
+        st.slice = R.slice & 0xFFFF;
+        st.needE = ENERGY && __builtin_amdgcn_readfirstlane(R.need) != 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         return st;
@@ -554,8 +560,10 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         if (ENERGY && st.slice != curSlice) { flushEnergy(); curSlice = st.slice; }
         const v2f qiS = qi * st.lamC, epsiS = epsi * st.lamL;      // lambda folded into the i-side parameters once per tile
         float fjx = 0, fjy = 0, fjz = 0;
-        if (st.hasMask) tileStepsPacked<MC, true, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, st.lamL, st.maskA, st.maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
-        else tileStepsPacked<MC, false, POLY, ENERGY, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, st.lamL, st.maskA, st.maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj);
+#define SNB_TILE_PACKED(M, E) tileStepsPacked<MC, M, POLY, E, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, st.lamL, st.maskA, st.maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj)
+        if (ENERGY && st.needE) { if (st.hasMask) SNB_TILE_PACKED(true, ENERGY); else SNB_TILE_PACKED(false, ENERGY); }
+        else { if (st.hasMask) SNB_TILE_PACKED(true, false); else SNB_TILE_PACKED(false, false); }      // forces only (also: energy steps, slice not wanted)
+#undef SNB_TILE_PACKED
         // rotate-then-subtract leaves lane c holding slot (c+1)&7: one more rotation brings every slot home, then the two
         // partial sums of a slot (lanes c and c+8) are merged
         fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
@@ -747,7 +755,7 @@ __global__ __launch_bounds__(256, 3) void k_directSub(const DirectParams<float> 
         //            [evaluate t from staged registers + LDS]  [stage t+1: wait for its atoms -- a whole tile old, three requests younger]
         // Two list sets alternate (the loop is unrolled by two) so that no requested register is ever copied.
         struct ListRegs { int code0, code1, head, maskIdx; };
-        struct AtomRegs { float4 pj0, pj1; float2 se0, se1; unsigned mrow; float2 lam; };
+        struct AtomRegs { float4 pj0, pj1; float2 se0, se1; unsigned mrow; float2 lam; int need; };
         struct Staged { float4 xj0, xj1; float2 sj0, sj1; int idx0, idx1; unsigned mrow; float lamC, lamL; int sm, slice; bool hasMask; };
         ListRegs LA, LB; AtomRegs AT; Staged st;
         int vzero; asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
@@ -767,6 +775,7 @@ __global__ __launch_bounds__(256, 3) void k_directSub(const DirectParams<float> 
             const int mi = r.maskIdx < 0 ? 0 : r.maskIdx;
             AT.mrow = p.masks[mi * 32 + (lane & 31)];      // i-row (lane & 31) of the tile's exclusion mask (unconditional: no phi, exact wait counts)
             AT.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * (r.head & 0xFFFF)]);
+            if (ENERGY) AT.need = p.sliceNeed[r.head & 0xFFFF];
         };
         auto stage = [&](const ListRegs& r) {      // atoms of the tile whose list entry is r -> evaluation-ready registers
             const float4 sh0 = s_shift[(r.code0 >> SNB_JSHIFT_BITS) & 127], sh1 = s_shift[(r.code1 >> SNB_JSHIFT_BITS) & 127];
@@ -866,8 +875,9 @@ __global__ __launch_bounds__(256, 3) void k_directSub(const DirectParams<float> 
 
 // evStart/evStop (both or neither): hipExtLaunchKernelGGL stamps them with the kernel's own begin and end -- the duration rocprofv3 reports,
 // without the marker-packet overhead of hipEventRecord pairs around the launch.  *timed tells the caller whether a kernel took them.
-#define SNB_LAUNCH(KERNEL, GRID, ...) do { if (evStart) { hipExtLaunchKernelGGL(KERNEL, GRID, block, 0, s, evStart, evStop, 0, __VA_ARGS__); *timed = true; } \
-                                           else hipLaunchKernelGGL(KERNEL, GRID, block, 0, s, __VA_ARGS__); } while (0)
+#define SNB_LAUNCH_LDS(KERNEL, GRID, LDS, ...) do { if (evStart) { hipExtLaunchKernelGGL(KERNEL, GRID, block, LDS, s, evStart, evStop, 0, __VA_ARGS__); *timed = true; } \
+                                                    else hipLaunchKernelGGL(KERNEL, GRID, block, LDS, s, __VA_ARGS__); } while (0)
+#define SNB_LAUNCH(KERNEL, GRID, ...) SNB_LAUNCH_LDS(KERNEL, GRID, 0, __VA_ARGS__)
 template <typename Real, int MC> static bool launchDirectMC(const DirectParams<Real>& p, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s, hipEvent_t evStart, hipEvent_t evStop, bool* timed) {
     const int myItems = p.numWork;
     if (myItems <= 0) return false;
@@ -880,7 +890,8 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
             PairListParams<float> q;
             std::memset(&q, 0, sizeof(q));
             int nExclBlocks = 0, nListBlocks = 0;
-            if (lists && !energy) { q = *lists; nExclBlocks = (q.nExclAtoms + 255) / 256; nListBlocks = nExclBlocks + (q.n + 255) / 256; }   // the energy pair lists need their LDS reduction: own launch
+            if (lists) { q = *lists; nExclBlocks = (q.nExclAtoms + 255) / 256; nListBlocks = nExclBlocks + (q.n + 255) / 256; }
+            const size_t listLds = (lists && energy) ? sizeof(double) * 2 * q.nSlices : 0;      // the energy list bodies reduce per slice in LDS
             dim3 gridAll(nwg + nListBlocks);
             const bool poly = (MC == MC_EWALD || MC == MC_LJPME) && p.ewUsePoly;
             if constexpr (MC != MC_NOCUTOFF) {
@@ -897,7 +908,7 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
                     return lists != nullptr && !energy;
                 }
             }
-#define SNB_PACKED(P, E, S) SNB_LAUNCH((k_directPacked<MC, P, E, S>), gridAll, p, q, nExclBlocks, nListBlocks)
+#define SNB_PACKED(P, E, S) SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S>), gridAll, listLds, p, q, nExclBlocks, nListBlocks)
             if constexpr (MC == MC_NOCUTOFF) { if (energy) SNB_PACKED(false, true, false); else SNB_PACKED(false, false, false); }
             else if (p.useSwitch && MC != MC_LJPME) {      // (no switching function under LJPME, Q2)
                 if (energy) { if (poly) SNB_PACKED(true, true, true); else SNB_PACKED(false, true, true); }
@@ -907,7 +918,7 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
                 else { if (poly) SNB_PACKED(true, false, false); else SNB_PACKED(false, false, false); }
             }
 #undef SNB_PACKED
-            return lists != nullptr && !energy;
+            return lists != nullptr;
         }
     }
     if (wrap) {
@@ -958,7 +969,7 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exceptions
         dEdR *= invR * invR;
         gAdd(&p.fx[ij.x * p.fs], dEdR * dx); gAdd(&p.fy[ij.x * p.fs], dEdR * dy); gAdd(&p.fz[ij.x * p.fs], dEdR * dz);
         gAdd(&p.fx[ij.y * p.fs], -dEdR * dx); gAdd(&p.fy[ij.y * p.fs], -dEdR * dy); gAdd(&p.fz[ij.y * p.fs], -dEdR * dz);
-        if (ENERGY) { e0 = par.z * invR; e1 = par.y * (s6 - Real(1)) * s6; }
+        if (ENERGY && p.sliceNeed[slice]) { e0 = par.z * invR; e1 = par.y * (s6 - Real(1)) * s6; }
     }
     if (ENERGY) {
         if (k < p.n) {
@@ -1011,7 +1022,8 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
                 // coordinates, charges and the double alpha -- products like k*qO*qH rounded to float are off by the SAME 1e-7 for all
                 // 2e5 identical pairs, which alone was 0.8 kJ/mol (1.1e-3 of the water-water slice of the 96k-atom box).
                 double erfv, rd = 0, qqd = 0;
-                if (ENERGY) {
+                const bool wantE = ENERGY && p.sliceNeed[slice] != 0;
+                if (wantE) {
                     rd = sqrt((double)dx * (double)dx + (double)dy * (double)dy + (double)dz * (double)dz);
                     qqd = (double)xi.w * (double)xj.w * SNB_ONE_4PI_EPS0;
                     erfv = erf(p.alpha64 * rd);
@@ -1019,8 +1031,8 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
                 Real f = 0;
                 if (erfv > 1e-6) {
                     f = -lamC * qq * invR * invR * invR * (Real(erfv) - ar * ex * Real(1.1283791670955126));
-                    if (ENERGY) __hip_atomic_fetch_add(&s_sliceE[2 * slice], -0.5 * qqd * erfv / rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else if (ENERGY)
+                    if (wantE) __hip_atomic_fetch_add(&s_sliceE[2 * slice], -0.5 * qqd * erfv / rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (wantE)
                     __hip_atomic_fetch_add(&s_sliceE[2 * slice], -0.5 * p.alpha64 * 1.1283791670955126 * qqd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (p.ljpme) {
                     const auto sej = p.sigeps[b];
@@ -1029,7 +1041,7 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
                     const Real invR2 = invR * invR;
                     const Real expd = fexp(-dar2);
                     const Real coef = c6 * invR2 * invR2 * invR2;
-                    if (ENERGY) __hip_atomic_fetch_add(&s_sliceE[2 * slice + 1], 0.5 * (double)(coef * (Real(1) - expd * (Real(1) + dar2 + Real(0.5) * dar4))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (wantE) __hip_atomic_fetch_add(&s_sliceE[2 * slice + 1], 0.5 * (double)(coef * (Real(1) - expd * (Real(1) + dar2 + Real(0.5) * dar4))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     // reference: dEdR = -6 c6 r^-8 (...), forces[ii] -= lam*dEdR*delta  =>  +6 lam c6 r^-8 (...) * delta on ii
                     f += lamL * Real(6) * coef * invR2 * (Real(1) - expd * (Real(1) + dar2 + Real(0.5) * dar4 + dar6 * Real(1.0 / 6.0)));
                 }

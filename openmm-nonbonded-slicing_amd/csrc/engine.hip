@@ -55,6 +55,7 @@ struct EngineBase {
     virtual void setLambdas(const double*) = 0;
     virtual void setParameterOffsets(int, int, const int32_t*, const int32_t*, const double*, int, const int32_t*, const int32_t*, const double*) = 0;
     virtual void setGlobalParameters(int, const double*) = 0;
+    virtual void setEnergySlices(const int32_t*) = 0;
     virtual void setDispersion(const double*) = 0;
     virtual void setBox(const double*) = 0;
     virtual void setPositions(const void*, int, int, int) = 0;
@@ -249,8 +250,9 @@ public:
     std::vector<int> hSubsetStart, hSubsetPaddedStart, staticBlkSubset; int staticNpad = 0; size_t tileCap = 0; bool staticDirty = true, gpuBuilt = false;
     DevBuf<int2> pairs14, pairsExcl, colRange; DevBuf<int4> tileInfo, workItems, workItemsStage, workItemsPartial; int numWorkItems = 0; int colCells[2] = {0, 0}; DevBuf<unsigned> masks;
     DevBuf<T4> params14, paramsExcl; int n14 = 0, nExcl = 0;
+    DevBuf<int> dSliceNeedAll, dSliceNeedSel; std::vector<int> sliceNeedSel;      // energy steps: every slice / the slices a derivative-only step (include_energy == 2) must produce
     DevBuf<double> dDispCoef, sliceE, sliceTotal;      // 64 partitioned copies of the raw [S][2] energies, and their sum (last kernel of an energy step)
-    bool energyPending = false;      // the last energy step's sums are still on the device
+    bool energyPending = false, energySelective = false;      // the last energy step's sums are still on the device
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
     PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
@@ -268,7 +270,7 @@ public:
     DevBuf<T4> posRef; int* hDispFlags = nullptr; int* dDispFlags = nullptr; int64_t listOverruns = 0;
     std::vector<int3> hKvec; DevBuf<int3> dKvec; DevBuf<Real> dCosSin;
     struct GraphKey {
-        const void* pos; int isDouble, stride4; bool direct, recip, energy; void* out; int outDouble, outAcc;
+        const void* pos; int isDouble, stride4; bool direct, recip; int energy; void* out; int outDouble, outAcc;      // energy: 0 forces only, 1 all slice energies, 2 selected slices
         bool operator==(const GraphKey& o) const { return pos == o.pos && isDouble == o.isDouble && stride4 == o.stride4 && direct == o.direct && recip == o.recip && energy == o.energy && out == o.out && outDouble == o.outDouble && outAcc == o.outAcc; }
     };
     void* outPtr = nullptr; int outIsDouble = 0, outAccumulate = 0; bool outputWritten = false;   // snb_set_force_output
@@ -294,6 +296,8 @@ public:
         lambdas.assign((size_t)S * 2, 1.0); dispCoef.assign(S, 0.0); hostSliceE.assign((size_t)S * 2, 0.0);
         sliceE.resize((size_t)S * 2 * SNB_SLICE_E_PARTS); sliceTotal.resize((size_t)S * 2);
         dDispCoef.upload(dispCoef, stream);
+        sliceNeedSel.assign(S, 1); dSliceNeedAll.upload(sliceNeedSel, stream); dSliceNeedSel.upload(sliceNeedSel, stream);
+        HIPCHECK(hipStreamSynchronize(stream));
         if (cfg.shard_count < 1) cfg.shard_count = 1;
         shardBegin = cfg.shard_count > 1 ? cfg.shard_rank : 0; shardEnd = shardBegin + 1; shardPeriod = cfg.shard_count;
         // tabulated Ewald force factor: opt-in.  Measured on MI355X it only trades 4 % of the VALU instructions for LDS gathers (the packed
@@ -450,6 +454,10 @@ public:
         lambdas.assign(l, l + (size_t)S * 2);
         hLambdas.assign(lambdas.begin(), lambdas.end());      // (a member: the staging array outlives the asynchronous copy; no synchronisation per lambda change)
         dLambdas.upload(hLambdas, stream);
+    }
+    void setEnergySlices(const int32_t* m) override {
+        for (int i = 0; i < S; i++) sliceNeedSel[i] = m[i] != 0;
+        dSliceNeedSel.upload(sliceNeedSel, stream);      // (a member: outlives the copy; same buffer, so captured graphs stay valid)
     }
     void setDispersion(const double* c) override {
         if (c) dispCoef.assign(c, c + S); else dispCoef.assign(S, 0.0);
@@ -1097,7 +1105,7 @@ public:
                              (box[3] * box[7] - box[4] * box[6]) * sc, -box[0] * box[7] * sc, box[0] * box[4] * sc};
         for (int i = 0; i < 9; i++) p.recip[i] = (Real)r[i];
         p.alpha = (Real)plan.alpha; p.volume = (Real)det; p.dispersion = plan.dispersion ? 1 : 0;
-        p.lambdas = dLambdas.p; p.gridSubset = gridSubset.p; p.nsubTotal = nsub; p.mix = cfg.shard_count == 1 ? 1 : 0;
+        p.lambdas = dLambdas.p; p.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p; p.gridSubset = gridSubset.p; p.nsubTotal = nsub; p.mix = cfg.shard_count == 1 ? 1 : 0;
         p.sliceE = sliceE.p; p.fpx = fpx.p; p.fpy = fpy.p; p.fpz = fpz.p; p.wantEnergy = wantEnergy ? 1 : 0;
         // brick kernels: the sort columns were cut for the Coulomb mesh; any mesh whose cells tile those columns can use them,
         // with bricks of `group` columns when one column is narrower than 5 cells (stencil 4 + 1 cell of drift)
@@ -1151,6 +1159,7 @@ public:
         stepsSinceRebuild++;
         outputWritten = outPtr != nullptr;
         const bool energy = includeEnergy != 0;
+        energySelective = includeEnergy == 2;      // derivative-only step: only the slices named by snb_set_energy_slices
         lastRecip = includeRecip && (isPme() || cfg.method == SNB_Ewald);
         // Forces-only steps replay a captured hipGraph (the ~14 small launches of a step are host-launch-bound otherwise:
         // 7-8 us of idle GPU between kernels).  Every 32nd step -- and every energy step -- is enqueued eagerly with HIP events
@@ -1168,7 +1177,7 @@ public:
             enqueueStep(energy, includeDirect != 0, includeRecip != 0, &ev);
             ev.pending = true;
         } else {
-            GraphKey key{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0, energy, outPtr, outIsDouble, outAccumulate};
+            GraphKey key{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0, energy ? (energySelective ? 2 : 1) : 0, outPtr, outIsDouble, outAccumulate};
             hipGraphExec_t graphExec = nullptr;
             for (auto& g : graphs) if (g.key == key) { graphExec = g.exec; break; }
             if (!graphExec) {
@@ -1250,7 +1259,7 @@ public:
         // O(N) pair lists: one rank only when sharded -- the LAST one, which carries no PME grid once there are more ranks than grids
         const bool haveLists = includeDirect && cfg.shard_rank == cfg.shard_count - 1;
         if (haveLists) {
-            q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.fs = fstride; q.sliceE = sliceE.p; q.lambdas = dLambdas.p;
+            q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.fs = fstride; q.sliceE = sliceE.p; q.lambdas = dLambdas.p; q.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p;
             const bool exPeriodic = (cfg.method == SNB_NoCutoff || cfg.method == SNB_CutoffNonPeriodic) ? false : cfg.exceptions_periodic != 0;
             q.periodic = exPeriodic ? 1 : 0; q.imageOffset = imageOffset.p;
             q.sigeps = sigeps.p; q.blockSubset = blockSubset.p; q.exclStart = exclStart.p; q.exclList = exclList.p; q.nSlices = S; q.sortedToUser = dSortedToUser.p; q.userToSorted = dUserToSorted.p;
@@ -1264,7 +1273,7 @@ public:
             DirectParams<Real> p;
             std::memset(&p, 0, sizeof(p));
             p.posq = posq.p; p.sigeps = sigeps.p; p.blockSubset = blockSubset.p; p.workItems = workItems.p;
-            p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.fs = fstride; p.sliceE = sliceE.p; p.lambdas = dLambdas.p;
+            p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.fs = fstride; p.sliceE = sliceE.p; p.lambdas = dLambdas.p; p.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p;
             const int r = cfg.shard_rank, c = cfg.shard_count;
             (void)r; (void)c;
             p.subTiles = (gpuBuilt && !wrapMode && subTileMode() != 0) ? 1 : 0;
@@ -1520,6 +1529,7 @@ snb_status snb_set_global_parameters(snb_handle h, int32_t n, const double* valu
     if (n < 0 || (n > 0 && !values)) return SNB_ERR_INVALID_ARGUMENT;
     return guard(h, [&] { h->impl->setGlobalParameters(n, values); });
 }
+snb_status snb_set_energy_slices(snb_handle h, const int32_t* mask) { if (!mask) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->setEnergySlices(mask); }); }
 snb_status snb_set_lambdas(snb_handle h, const double* l) { if (!l) return SNB_ERR_INVALID_ARGUMENT; return guard(h, [&] { h->impl->setLambdas(l); }); }
 snb_status snb_set_dispersion_coefficients(snb_handle h, const double* c) { return guard(h, [&] { h->impl->setDispersion(c); }); }
 snb_status snb_compute_dispersion_coefficients(int32_t n, int32_t nsub, const double* sigma, const double* epsilon, const int32_t* subset, double cutoff,

@@ -781,6 +781,10 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
         const int term = p.dispersion ? 1 : 0;
         for (int I = 0; I < nsub; I++)
             for (int J = 0; J <= I; J++) {
+                {   // derivative-only steps ask for a few slices: the others' Gram sums (a pass over the spectra and two barriers each) are skipped
+                    const int gi = p.gridSubset[I], gj = p.gridSubset[J];
+                    if (!p.sliceNeed[gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi]) continue;      // (uniform)
+                }
                 double acc = 0;
                 for (int it = tid; it < nx * NB; it += NT) {
                     const int kx = dNB.div(it), col = it - kx * NB;

@@ -52,6 +52,7 @@ template <typename Real> struct DirectParams {
     Real* fx; Real* fy; Real* fz; int fs;   // direct-space force accumulators: component bases and the index stride of an atom (1: three arrays; 4: one (x,y,z,-) record per atom)
     double* sliceE;           // [S*2] raw energies
     const Real* lambdas;      // [S*2]
+    const int* sliceNeed;     // [S] energy steps: non-zero = this slice's raw energies are wanted (derivative-only steps ask for a few slices)
     int numWork, workStart, workStride;   // sharding: items workStart, workStart+workStride, ...
     int subTiles;             // the lists carry octet-ordered blocks and sub-tile occupancies (GPU builder): k_directSub applies
     int nsub;
@@ -81,6 +82,7 @@ template <typename Real> struct PairListParams {  // 1-4 exceptions: one thread 
     Real* fx; Real* fy; Real* fz; int fs;
     double* sliceE;
     const Real* lambdas;
+    const int* sliceNeed;     // [S] as in DirectParams
     int periodic;
     const Real* imageOffset;  // [Npad*3] wrapped - user coordinates (to undo the wrap for non-periodic exceptions)
     Real box[9];
@@ -116,6 +118,7 @@ template <typename Real> struct PmeParams {
     Real alpha, volume;
     int dispersion;           // 0: Coulomb charges & kernel, 1: LJPME dispersion
     const Real* lambdas;      // [S*2]
+    const int* sliceNeed;     // [S] energy steps: slices whose reciprocal energy is wanted
     const int* gridSubset;    // [nsub] subset id of each held grid
     int nsubTotal;
     int mix;                  // 1: lambda-mix the potentials in k-space (unsharded); 0: plain convolution (sharded)

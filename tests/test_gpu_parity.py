@@ -702,3 +702,35 @@ def test_changing_subsets_through_update_parameters(snb, F, oev, prec):
         force.setParticleSubset(int(i), 1)
     force.updateParametersInContext(ctx)
     check()
+
+
+def test_derivative_only_steps_evaluate_only_the_bound_slices(snb, F, oev, prec):
+    """A force with energy-parameter derivatives accumulates dE/dlambda on every evaluation, energy requested or not (Q4,
+    ReferenceNonbondedSlicingKernels.cpp:259-265).  Such derivative-only steps run with include_energy == 2: only the slices bound to a
+    derivative-requested parameter are evaluated (snb_set_energy_slices), the pair kernel runs forces-only arithmetic on every other
+    tile.  Forces and derivatives must still be the oracle's, step after step (graph replay included)."""
+    n, L = 13824, 6.0
+    force, pos, box = systems.random_box(F, n, 4, 4, L, 1.0, pme=(2.6283, 48, 48, 48))
+    system = snb.System()
+    for _ in range(n):
+        system.addParticle(1.0)
+    system.setDefaultPeriodicBoxVectors(*box)
+    system.addForce(force)
+    ctx = snb.Context(system, precision=prec, neighbor_padding=0.1, rebuild_interval=10)
+    rng = np.random.default_rng(3)
+    tol = TOLS[prec]
+    for step in range(4):
+        ctx.setPositions(pos)
+        st = ctx.getState(getForces=True, getParameterDerivatives=True)          # no energy: derivative-only step
+        o = oev(force, pos, box, dict(ctx.getParameters()))
+        err = np.linalg.norm(o["forces"] - st.getForces(), axis=1) / np.maximum(np.linalg.norm(o["forces"], axis=1), 1.0)
+        assert err.max() <= tol, "step %d: max force error %g" % (step, err.max())
+        assert o["derivatives"], "the test system must request derivatives"
+        for name, v in o["derivatives"].items():
+            K.assertEqualTo(v, st.getEnergyParameterDerivatives()[name], tol)
+        pos = pos + rng.normal(0.0, 0.004, pos.shape)
+    # and a full energy evaluation afterwards still produces every slice
+    ctx.setPositions(pos)
+    st = ctx.getState(getEnergy=True)
+    o = oev(force, pos, box, dict(ctx.getParameters()))
+    K.assertEqualTo(o["energy"], st.getPotentialEnergy(), tol)
