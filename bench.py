@@ -147,8 +147,8 @@ CONFIGS = {
     "c3t": (300000, 14.42, 4, 4, 120, 0, "single"),      # c3 in a triclinic cell (shear_workload)
     "c3l": (300000, 14.42, 4, 5, 120, 60, "single"),     # c3 with LJPME (dispersion mesh 60^3)
 }
-# 1-GPU rates of this build on MI355X (bench.py --config <name>, round 1), quoted beside N > 1 results of the same workload
-ONE_GPU_NS_DAY = {"c4": 259.9, "c3": 365.1, "c2": 889.1}
+# 1-GPU rates of this build on MI355X (bench.py --config <name>, round 2, random-walk coordinates), quoted beside N > 1 results of the same workload
+ONE_GPU_NS_DAY = {"c4": 245.2, "c3": 371.4, "c2": 906.2}
 ALPHA = 2.6283
 CUTOFF = 1.0
 
@@ -505,7 +505,7 @@ def main():
     }
     # HBM-side traffic of the same kernel: PMC passes cannot run inside this process, so the figure comes from the committed
     # summary of `tools/pmc_hbm.sh` (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes over this command)
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_%s_pmc_hbm.json" % cfg_name)
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_%s_pmc_hbm.json" % cfg_name)
     if os.path.exists(pmc_file) and world == 1:
         try:
             rec = json.load(open(pmc_file))["k_direct_forces"]

@@ -1269,8 +1269,11 @@ template <typename Real> static bool launchInterpolateBricks(const PmeParams<Rea
         static const int zsEnv = getenv("SNB_INTERP_ZSLABS") ? atoi(getenv("SNB_INTERP_ZSLABS")) : 0;
         int zSlabs = 1;      // measured on c3: 1 slab 52 us, 2 slabs 70, 4 slabs 72 (every slab rescans the columns' atoms)
         if (zsEnv > 0 && p.d.nz % zsEnv == 0 && p.d.nz / zsEnv >= 8) zSlabs = zsEnv;
-        const int bz = p.d.nz / zSlabs + 4;
-        const size_t lds = ((sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * bz + 15) & ~(size_t)15) + sizeof(double) * p.nsubTotal * (p.nsubTotal + 1);
+        auto ldsFor = [&](int slabs) { return ((sizeof(Real) * (size_t)(cx + 6) * (cy + 6) * (p.d.nz / slabs + 4) + 15) & ~(size_t)15) + sizeof(double) * p.nsubTotal * (p.nsubTotal + 1); };
+        // a brick that does not fit LDS in one piece (double precision on a large mesh: 12 x 12 x 184 doubles = 212 KB for the 180^3 mesh of
+        // c5) is cut into the fewest z slabs that do, rather than falling back to the 32-lanes-per-atom gather kernel (424 us there)
+        if (zsEnv <= 0) for (int k = 2; k <= 8 && ldsFor(zSlabs) > 150 * 1024; k++) if (p.d.nz % k == 0 && p.d.nz / k >= 8) zSlabs = k;
+        const size_t lds = ldsFor(zSlabs);
         static const bool noBrick = getenv("SNB_NO_INTERP_BRICKS") != nullptr;   // testing aid: force the 32-lanes-per-atom kernel
         if (lds <= 150 * 1024 && !noBrick && p.nsubTotal * p.groupX * p.groupY <= 256) {
             const int nblocks = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * zSlabs;
