@@ -500,7 +500,7 @@ def main():
                    "gpu_ms_per_step": round(gpu_ms, 4), "direct_kernel_ms": round(direct_ms, 4), "reciprocal_ms": round(recip_ms, 4),
                    "parallelism": ("subset-grid + i-block sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": ("snb::k_directPacked<%d, true, false, false>" % (2 if method == 4 else 3)) if not is_double else "snb::k_direct<double, ...>",
-                     "timing": "kernel begin/end stamps of hipExtLaunchKernelGGL on the eager (every 32nd) steps of the timed region", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "timing": "kernel begin/end stamps of hipExtLaunchKernelGGL on the eager steps of the timed region (snb_set_timing_interval: at least 5 of them)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(bytes_direct), "avg_launch_ms": round(direct_ms, 4)},
     }
     # HBM-side traffic of the same kernel: PMC passes cannot run inside this process, so the figure comes from the committed
