@@ -138,8 +138,9 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
     const int nbx = ncx / p.groupX, nby = ncy / p.groupY;
     const int ncol = ncx * ncy;
     // ... and one of zSlabs slabs along z (more, smaller work-groups: the bulk subset alone has only ~#columns busy bricks)
-    const int sz = nz / p.zSlabs;
-    const int zs = blockIdx.x % p.zSlabs, brickId = blockIdx.x / p.zSlabs;
+    const int nSlabs = FUSEZ ? 1 : p.zSlabs;      // (the fused-z instantiation is launched with one slab only)
+    const int sz = nz / nSlabs;
+    const int zs = blockIdx.x % nSlabs, brickId = blockIdx.x / nSlabs;
     const int slot = brickId / (nbx * nby), bcol = brickId - slot * (nbx * nby);
     const int Bx = bcol / nby, By = bcol - Bx * nby;
     const int x0 = Bx * cx, y0 = By * cy, z0 = zs * sz;
@@ -209,7 +210,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
             int rx = idx[0] - x0; if (rx > hx) rx -= p.d.nx; else if (rx < -hx) rx += p.d.nx;
             int ry = idx[1] - y0; if (ry > hy) ry -= p.d.ny; else if (ry < -hy) ry += p.d.ny;
             int rz = idx[2] - z0; if (rz > hz) rz -= nz; else if (rz < -hz) rz += nz;
-            const bool zHit = p.zSlabs == 1 || (rz + 4 >= 0 && rz < sz);
+            const bool zHit = nSlabs == 1 || (rz + 4 >= 0 && rz < sz);
             if (cell >= 0 && zHit && rx + 4 >= 0 && rx < cx && ry + 4 >= 0 && ry < cy) {
                 ixLo = rx < 0 ? -rx : 0;                                                   // lines with 0 <= rx + ix < cx
                 nEnt = ((cx - rx < 5) ? cx - rx : 5) - ixLo;
@@ -259,7 +260,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     int z = (idx[2] & ~1) + 2 * j - z0; if (z >= nz) z -= nz; else if (z < 0) z += nz;
-                    zp[j] = z < sz ? z : -1;
+                    zp[j] = (FUSEZ || z < sz) ? z : -1;      // (FUSEZ: one slab, the brick holds whole lines -- every point is inside)
                 }
                 const Real wq = wx * fixScale;
 #pragma unroll
@@ -278,7 +279,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
                         const unsigned long long packed = ((unsigned long long)(unsigned)(hi[j] + (lo[j] >> 31)) << 32) | (unsigned)lo[j];
-                        if (zp[j] >= 0) __hip_atomic_fetch_add(&line[zp[j] >> 1], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (FUSEZ || zp[j] >= 0) __hip_atomic_fetch_add(&line[zp[j] >> 1], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             } else {
