@@ -840,7 +840,7 @@ public:
         for (int i = 0; i < N; i++) start[i + 1] += start[i];
         { std::vector<int> fill(N, 0); for (auto& o : offP) { const int at = start[o.target] + fill[o.target]++; glob[at] = o.global; for (int d = 0; d < 3; d++) delta[3 * (size_t)at + d] = o.d[d]; } }
         dBaseP.upload(hb, stream); dOffPStart.upload(start, stream); dOffPGlobal.upload(glob, stream); dOffPDelta.upload(delta, stream);
-        dUCharge.resize(N); dUSigEps.resize(N); dParamSums.resize(3 * (size_t)nsub + 1); dFixScale.resize(4);
+        dUCharge.resize(N); dUSigEps.resize(N); dParamSums.resize((3 * (size_t)nsub + 1) * (1 + SNB_PARAM_SUM_ROWS)); dFixScale.resize(4);
         HIPCHECK(hipStreamSynchronize(stream));
         basePDirty = false;
     }

@@ -131,49 +131,88 @@ __global__ void k_exceptionParams(int n, const double* __restrict__ base, const 
 // of q, q^2 and c6^2 (self energies, neutralising background: ReferenceSlicedLJCoulombIxn.cpp:203-222), and the largest |q| and |c6|
 // (fixed-point scale of the brick spreader).  sums: [3 nsub] doubles, then two ints holding the maxima as float bit patterns.
 template <typename Real>
-__global__ void k_paramSums(int n, int nsub, const Real* __restrict__ uCharge, const typename Vec<Real>::T2* __restrict__ uSigEps, const int* __restrict__ uSubset,
-                            double* __restrict__ sums) {
+__global__ void __launch_bounds__(1024) k_paramSums(int n, int nsub, const Real* __restrict__ uCharge, const typename Vec<Real>::T2* __restrict__ uSigEps, const int* __restrict__ uSubset,
+                            double* __restrict__ partials) {
     extern __shared__ double s_sums[];      // [3 nsub]
+    __shared__ int s_max[2];
     for (int i = threadIdx.x; i < 3 * nsub; i += blockDim.x) s_sums[i] = 0.0;
+    if (threadIdx.x < 2) s_max[threadIdx.x] = 0;
     __syncthreads();
     float mq = 0.f, mc = 0.f;
-    for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
-        const double q = (double)uCharge[u], hs = (double)uSigEps[u].x, se = (double)uSigEps[u].y;
-        const double c6 = 8.0 * hs * hs * hs * se;
-        const int sb = uSubset[u];
-        __hip_atomic_fetch_add(&s_sums[3 * sb], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&s_sums[3 * sb + 1], q * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&s_sums[3 * sb + 2], c6 * c6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        mq = fmaxf(mq, fabsf((float)q)); mc = fmaxf(mc, fabsf((float)c6));
+    const int lane = threadIdx.x & 63;
+    for (int u0 = blockIdx.x * blockDim.x; u0 < n; u0 += gridDim.x * blockDim.x) {      // (uniform trip count: the wave reductions below need every lane)
+        const int u = u0 + threadIdx.x;
+        const bool valid = u < n;
+        double q = 0, c6 = 0; int sb = -1;
+        if (valid) {
+            q = (double)uCharge[u];
+            const double hs = (double)uSigEps[u].x, se = (double)uSigEps[u].y;
+            c6 = 8.0 * hs * hs * hs * se;
+            sb = uSubset[u];
+            mq = fmaxf(mq, fabsf((float)q)); mc = fmaxf(mc, fabsf((float)c6));
+        }
+        // one wave reduction per subset present in the wave (usually one), then three LDS adds by one lane -- 64 lanes adding to the
+        // same three doubles were serialised (52 us for 300k atoms; a parameter change costs this pass)
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int sel = __shfl(sb, __builtin_ctzll(todo), 64);
+            const bool mine = valid && sb == sel;
+            double a = mine ? q : 0.0, b = mine ? q * q : 0.0, c = mine ? c6 * c6 : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+            if (lane == 0) {
+                __hip_atomic_fetch_add(&s_sums[3 * sel], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_sums[3 * sel + 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_sums[3 * sel + 2], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            todo &= ~__ballot(mine);
+        }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 3 * nsub; i += blockDim.x) if (s_sums[i] != 0.0) atomicAdd(&sums[i], s_sums[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mq = fmaxf(mq, __shfl_xor(mq, o, 64)); mc = fmaxf(mc, __shfl_xor(mc, o, 64)); }
-    if ((threadIdx.x & 63) == 0) {      // non-negative floats order like their bit patterns
-        int* im = reinterpret_cast<int*>(sums + 3 * nsub);
-        atomicMax(&im[0], __float_as_int(mq)); atomicMax(&im[1], __float_as_int(mc));
-    }
+    if (lane == 0) { atomicMax(&s_max[0], __float_as_int(mq)); atomicMax(&s_max[1], __float_as_int(mc)); }      // non-negative floats order like their bit patterns
+    __syncthreads();
+    // partials, one row per work-group, summed by k_fixScale: atomics on ONE address are serialised in the memory-side unit (about 5 ns
+    // each; 512 groups x 20 of them were the whole 50 us of the first version of this kernel)
+    double* row = partials + (size_t)blockIdx.x * (3 * nsub + 1);
+    for (int i = threadIdx.x; i < 3 * nsub; i += blockDim.x) row[i] = s_sums[i];
+    if (threadIdx.x < 2) reinterpret_cast<int*>(row + 3 * nsub)[threadIdx.x] = s_max[threadIdx.x];
 }
 // fixed point: 16 x the largest per-atom value fits 31 bits (a grid point collects at most a few atoms' weights, each <= 1)
-template <typename Real> __global__ void k_fixScale(const double* __restrict__ sums, int nsub, Real* __restrict__ fix) {
+template <typename Real> __global__ void k_fixScale(const double* __restrict__ partials, int rows, int nsub, double* __restrict__ sums, Real* __restrict__ fix) {
+    const int w = 3 * nsub + 1, lane = threadIdx.x & 63;      // four waves share the columns; every wave finds the maxima, the first writes them
+    for (int i = threadIdx.x >> 6; i < 3 * nsub; i += 4) {
+        double a = 0;
+        for (int r = lane; r < rows; r += 64) a += partials[(size_t)r * w + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) sums[i] = a;
+    }
+    int mq = 0, mc = 0;
+    for (int r = lane; r < rows; r += 64) {
+        const int* im = reinterpret_cast<const int*>(partials + (size_t)r * w + 3 * nsub);
+        mq = max(mq, im[0]); mc = max(mc, im[1]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mq = max(mq, __shfl_xor(mq, o, 64)); mc = max(mc, __shfl_xor(mc, o, 64)); }
     if (threadIdx.x < 2) {
-        const int* im = reinterpret_cast<const int*>(sums + 3 * nsub);
-        const double m = fmax((double)__int_as_float(im[threadIdx.x]), 1e-30);
+        const double m = fmax((double)__int_as_float(threadIdx.x ? mc : mq), 1e-30);
         const Real sc = (Real)(1073741824.0 / (16.0 * m));
         fix[2 * threadIdx.x] = sc; fix[2 * threadIdx.x + 1] = (Real)(1.0 / (double)sc);
+        reinterpret_cast<int*>(sums + 3 * nsub)[threadIdx.x] = threadIdx.x ? mc : mq;
     }
 }
 template <typename Real>
 void launchParticleParams(int n, int nsub, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals,
                           const int* uSubset, Real* uCharge, typename Vec<Real>::T2* uSigEps, double* sums, Real* fix, hipStream_t s) {
-    (void)hipMemsetAsync(sums, 0, sizeof(double) * (3 * (size_t)nsub + 1), s);
+    // sums: [3 nsub + 1] totals, then SNB_PARAM_SUM_ROWS rows of [3 nsub + 1] partials
+    double* partials = sums + 3 * (size_t)nsub + 1;
+    const int rows = std::min((n + 1023) / 1024, SNB_PARAM_SUM_ROWS);
     if (n > 0) {
         hipLaunchKernelGGL((k_particleParams<Real>), dim3((n + 255) / 256), dim3(256), 0, s, n, base, offStart, offGlobal, offDelta, globals, uCharge, uSigEps);
-        const int nb = std::min((n + 255) / 256, 512);
-        hipLaunchKernelGGL((k_paramSums<Real>), dim3(nb), dim3(256), sizeof(double) * 3 * nsub, s, n, nsub, uCharge, uSigEps, uSubset, sums);
+        hipLaunchKernelGGL((k_paramSums<Real>), dim3(rows), dim3(1024), sizeof(double) * 3 * nsub, s, n, nsub, uCharge, uSigEps, uSubset, partials);
     }
-    hipLaunchKernelGGL((k_fixScale<Real>), dim3(1), dim3(64), 0, s, sums, nsub, fix);
+    hipLaunchKernelGGL((k_fixScale<Real>), dim3(1), dim3(256), 0, s, partials, rows, nsub, sums, fix);
 }
 template <typename Real>
 void launchExceptionParams(int n, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals, const int* slice,

@@ -238,6 +238,7 @@ struct SliceFinish {
     double invVolume;         // 1 / V                                    (x dispersion coefficient)
 };
 void launchFinishSliceEnergies(const double* parts, double* out, int n, const SliceFinish& f, hipStream_t s);
+#define SNB_PARAM_SUM_ROWS 256      // work-groups of k_paramSums, each leaving one row of partial sums
 template <typename Real>
 void launchParticleParams(int n, int nsub, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals,
                           const int* uSubset, Real* uCharge, typename Vec<Real>::T2* uSigEps, double* sums, Real* fix, hipStream_t s);
