@@ -227,7 +227,7 @@ class Engine:
         self.capi = pkg.capi; self.L = pkg.capi.lib(); self.h = ctypes.c_void_p()
         cfg = self.capi.SnbConfig()
         cfg.abi_version = self.capi.SNB_ABI_VERSION; cfg.n_atoms = len(w["q"]); cfg.n_subsets = w["nsub"]; cfg.method = method
-        cfg.precision = 1 if precision == "double" else 0; cfg.device = device; cfg.cutoff = CUTOFF; cfg.rf_dielectric = 78.3
+        cfg.precision = {"single": 0, "double": 1, "mixed": 2}[precision]; cfg.device = device; cfg.cutoff = CUTOFF; cfg.rf_dielectric = 78.3
         cfg.alpha = ALPHA; cfg.grid[0] = cfg.grid[1] = cfg.grid[2] = grid
         cfg.alpha_d = ALPHA; cfg.dgrid[0] = cfg.dgrid[1] = cfg.dgrid[2] = max(dgrid, 1)
         cfg.neighbor_padding = padding; cfg.rebuild_interval = rebuild_interval
@@ -303,6 +303,7 @@ def main():
     ap.add_argument("--config", default=None)
     ap.add_argument("--padding", type=float, default=0.1, help="neighbour-list skin in nm")
     ap.add_argument("--rebuild-interval", type=int, default=20, help="re-sort atoms and rebuild the tile lists every this many steps (inside the timed region)")
+    ap.add_argument("--precision", default=None, choices=["single", "mixed", "double"], help="override the config's precision (mixed: single-precision arithmetic, 64-bit fixed-point force accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-balance", action="store_true", help="N > 1: keep the even i-block split instead of balancing direct-space work against the ranks' reciprocal work")
     ap.add_argument("--check", action="store_true", help="also compare forces/energies with the CPU oracle (slow at full size)")
@@ -333,6 +334,7 @@ def main():
     # whose 8 subset grids shard over the ranks (strong scaling; `config.one_gpu_value_same_workload` carries the 1-GPU rate of c4)
     cfg_name = args.config or ("c3" if world == 1 else "c4")
     n_target, Lbox, nsub, method, grid, dgrid, precision = CONFIGS[cfg_name]
+    precision = args.precision or precision
     pkg = importlib.import_module("openmm-nonbonded-slicing_amd")
     pkg.capi.build()
     w = build_workload(n_target, Lbox, nsub, np.random.default_rng(SEED))
@@ -499,7 +501,7 @@ def main():
                    "first_call_ms": round(first_ms, 1), "energy_step_ms": round(energy_ms, 3), "energy_step_gpu_ms": round(eng.stats().last_total_ms, 3),
                    "gpu_ms_per_step": round(gpu_ms, 4), "direct_kernel_ms": round(direct_ms, 4), "reciprocal_ms": round(recip_ms, 4),
                    "parallelism": ("subset-grid + i-block sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},
-        "roofline": {"bound": "hbm", "kernel": ("snb::k_directPacked<%d, true, false, false>" % (2 if method == 4 else 3)) if not is_double else "snb::k_direct<double, ...>",
+        "roofline": {"bound": "hbm", "kernel": ("snb::k_directPacked<%d, true, false, false, %s>" % (2 if method == 4 else 3, "true" if precision == "mixed" else "false")) if not is_double else "snb::k_direct<double, ...>",
                      "timing": "kernel begin/end stamps of hipExtLaunchKernelGGL on the eager steps of the timed region (snb_set_timing_interval: at least 5 of them)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(bytes_direct), "avg_launch_ms": round(direct_ms, 4)},
     }

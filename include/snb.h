@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SNB_ABI_VERSION 4
+#define SNB_ABI_VERSION 5
 
 typedef struct snb_engine* snb_handle;
 
@@ -46,7 +46,13 @@ typedef enum {
     SNB_NoCutoff = 0, SNB_CutoffNonPeriodic = 1, SNB_CutoffPeriodic = 2, SNB_Ewald = 3, SNB_PME = 4, SNB_LJPME = 5
 } snb_method;
 
-typedef enum { SNB_SINGLE = 0, SNB_DOUBLE = 1 } snb_precision;
+/* The precision modes of the reference's GPU platforms (CudaPlatform "Precision" property: single / mixed / double).
+ * SNB_MIXED: single-precision pair and mesh arithmetic as SNB_SINGLE, but the direct-space forces are accumulated in 64-bit fixed
+ * point (2^32 per kJ/mol/nm) the way the reference's GPU platforms accumulate every force (platforms/common/src/kernels/pme.cc:381-389,
+ * realToFixedPoint; CommonNonbondedSlicingKernels.cpp getLongForceBuffer): integer sums are independent of the order in which waves
+ * finish, so with the charge mesh already spread in fixed point the force of a step is reproducible bit for bit; the accumulators and
+ * the reciprocal part are summed in double on delivery.  Range: |force component| < 2^31 kJ/mol/nm (saturating), as in the reference. */
+typedef enum { SNB_SINGLE = 0, SNB_DOUBLE = 1, SNB_MIXED = 2 } snb_precision;
 
 typedef struct {
     int32_t abi_version;        /* SNB_ABI_VERSION                                                      */

@@ -82,7 +82,8 @@ public:
         snb_config cfg = {};
         cfg.abi_version = SNB_ABI_VERSION;
         cfg.n_atoms = numParticles;  cfg.n_subsets = numSubsets;  cfg.method = method;
-        cfg.precision = useDouble ? SNB_DOUBLE : SNB_SINGLE;
+        // Precision property of the platform: single / mixed / double.  mixed: float arithmetic, 64-bit fixed-point force sums (snb.h SNB_MIXED)
+        cfg.precision = useDouble ? SNB_DOUBLE : (cu.getUseMixedPrecision() ? SNB_MIXED : SNB_SINGLE);
         cfg.use_switch = force.getUseSwitchingFunction();  cfg.switch_distance = force.getSwitchingDistance();
         cfg.cutoff = force.getCutoffDistance();  cfg.rf_dielectric = force.getReactionFieldDielectric();
         cfg.exceptions_periodic = force.getExceptionsUsePeriodicBoundaryConditions();

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNB_LIB_PATH") or os.path.join(_HERE, "libsnb_hip.so")      # (SNB_LIB_PATH: an experimental build of the same ABI, tools/ only)
-SNB_ABI_VERSION = 4
+SNB_ABI_VERSION = 5
 
 # every symbol include/snb.h declares (tests check the library exports each one)
 SYMBOLS = [

@@ -110,7 +110,7 @@ class HipCalcSlicedNonbondedForceKernel:
         cfg.n_atoms = self.numParticles; cfg.n_subsets = self.numSubsets
         method = force.getNonbondedMethod()
         cfg.method = method
-        cfg.precision = 1 if self.precision == "double" else 0
+        cfg.precision = {"single": 0, "double": 1, "mixed": 2}[self.precision]
         cfg.use_switch = int(force.getUseSwitchingFunction() and method != SlicedNonbondedForce.NoCutoff)
         cfg.exceptions_periodic = int(force.getExceptionsUsePeriodicBoundaryConditions())
         cfg.device = self.device

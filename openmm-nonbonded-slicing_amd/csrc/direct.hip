@@ -53,6 +53,21 @@ __device__ inline void ldsAdd(float* p, float v) { __hip_atomic_fetch_add(p, v, 
 __device__ inline void ldsAdd(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void gAdd(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void gAdd(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Force accumulation of atom slot `a`.  SNB_MIXED engines (P::fixed) keep the direct-space accumulators as 64-bit fixed point, 2^32 per
+// kJ/mol/nm, the way every GPU platform of the reference does (realToFixedPoint; CommonNonbondedSlicingKernels.cpp adds into
+// getLongForceBuffer, pme.cc:381-389): integer sums do not depend on the order in which waves arrive, so the force of a step is
+// reproducible bit for bit.  The component arrays are then arrays of 64-bit words behind the same base pointers.
+__device__ inline unsigned long long toFixedForce(float v) { return (unsigned long long)(long long)(v * 4294967296.0f); }
+template <typename P> __device__ inline void fAdd(const P& p, float* comp, size_t a, float v) {
+    if (p.fixed) { __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(comp) + a * p.fs, toFixedForce(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    gAdd(comp + a * p.fs, v);
+}
+template <typename P> __device__ inline void fAdd(const P& p, double* comp, size_t a, double v) { gAdd(comp + a * p.fs, v); }
+// (the packed tile kernel takes the choice as a template parameter: the run-time test cost the default path 2.7 % on c3)
+template <bool FIXED, typename P> __device__ inline void fAddT(const P& p, float* comp, size_t a, float v) {
+    if constexpr (FIXED) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(comp) + a * p.fs, toFixedForce(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else gAdd(comp + a * p.fs, v);
+}
 
 __device__ inline double waveSum(double v) {
 #pragma unroll
@@ -317,12 +332,12 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
         fjx += __shfl_xor(fjx, 16, 64); fjy += __shfl_xor(fjy, 16, 64); fjz += __shfl_xor(fjz, 16, 64);
         if ((row & 1) == 0 && curCode != -1) {            // lanes 0-15 (j-half 0) and 32-47 (j-half 1): entry `lane` == j-slot
             const int jidx = curCode & SNB_JIDX_MASK;
-            gAdd(&p.fx[jidx * p.fs], fjx); gAdd(&p.fy[jidx * p.fs], fjy); gAdd(&p.fz[jidx * p.fs], fjz);
+            fAdd(p, p.fx, jidx, fjx); fAdd(p, p.fy, jidx, fjy); fAdd(p, p.fz, jidx, fjz);
         }
     }
     // rows r and r^2 hold the same i-atoms (different j-halves)
     fix += __shfl_xor(fix, 32, 64); fiy += __shfl_xor(fiy, 32, 64); fiz += __shfl_xor(fiz, 32, 64);
-    if (row < 2) { gAdd(&p.fx[(I * 32 + il) * p.fs], fix); gAdd(&p.fy[(I * 32 + il) * p.fs], fiy); gAdd(&p.fz[(I * 32 + il) * p.fs], fiz); }
+    if (row < 2) { fAdd(p, p.fx, (I * 32 + il), fix); fAdd(p, p.fy, (I * 32 + il), fiy); fAdd(p, p.fz, (I * 32 + il), fiz); }
     if (ENERGY && curSlice >= 0) {
         double a = waveSum((double)ecl), b = waveSum((double)elj);
         if (lane == 0) { atomicAdd(&sliceE[2 * curSlice], a); atomicAdd(&sliceE[2 * curSlice + 1], b); }
@@ -452,7 +467,7 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
 
 // The first nListBlocks work-groups of the launch run the O(N) pair lists (exclusion corrections, then 1-4 exceptions: latency-bound
 // work that overlaps the VALU-bound tile work instead of trailing it as a launch of its own); the others loop over tile work items.
-template <int MC, bool POLY, bool ENERGY, bool SWITCH>
+template <int MC, bool POLY, bool ENERGY, bool SWITCH, bool FIXED>
 __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<float> p, const PairListParams<float> q, const int nExclBlocks, const int nListBlocks) {
     if ((int)blockIdx.x < nListBlocks) {      // (energy steps: the list bodies reduce their slice energies in 2 S doubles of dynamic LDS)
         if ((int)blockIdx.x < nExclBlocks) { PairListParams<float> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<float, ENERGY>(qe, blockIdx.x); }
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     // (the j-force atomics of a tile are issued at the start of the NEXT trip: an atomic sits behind a conditional skip the wait-count
     // pass cannot count, so any wait after it degrades to "everything"; issued first, they are a whole tile old when that wait comes)
     float pendX = 0.f, pendY = 0.f, pendZ = 0.f; int pendIdx = -1;
-    auto flushPending = [&]() { if (pendIdx >= 0) { gAdd(&p.fx[pendIdx * p.fs], pendX); gAdd(&p.fy[pendIdx * p.fs], pendY); gAdd(&p.fz[pendIdx * p.fs], pendZ); } };
+    auto flushPending = [&]() { if (pendIdx >= 0) { fAddT<FIXED>(p, p.fx, pendIdx, pendX); fAddT<FIXED>(p, p.fy, pendIdx, pendY); fAddT<FIXED>(p, p.fz, pendIdx, pendZ); } };
     auto requestList = [&](TileRegs& r, int t) {                    // list entry + header of tile t
         r.jcode = p.tileJ[t * 32 + stageJ];
         const int2 v = *reinterpret_cast<const int2*>(&p.tileInfo[t + vzero]);
@@ -588,8 +603,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     ux += __shfl_xor(ux, 16, 64); uy += __shfl_xor(uy, 16, 64); uz += __shfl_xor(uz, 16, 64);
     ox += __shfl_xor(ox, 32, 64); oy += __shfl_xor(oy, 32, 64); oz += __shfl_xor(oz, 32, 64);
     ux += __shfl_xor(ux, 32, 64); uy += __shfl_xor(uy, 32, 64); uz += __shfl_xor(uz, 32, 64);
-    if (row == 0) { gAdd(&p.fx[(I * 32 + c) * p.fs], ox); gAdd(&p.fy[(I * 32 + c) * p.fs], oy); gAdd(&p.fz[(I * 32 + c) * p.fs], oz); }
-    if (row == 1) { gAdd(&p.fx[(I * 32 + 16 + c) * p.fs], ux); gAdd(&p.fy[(I * 32 + 16 + c) * p.fs], uy); gAdd(&p.fz[(I * 32 + 16 + c) * p.fs], uz); }
+    if (row == 0) { fAddT<FIXED>(p, p.fx, (I * 32 + c), ox); fAddT<FIXED>(p, p.fy, (I * 32 + c), oy); fAddT<FIXED>(p, p.fz, (I * 32 + c), oz); }
+    if (row == 1) { fAddT<FIXED>(p, p.fx, (I * 32 + 16 + c), ux); fAddT<FIXED>(p, p.fy, (I * 32 + 16 + c), uy); fAddT<FIXED>(p, p.fz, (I * 32 + 16 + c), uz); }
     if (ENERGY) { flushEnergy(); curSlice = -1; }
     __builtin_amdgcn_wave_barrier();
     }   // work-item loop
@@ -866,7 +881,7 @@ __global__ __launch_bounds__(256, 3) void k_directSub(const DirectParams<float> 
             }
             if (jl == g) {
                 const int a0 = I * 32 + 8 * g + 2 * ip;
-                gAdd(&p.fx[a0 * p.fs], v[0]); gAdd(&p.fy[a0 * p.fs], v[2]); gAdd(&p.fz[a0 * p.fs], v[4]); gAdd(&p.fx[(a0 + 1) * p.fs], v[1]); gAdd(&p.fy[(a0 + 1) * p.fs], v[3]); gAdd(&p.fz[(a0 + 1) * p.fs], v[5]);
+                fAdd(p, p.fx, a0, v[0]); fAdd(p, p.fy, a0, v[2]); fAdd(p, p.fz, a0, v[4]); fAdd(p, p.fx, (a0 + 1), v[1]); fAdd(p, p.fy, (a0 + 1), v[3]); fAdd(p, p.fz, (a0 + 1), v[5]);
             }
         }
         if (ENERGY) { flushEnergy(); curSlice = -1; }
@@ -908,7 +923,8 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
                     return lists != nullptr && !energy;
                 }
             }
-#define SNB_PACKED(P, E, S) SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S>), gridAll, listLds, p, q, nExclBlocks, nListBlocks)
+#define SNB_PACKED(P, E, S) do { if (p.fixed) SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S, true>), gridAll, listLds, p, q, nExclBlocks, nListBlocks); \
+                                 else SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S, false>), gridAll, listLds, p, q, nExclBlocks, nListBlocks); } while (0)
             if constexpr (MC == MC_NOCUTOFF) { if (energy) SNB_PACKED(false, true, false); else SNB_PACKED(false, false, false); }
             else if (p.useSwitch && MC != MC_LJPME) {      // (no switching function under LJPME, Q2)
                 if (energy) { if (poly) SNB_PACKED(true, true, true); else SNB_PACKED(false, true, true); }
@@ -967,8 +983,8 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exceptions
         const Real lamC = p.lambdas[2 * slice], lamL = p.lambdas[2 * slice + 1];
         Real dEdR = lamL * par.y * (Real(12) * s6 - Real(6)) * s6 + lamC * par.z * invR;
         dEdR *= invR * invR;
-        gAdd(&p.fx[ij.x * p.fs], dEdR * dx); gAdd(&p.fy[ij.x * p.fs], dEdR * dy); gAdd(&p.fz[ij.x * p.fs], dEdR * dz);
-        gAdd(&p.fx[ij.y * p.fs], -dEdR * dx); gAdd(&p.fy[ij.y * p.fs], -dEdR * dy); gAdd(&p.fz[ij.y * p.fs], -dEdR * dz);
+        fAdd(p, p.fx, ij.x, dEdR * dx); fAdd(p, p.fy, ij.x, dEdR * dy); fAdd(p, p.fz, ij.x, dEdR * dz);
+        fAdd(p, p.fx, ij.y, -dEdR * dx); fAdd(p, p.fy, ij.y, -dEdR * dy); fAdd(p, p.fz, ij.y, -dEdR * dz);
         if (ENERGY && p.sliceNeed[slice]) { e0 = par.z * invR; e1 = par.y * (s6 - Real(1)) * s6; }
     }
     if (ENERGY) {
@@ -1047,7 +1063,7 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
                 }
                 fx += f * dx; fy += f * dy; fz += f * dz;
             }
-            gAdd(&p.fx[a * p.fs], fx); gAdd(&p.fy[a * p.fs], fy); gAdd(&p.fz[a * p.fs], fz);   // atomics: the 1-4 blocks of the same launch add to the same atoms
+            fAdd(p, p.fx, a, fx); fAdd(p, p.fy, a, fy); fAdd(p, p.fz, a, fz);   // atomics: the 1-4 blocks of the same launch add to the same atoms
         }
     }
     if (ENERGY) {

@@ -221,10 +221,20 @@ public:
     }
     bool recordForces() const {
         static const bool soa = getenv("SNB_FORCE_SOA") != nullptr;
-        return sizeof(Real) == 4 && cfg.method != SNB_NoCutoff && !cfg.host_neighbor_build && subTileMode() != 0 && !soa;
+        return sizeof(Real) == 4 && cfg.precision != SNB_MIXED && cfg.method != SNB_NoCutoff && !cfg.host_neighbor_build && subTileMode() != 0 && !soa;
     }
+    // SNB_MIXED: single-precision arithmetic, direct-space forces accumulated in 64-bit fixed point (direct.hip, fAdd) -- three arrays of
+    // Npad 64-bit words (6 Npad floats, one spare), then the three reciprocal arrays: 10 Npad floats, all cleared by the gather pass
+    bool fixedForces() const { return sizeof(Real) == 4 && cfg.precision == SNB_MIXED; }
+    int forceArrays() const { return fixedForces() ? 10 : 7; }
     void layoutForces() {
-        forceBuf.resize((size_t)7 * Npad);
+        forceBuf.resize((size_t)forceArrays() * Npad);
+        if (fixedForces()) {
+            fstride = 1;
+            fx.p = forceBuf.p; fy.p = fx.p + 2 * (size_t)Npad; fz.p = fx.p + 4 * (size_t)Npad;      // bases of 64-bit arrays
+            fpx.p = forceBuf.p + 7 * (size_t)Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
+            return;
+        }
         fstride = recordForces() ? 4 : 1;
         fx.p = forceBuf.p; fy.p = fx.p + (fstride == 4 ? 1 : Npad); fz.p = fx.p + (fstride == 4 ? 2 : 2 * (size_t)Npad);
         fpx.p = forceBuf.p + 4 * (size_t)Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
@@ -1242,7 +1252,7 @@ public:
             const double half = 0.5 * cfg.neighbor_padding;
             gc.fail2 = (Real)(half * half); gc.warn2 = (Real)(0.64 * half * half);      // rebuild request at 80 % of skin/2: the flag is read one step late
         }
-        launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, forceBuf.p, gc, stream);
+        launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, forceBuf.p, forceArrays(), gc, stream);
         if (energy) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2 * SNB_SLICE_E_PARTS, stream));
         const bool ew = cfg.method >= SNB_Ewald;
         // Opt-in (SNB_CONCURRENT_PME=1): forces-only graph steps run the reciprocal pipeline on a second stream beside the pair
@@ -1259,7 +1269,7 @@ public:
         // O(N) pair lists: one rank only when sharded -- the LAST one, which carries no PME grid once there are more ranks than grids
         const bool haveLists = includeDirect && cfg.shard_rank == cfg.shard_count - 1;
         if (haveLists) {
-            q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.fs = fstride; q.sliceE = sliceE.p; q.lambdas = dLambdas.p; q.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p;
+            q.posq = posq.p; q.fx = fx.p; q.fy = fy.p; q.fz = fz.p; q.fs = fstride; q.fixed = fixedForces(); q.sliceE = sliceE.p; q.lambdas = dLambdas.p; q.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p;
             const bool exPeriodic = (cfg.method == SNB_NoCutoff || cfg.method == SNB_CutoffNonPeriodic) ? false : cfg.exceptions_periodic != 0;
             q.periodic = exPeriodic ? 1 : 0; q.imageOffset = imageOffset.p;
             q.sigeps = sigeps.p; q.blockSubset = blockSubset.p; q.exclStart = exclStart.p; q.exclList = exclList.p; q.nSlices = S; q.sortedToUser = dSortedToUser.p; q.userToSorted = dUserToSorted.p;
@@ -1273,10 +1283,10 @@ public:
             DirectParams<Real> p;
             std::memset(&p, 0, sizeof(p));
             p.posq = posq.p; p.sigeps = sigeps.p; p.blockSubset = blockSubset.p; p.workItems = workItems.p;
-            p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.fs = fstride; p.sliceE = sliceE.p; p.lambdas = dLambdas.p; p.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p;
+            p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.fs = fstride; p.fixed = fixedForces(); p.sliceE = sliceE.p; p.lambdas = dLambdas.p; p.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p;
             const int r = cfg.shard_rank, c = cfg.shard_count;
             (void)r; (void)c;
-            p.subTiles = (gpuBuilt && !wrapMode && subTileMode() != 0) ? 1 : 0;
+            p.subTiles = (gpuBuilt && !wrapMode && subTileMode() != 0 && !fixedForces()) ? 1 : 0;
             p.workStart = 0; p.workStride = 1; p.numWork = numWorkItems;      // the lists hold only the i-blocks this engine owns (block % shard_count == shard_rank)
             p.nsub = nsub;
             p.cutoff2 = (Real)(cfg.cutoff * cfg.cutoff);
@@ -1318,7 +1328,7 @@ public:
                 const bool canFinish = outPtr && !fork && !noFuse && cfg.shard_count == 1;
                 auto withOutput = [&](PmeParams<Real>& q, bool last) {
                     q.outForces = (canFinish && last) ? outPtr : nullptr; q.outIsDouble = outIsDouble; q.outAccumulate = outAccumulate;
-                    q.dfx = fx.p; q.dfy = fy.p; q.dfz = fz.p; q.dfs = fstride; q.sortedToUser = dSortedToUser.p;
+                    q.dfx = fx.p; q.dfy = fy.p; q.dfz = fz.p; q.dfs = fstride; q.dfixed = fixedForces(); q.sortedToUser = dSortedToUser.p;
                 };
                 fillPme(pp, pme, energy); withOutput(pp, cfg.method != SNB_LJPME);
                 finished = runPme(pp, pmeStream);
@@ -1329,7 +1339,7 @@ public:
         if (includeRecip && cfg.method == SNB_Ewald && cfg.shard_rank == 0) runEwald(energy);
         if (outPtr && !finished) {   // the step's last kernel: user-order forces into the caller's buffer (part of the graph)
             const bool recipDone = includeRecip && (isPme() || cfg.method == SNB_Ewald);
-            launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, recipDone ? fpx.p : nullptr, fpy.p, fpz.p, dUserToSorted.p, N, outPtr, outIsDouble, outAccumulate, stream);
+            launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, fixedForces(), recipDone ? fpx.p : nullptr, fpy.p, fpz.p, dUserToSorted.p, N, outPtr, outIsDouble, outAccumulate, stream);
         }
         if (energy) {
             // closed-form terms on the device (rank 0 only when sharded), as the reference GPU path keeps them next to its kernels
@@ -1398,10 +1408,10 @@ public:
         if (isDevice && out == outPtr && isDouble == outIsDouble && outputWritten) return;   // the last execute already delivered them there
         const size_t bytes = (size_t)N * 3 * (isDouble ? 8 : 4);
         const Real* px = lastRecip ? fpx.p : nullptr;
-        if (isDevice) { launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, px, fpy.p, fpz.p, dUserToSorted.p, N, out, isDouble, accumulate, stream); return; }
+        if (isDevice) { launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, fixedForces(), px, fpy.p, fpz.p, dUserToSorted.p, N, out, isDouble, accumulate, stream); return; }
         DevBuf<unsigned char> tmp; tmp.resize(bytes);
         if (accumulate) HIPCHECK(hipMemcpyAsync(tmp.p, out, bytes, hipMemcpyHostToDevice, stream));
-        launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, px, fpy.p, fpz.p, dUserToSorted.p, N, tmp.p, isDouble, accumulate, stream);
+        launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, fixedForces(), px, fpy.p, fpz.p, dUserToSorted.p, N, tmp.p, isDouble, accumulate, stream);
         HIPCHECK(hipMemcpyAsync(out, tmp.p, bytes, hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
     }
@@ -1485,7 +1495,7 @@ snb_status snb_create(const snb_config* cfg, snb_handle* out) {
     if (!cfg || !out) { g_createError = "null argument"; return SNB_ERR_INVALID_ARGUMENT; }
     *out = nullptr;
     if (cfg->abi_version != SNB_ABI_VERSION) { g_createError = "snb_config.abi_version mismatch"; return SNB_ERR_INVALID_ARGUMENT; }
-    if (cfg->n_atoms < 0 || cfg->n_subsets < 1 || cfg->method < 0 || cfg->method > 5 || (cfg->precision != SNB_SINGLE && cfg->precision != SNB_DOUBLE)) {
+    if (cfg->n_atoms < 0 || cfg->n_subsets < 1 || cfg->method < 0 || cfg->method > 5 || (cfg->precision != SNB_SINGLE && cfg->precision != SNB_DOUBLE && cfg->precision != SNB_MIXED)) {
         g_createError = "invalid n_atoms / n_subsets / method / precision"; return SNB_ERR_INVALID_ARGUMENT;
     }
     if (cfg->method != SNB_NoCutoff && !(cfg->cutoff > 0)) { g_createError = "cutoff must be positive"; return SNB_ERR_INVALID_ARGUMENT; }

@@ -11,12 +11,11 @@ namespace snb {
 template <typename Real, typename In>
 __global__ void k_gatherPositions(const In* __restrict__ userPos, int stride, const int* __restrict__ sortedToUser,
                                   const Real* __restrict__ imageOffset, typename Vec<Real>::T4* __restrict__ posq, int nPadded,
-                                  Real* __restrict__ forces, const GatherCells<Real> gc) {
+                                  Real* __restrict__ forces, int nClear, const GatherCells<Real> gc) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nPadded) return;
     if (forces) {
-#pragma unroll
-        for (int k = 0; k < 7; k++) forces[(size_t)k * nPadded + s] = Real(0);      // 4 n direct-space (either layout) + 3 n reciprocal
+        for (int k = 0; k < nClear; k++) forces[(size_t)k * nPadded + s] = Real(0);      // 7: 4 n direct-space (either layout) + 3 n reciprocal; 10 with 64-bit accumulators
     }
     const int u = sortedToUser[s];
     if (u < 0) { if (gc.cells) gc.cells[s] = -1; return; }
@@ -44,12 +43,12 @@ __global__ void k_gatherPositions(const In* __restrict__ userPos, int stride, co
 
 template <typename Real>
 void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
-                           typename Vec<Real>::T4* posq, int nPadded, Real* forces, const GatherCells<Real>& gc, hipStream_t s) {
+                           typename Vec<Real>::T4* posq, int nPadded, Real* forces, int nClear, const GatherCells<Real>& gc, hipStream_t s) {
     if (nPadded <= 0) return;
     dim3 grid((nPadded + 255) / 256), block(256);
     const int stride = stride4 ? 4 : 3;
-    if (isDouble) hipLaunchKernelGGL((k_gatherPositions<Real, double>), grid, block, 0, s, (const double*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, gc);
-    else hipLaunchKernelGGL((k_gatherPositions<Real, float>), grid, block, 0, s, (const float*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, gc);
+    if (isDouble) hipLaunchKernelGGL((k_gatherPositions<Real, double>), grid, block, 0, s, (const double*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, nClear, gc);
+    else hipLaunchKernelGGL((k_gatherPositions<Real, float>), grid, block, 0, s, (const float*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, nClear, gc);
 }
 
 // In-place refresh of the sorted per-atom parameters from the user-order values (parameter offsets / updateParametersInContext)
@@ -73,25 +72,30 @@ template void launchRefreshParams<float>(const int*, const float*, const Vec<flo
 template void launchRefreshParams<double>(const int*, const double*, const Vec<double>::T2*, Vec<double>::T4*, Vec<double>::T2*, int, hipStream_t);
 
 template <typename Real, typename Out>
-__global__ void k_finishForces(const Real* __restrict__ fx, const Real* __restrict__ fy, const Real* __restrict__ fz, int fs,
+__global__ void k_finishForces(const Real* __restrict__ fx, const Real* __restrict__ fy, const Real* __restrict__ fz, int fs, int fixed,
                                const Real* __restrict__ fpx, const Real* __restrict__ fpy, const Real* __restrict__ fpz,
                                const int* __restrict__ userToSorted, int nAtoms, Out* __restrict__ out, int accumulate) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nAtoms) return;
     const int s = userToSorted[u];
-    Out x = (Out)fx[(size_t)s * fs], y = (Out)fy[(size_t)s * fs], z = (Out)fz[(size_t)s * fs];
+    Out x, y, z;
+    if (fixed) {      // 64-bit fixed point, 2^32 per unit (SNB_MIXED)
+        x = (Out)((double)reinterpret_cast<const long long*>(fx)[(size_t)s * fs] * (1.0 / 4294967296.0));
+        y = (Out)((double)reinterpret_cast<const long long*>(fy)[(size_t)s * fs] * (1.0 / 4294967296.0));
+        z = (Out)((double)reinterpret_cast<const long long*>(fz)[(size_t)s * fs] * (1.0 / 4294967296.0));
+    } else { x = (Out)fx[(size_t)s * fs]; y = (Out)fy[(size_t)s * fs]; z = (Out)fz[(size_t)s * fs]; }
     if (fpx) { x += (Out)fpx[s]; y += (Out)fpy[s]; z += (Out)fpz[s]; }
     if (accumulate) { x += out[3 * (size_t)u]; y += out[3 * (size_t)u + 1]; z += out[3 * (size_t)u + 2]; }
     out[3 * (size_t)u] = x; out[3 * (size_t)u + 1] = y; out[3 * (size_t)u + 2] = z;
 }
 
 template <typename Real>
-void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, int fs, const Real* fpx, const Real* fpy, const Real* fpz,
+void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, int fs, int fixed, const Real* fpx, const Real* fpy, const Real* fpz,
                         const int* userToSorted, int nAtoms, void* out, int isDouble, int accumulate, hipStream_t s) {
     if (nAtoms <= 0) return;
     dim3 grid((nAtoms + 255) / 256), block(256);
-    if (isDouble) hipLaunchKernelGGL((k_finishForces<Real, double>), grid, block, 0, s, fx, fy, fz, fs, fpx, fpy, fpz, userToSorted, nAtoms, (double*)out, accumulate);
-    else hipLaunchKernelGGL((k_finishForces<Real, float>), grid, block, 0, s, fx, fy, fz, fs, fpx, fpy, fpz, userToSorted, nAtoms, (float*)out, accumulate);
+    if (isDouble) hipLaunchKernelGGL((k_finishForces<Real, double>), grid, block, 0, s, fx, fy, fz, fs, fixed, fpx, fpy, fpz, userToSorted, nAtoms, (double*)out, accumulate);
+    else hipLaunchKernelGGL((k_finishForces<Real, float>), grid, block, 0, s, fx, fy, fz, fs, fixed, fpx, fpy, fpz, userToSorted, nAtoms, (float*)out, accumulate);
 }
 
 // ---- effective parameters on the device (the reference: nonbondedParameters.cc computeParameters :4-137, computePlasmaCorrection :139-179) ----
@@ -252,9 +256,9 @@ void launchFinishSliceEnergies(const double* parts, double* out, int n, const Sl
     if (n > 0) hipLaunchKernelGGL(k_finishSliceEnergies, dim3((n + 63) / 64), dim3(64), 0, s, parts, out, n, f);
 }
 
-template void launchGatherPositions<float>(const void*, int, int, const int*, const float*, Vec<float>::T4*, int, float*, const GatherCells<float>&, hipStream_t);
-template void launchGatherPositions<double>(const void*, int, int, const int*, const double*, Vec<double>::T4*, int, double*, const GatherCells<double>&, hipStream_t);
-template void launchFinishForces<float>(const float*, const float*, const float*, int, const float*, const float*, const float*, const int*, int, void*, int, int, hipStream_t);
-template void launchFinishForces<double>(const double*, const double*, const double*, int, const double*, const double*, const double*, const int*, int, void*, int, int, hipStream_t);
+template void launchGatherPositions<float>(const void*, int, int, const int*, const float*, Vec<float>::T4*, int, float*, int, const GatherCells<float>&, hipStream_t);
+template void launchGatherPositions<double>(const void*, int, int, const int*, const double*, Vec<double>::T4*, int, double*, int, const GatherCells<double>&, hipStream_t);
+template void launchFinishForces<float>(const float*, const float*, const float*, int, int, const float*, const float*, const float*, const int*, int, void*, int, int, hipStream_t);
+template void launchFinishForces<double>(const double*, const double*, const double*, int, int, const double*, const double*, const double*, const int*, int, void*, int, int, hipStream_t);
 
 }  // namespace snb

@@ -1183,6 +1183,19 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
                     auto deliver = [&](Real rx_, Real ry_, Real rz_) {
                         const int u = p.sortedToUser[a];
                         if (u < 0) return;
+                        if (p.dfixed) {      // SNB_MIXED: 64-bit fixed-point accumulators, summed with the reciprocal part in double
+                            const double k = 1.0 / 4294967296.0;
+                            const double X = (double)reinterpret_cast<const long long*>(p.dfx)[(size_t)a * p.dfs] * k + (double)rx_, Y = (double)reinterpret_cast<const long long*>(p.dfy)[(size_t)a * p.dfs] * k + (double)ry_,
+                                         Z = (double)reinterpret_cast<const long long*>(p.dfz)[(size_t)a * p.dfs] * k + (double)rz_;
+                            if (p.outIsDouble) {
+                                double* o = reinterpret_cast<double*>(p.outForces) + 3 * (size_t)u;
+                                if (p.outAccumulate) { o[0] += X; o[1] += Y; o[2] += Z; } else { o[0] = X; o[1] = Y; o[2] = Z; }
+                            } else {
+                                float* o = reinterpret_cast<float*>(p.outForces) + 3 * (size_t)u;
+                                if (p.outAccumulate) { o[0] += (float)X; o[1] += (float)Y; o[2] += (float)Z; } else { o[0] = (float)X; o[1] = (float)Y; o[2] = (float)Z; }
+                            }
+                            return;
+                        }
                         const Real X = p.dfx[(size_t)a * p.dfs] + rx_, Y = p.dfy[(size_t)a * p.dfs] + ry_, Z = p.dfz[(size_t)a * p.dfs] + rz_;
                         if (p.outIsDouble) {
                             double* o = reinterpret_cast<double*>(p.outForces) + 3 * (size_t)u;

@@ -50,6 +50,7 @@ template <typename Real> struct DirectParams {
     const int4* tileInfo;     // [T]
     const unsigned* masks;    // [M*32]
     Real* fx; Real* fy; Real* fz; int fs;   // direct-space force accumulators: component bases and the index stride of an atom (1: three arrays; 4: one (x,y,z,-) record per atom)
+    int fixed;                              // SNB_MIXED: the accumulators are 64-bit fixed point (2^32 per kJ/mol/nm) behind the same bases
     double* sliceE;           // [S*2] raw energies
     const Real* lambdas;      // [S*2]
     const int* sliceNeed;     // [S] energy steps: non-zero = this slice's raw energies are wanted (derivative-only steps ask for a few slices)
@@ -79,7 +80,7 @@ template <typename Real> struct PairListParams {  // 1-4 exceptions: one thread 
     const typename Vec<Real>::T4* params;   // 1-4: (sigma, 4 eps, k*qq, slice bits) ; exclusion: (k*qi*qj, c6i*c6j, -, slice bits)
     int n;                    // number of 1-4 pairs
     int nExclAtoms;           // atoms visited by the exclusion-correction part (0: none)
-    Real* fx; Real* fy; Real* fz; int fs;
+    Real* fx; Real* fy; Real* fz; int fs, fixed;
     double* sliceE;
     const Real* lambdas;
     const int* sliceNeed;     // [S] as in DirectParams
@@ -132,7 +133,7 @@ template <typename Real> struct PmeParams {
     // brick interpolation of the step's LAST mesh, unsharded: the atom's thread also writes the step's user-order force,
     // direct-space accumulator + reciprocal force, into the caller's buffer (what k_finishForces does as a launch of its own)
     void* outForces; int outIsDouble, outAccumulate;      // [N][3] in the caller's type, or null
-    const Real* dfx; const Real* dfy; const Real* dfz; int dfs;   // direct-space accumulators (component bases, atom stride)
+    const Real* dfx; const Real* dfy; const Real* dfz; int dfs, dfixed;   // direct-space accumulators (component bases, atom stride, 64-bit fixed point)
     const int* sortedToUser;
 };
 
@@ -222,10 +223,10 @@ template <typename Real> struct GatherCells {
 };
 
 template <typename Real> void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
-                                                    typename Vec<Real>::T4* posq, int nPadded, Real* forces, const GatherCells<Real>& gc, hipStream_t s);      // forces: 7 * nPadded values cleared
+                                                    typename Vec<Real>::T4* posq, int nPadded, Real* forces, int nClear, const GatherCells<Real>& gc, hipStream_t s);      // forces: 7 * nPadded values cleared
 template <typename Real> void launchRefreshParams(const int* sortedToUser, const Real* uCharge, const typename Vec<Real>::T2* uSigEps, typename Vec<Real>::T4* posq,
                                                   typename Vec<Real>::T2* sigeps, int nPadded, hipStream_t s);
-template <typename Real> void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, int fs, const Real* fpx, const Real* fpy, const Real* fpz,
+template <typename Real> void launchFinishForces(const Real* fx, const Real* fy, const Real* fz, int fs, int fixed, const Real* fpx, const Real* fpy, const Real* fpz,
                                                  const int* userToSorted, int nAtoms, void* out, int isDouble, int accumulate, hipStream_t s);
 
 // closed-form terms of the raw slice energies (k_finishSliceEnergies); a null pointer / zero factor switches a term off

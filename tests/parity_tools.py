@@ -25,7 +25,7 @@ import bench
 # relative half-width of the undecidable band in r^2.  Single precision, coordinates below 16 nm (ulp 9.5e-7 nm): each stored coordinate
 # is off by <= 4.8e-7 nm (user + image offset, rounded once), a lattice-shifted j by as much again, so r^2 = 1 nm^2 is off by at most
 # 2 * sqrt(3) * 1.4e-6 = 5e-6 (all roundings extreme and aligned), 1e-6 rms.
-BAND_REL = {"single": 6e-6, "double": 0.0}
+BAND_REL = {"single": 6e-6, "mixed": 6e-6, "double": 0.0}
 
 
 def float_positions(w):
