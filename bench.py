@@ -542,7 +542,7 @@ def main():
         import parity_tools as pt
         wc = pt.float_positions(w) if not is_double else w
         fo, so, _, _ = oracle_eval(wc, method, grid, dgrid)
-        fa, ea, nband = pt.band_allowance(wc, method, grid, dgrid, pt.BAND_REL[precision])
+        fa, ea, nband = pt.band_allowance(wc, method, grid, dgrid, pt.band_rel(wc, precision))
         tol = 1e-5 if is_double else 1e-3
         eng.rebuild()
         eng.set_positions_device(pos0.data_ptr(), is_double); eng.execute(True); eng.forces_to(forces.data_ptr(), is_double); eng.sync()

@@ -1113,7 +1113,7 @@ public:
         const double det = box[0] * box[4] * box[8], sc = 1.0 / det;
         const double r[9] = {box[4] * box[8] * sc, 0, 0, -box[3] * box[8] * sc, box[0] * box[8] * sc, 0,
                              (box[3] * box[7] - box[4] * box[6]) * sc, -box[0] * box[7] * sc, box[0] * box[4] * sc};
-        for (int i = 0; i < 9; i++) p.recip[i] = (Real)r[i];
+        for (int i = 0; i < 9; i++) { p.recip[i] = (Real)r[i]; p.recipLo[i] = (Real)(r[i] - (double)p.recip[i]); }
         p.alpha = (Real)plan.alpha; p.volume = (Real)det; p.dispersion = plan.dispersion ? 1 : 0;
         p.lambdas = dLambdas.p; p.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p; p.gridSubset = gridSubset.p; p.nsubTotal = nsub; p.mix = cfg.shard_count == 1 ? 1 : 0;
         p.sliceE = sliceE.p; p.fpx = fpx.p; p.fpy = fpy.p; p.fpz = fpz.p; p.wantEnergy = wantEnergy ? 1 : 0;
@@ -1242,7 +1242,7 @@ public:
             std::memset(&pp, 0, sizeof(pp));
             fillPme(pp, pme, false);
             if (pp.sortNcx > 0 && pp.colRange != nullptr) {
-                for (int i = 0; i < 9; i++) gc.recip[i] = pp.recip[i];
+                for (int i = 0; i < 9; i++) { gc.recip[i] = pp.recip[i]; gc.recipLo[i] = pp.recipLo[i]; }
                 gc.nx = pp.d.nx; gc.ny = pp.d.ny; gc.nz = pp.d.nz; gc.cells = pp.cells; gc.atomGrid = pp.atomGrid;
                 cellsFromGather = true;
             }

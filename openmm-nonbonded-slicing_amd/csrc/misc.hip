@@ -34,7 +34,7 @@ __global__ void k_gatherPositions(const In* __restrict__ userPos, int stride, co
         int cell = -1;
         if (gc.atomGrid[s] >= 0 && v.w != Real(0)) {
             int idx[3]; Real fr[3];
-            gridCoord<Real>(gc.recip, v.x, v.y, v.z, gc.nx, gc.ny, gc.nz, idx, fr);
+            gridCoord<Real>(gc.recip, gc.recipLo, v.x, v.y, v.z, gc.nx, gc.ny, gc.nz, idx, fr);
             cell = idx[0] | (idx[1] << 10) | (idx[2] << 20);
         }
         gc.cells[s] = cell;

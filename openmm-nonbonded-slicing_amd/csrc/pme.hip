@@ -87,7 +87,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_spread(const P
     if (q == Real(0)) return;
     const auto pos = p.posq[gid];
     int idx[3]; Real fr[3];
-    gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, p.d.nz, idx, fr);
+    gridCoord<Real>(p.recip, p.recipLo, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, p.d.nz, idx, fr);
     Real tx[5], ty[5], tz[5], dtmp[5];
     bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
     const int ix = r / 5, iy = r - ix * 5;
@@ -115,7 +115,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_pmeCells(const
     if (p.atomGrid[a] >= 0 && pmeCharge(p, a) != Real(0)) {
         const auto pos = p.posq[a];
         int idx[3]; Real fr[3];
-        gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, p.d.nz, idx, fr);
+        gridCoord<Real>(p.recip, p.recipLo, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, p.d.nz, idx, fr);
         cell = idx[0] | (idx[1] << 10) | (idx[2] << 20);
     }
     p.cells[a] = cell;
@@ -238,7 +238,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
             const Real q = pmeCharge(p, a);
             const auto pos = p.posq[a];
             int idx[3]; Real fr[3];
-            gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
+            gridCoord<Real>(p.recip, p.recipLo, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
             int rx = idx[0] - x0; if (rx > hx) rx -= p.d.nx; else if (rx < -hx) rx += p.d.nx;
             int ry = idx[1] - y0; if (ry > hy) ry -= p.d.ny; else if (ry < -hy) ry += p.d.ny;
             Real tx[5], ty[5], tz[5], dtmp[5];
@@ -1004,7 +1004,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_interpolate(co
     const Real q = si >= 0 ? pmeCharge(p, gid) : Real(0);
     const auto pos = p.posq[gid];
     int idx[3]; Real fr[3];
-    gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, p.d.nz, idx, fr);
+    gridCoord<Real>(p.recip, p.recipLo, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, p.d.nz, idx, fr);
     Real tx[5], ty[5], tz[5], dx[5], dy[5], dz[5];
     bspline5<Real>(fr[0], tx, dx); bspline5<Real>(fr[1], ty, dy); bspline5<Real>(fr[2], tz, dz);
     Real fx = 0, fy = 0, fz = 0;
@@ -1213,7 +1213,7 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
                     const Real lam = p.mix ? Real(1) : p.lambdas[2 * slice + term];
                     const auto pos = p.posq[a];
                     int idx[3]; Real fr[3];
-                    gridCoord<Real>(p.recip, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
+                    gridCoord<Real>(p.recip, p.recipLo, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
                     if (idx[2] < z0 || idx[2] >= z0 + sz) continue;       // another slab's atom
                     int rx = idx[0] - x0; if (rx > p.d.nx / 2) rx -= p.d.nx; else if (rx < -(p.d.nx / 2)) rx += p.d.nx;
                     int ry = idx[1] - y0; if (ry > p.d.ny / 2) ry -= p.d.ny; else if (ry < -(p.d.ny / 2)) ry += p.d.ny;

@@ -116,6 +116,7 @@ template <typename Real> struct PmeParams {
     const typename Vec<Real>::T2* twx; const typename Vec<Real>::T2* twy; const typename Vec<Real>::T2* twz;   // roots of unity exp(-2 pi i k/n)
     const Real* modx; const Real* mody; const Real* modz;       // B-spline moduli
     Real recip[9];            // reciprocal box (ReferencePME.cpp:186-194)
+    Real recipLo[9];          // single precision: the rounding remainder of recip (double-float pair), see gridCoord
     Real alpha, volume;
     int dispersion;           // 0: Coulomb charges & kernel, 1: LJPME dispersion
     const Real* lambdas;      // [S*2]
@@ -200,23 +201,49 @@ template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipS
 template <typename Real> void launchPmeFFTX(const PmeParams<Real>& p, int sign, hipStream_t s);   // x axis alone (test hook)
 template <typename Real> bool launchPmeInterpolate(const PmeParams<Real>& p, hipStream_t s);   // true: the kernel also delivered the user-order forces (p.outForces)
 // fractional mesh coordinate of a position: cell index and offset inside the cell (ReferencePME.cpp:268-305); shared by the PME
-// kernels and the position-gather pass so that both always agree on an atom's cell
-template <typename Real> __device__ inline void gridCoord(const Real* recip, Real x, Real y, Real z, int nx, int ny, int nz, int* idx, Real* frac) {
+// kernels and the position-gather pass so that both always agree on an atom's cell.
+// Single precision carries the fraction as a double-float pair.  The plain form t = frac(x r) n rounds x r at magnitude 1 (6e-8) and
+// r itself to 6e-8 relative, i.e. the offset inside the cell to 1e-5 cells on a 180-point mesh -- 2e-6 nm, times the gradient of the
+// reciprocal force (1e4 kJ/mol/nm^2 on a water atom) = 0.02 kJ/mol/nm per atom: measured on c5 (1M atoms, 180^3 + 90^3) as
+// 0.011-0.03 on atoms whose total force is 5, 2e-3 relative; the exact products below leave 1e-7 cells (tools/dbg_tail.py).
+__device__ inline void twoProdAdd(float a, float bh, float bl, float& hi, float& lo) {      // (hi, lo) += a * (bh + bl), hi + lo exact up to second order
+    const float ph = __fmul_rn(a, bh), pl = fmaf(a, bh, -ph) + a * bl;      // (__fmul_rn / __fadd_rn: never contracted into an fma)
+    const float s = __fadd_rn(hi, ph), bb = s - hi;
+    lo += ((hi - (s - bb)) + (ph - bb)) + pl;
+    hi = s;
+}
+template <typename Real> __device__ inline void gridCoord(const Real* recip, const Real* recipLo, Real x, Real y, Real z, int nx, int ny, int nz, int* idx, Real* frac) {
     const int n[3] = {nx, ny, nz};
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        Real t = x * recip[d] + y * recip[3 + d] + z * recip[6 + d];
-        t = (t - floor(t)) * n[d];
-        int ti = (int)t;
-        frac[d] = t - ti;
-        idx[d] = ti >= n[d] ? ti - n[d] : ti;
+        if constexpr (sizeof(Real) == 4) {
+            float hi = __fmul_rn(x, recip[d]), lo = fmaf(x, recip[d], -hi) + x * recipLo[d];
+            if (recip[3 + d] != 0.f) twoProdAdd(y, recip[3 + d], recipLo[3 + d], hi, lo);      // (lower-triangular reciprocal box: uniform branches,
+            if (recip[6 + d] != 0.f) twoProdAdd(z, recip[6 + d], recipLo[6 + d], hi, lo);      //  a rectangular box takes neither)
+            const float u = hi - floorf(hi);                      // exact
+            const float fn = (float)n[d];
+            const float ph = __fmul_rn(u, fn), pl = fmaf(u, fn, -ph) + lo * fn;      // (u + lo) n as a pair
+            float tf = floorf(ph);
+            float fr = (ph - tf) + pl;                            // ph - tf exact
+            if (fr < 0.f) { fr += 1.f; tf -= 1.f; } else if (fr >= 1.f) { fr -= 1.f; tf += 1.f; }
+            if (fr < 0.f) fr = 0.f;
+            int ti = (int)tf;
+            ti = ti >= n[d] ? ti - n[d] : (ti < 0 ? ti + n[d] : ti);
+            frac[d] = fr; idx[d] = ti;
+        } else {
+            Real t = x * recip[d] + y * recip[3 + d] + z * recip[6 + d];
+            t = (t - floor(t)) * n[d];
+            int ti = (int)t;
+            frac[d] = t - ti;
+            idx[d] = ti >= n[d] ? ti - n[d] : ti;
+        }
     }
 }
 
 
 // Coulomb-mesh geometry handed to the position-gather pass (cells == nullptr: no mesh / brick spreader not in use)
 template <typename Real> struct GatherCells {
-    Real recip[9]; int nx, ny, nz; int* cells; const int* atomGrid;
+    Real recip[9], recipLo[9]; int nx, ny, nz; int* cells; const int* atomGrid;
     // displacement watch (posRef == nullptr: off): positions at the last rebuild; flags[0] |= 1 when an atom has moved further than
     // sqrt(warn2) (time to rebuild), flags[1] |= 1 beyond sqrt(fail2) = skin/2 (the list may already have missed a pair)
     const typename Vec<Real>::T4* posRef; int* flags; Real warn2, fail2;

@@ -28,6 +28,15 @@ import bench
 BAND_REL = {"single": 6e-6, "mixed": 6e-6, "double": 0.0}
 
 
+def band_rel(w, precision):
+    """BAND_REL for the workload's own coordinate range: the figure above is for coordinates below 16 nm; a float's spacing doubles at
+    16 nm (the 1M-atom box of c5 is 21.5 nm wide), and the band with it."""
+    if BAND_REL[precision] == 0.0:
+        return 0.0
+    ulp = float(np.spacing(np.float32(np.abs(w["pos"]).max())))
+    return BAND_REL[precision] * max(1.0, ulp / 9.5367431640625e-07)
+
+
 def float_positions(w):
     """The workload with its coordinates rounded to float32 and widened back: what a single-precision engine is given."""
     wf = dict(w)
