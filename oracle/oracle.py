@@ -180,6 +180,38 @@ def bspline_moduli(n, order=5):
     return out
 
 
+_ref_fft = None
+
+
+def ref_fft_lib():
+    """oracle/_ref/libref_fft.so: the reference's OWN 3D FFT (its vendored pocketfft header compiled where it lies under /root/reference,
+    oracle/ref_fft_wrapper.cpp) -- or None where neither the prebuilt file nor the reference tree exists."""
+    global _ref_fft
+    if _ref_fft is None:
+        path = os.path.join(_HERE, "_ref", "libref_fft.so")
+        if not os.path.exists(path) and os.path.exists("/root/reference/openmmapi/include/internal/pocketfft_hdronly.h"):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+        if not os.path.exists(path):
+            return None
+        L = ctypes.CDLL(path)
+        L.ref_c2c_3d.argtypes = [ctypes.POINTER(ctypes.c_double)] + [ctypes.c_int] * 5
+        L.ref_c2c_3d.restype = ctypes.c_int
+        _ref_fft = L
+    return _ref_fft
+
+
+def ref_fft3d(a, forward=True):
+    """Complex 3D transform of a [batch][nx][ny][nz] (or [nx][ny][nz]) array by the reference's pocketfft::c2c, called as
+    ReferencePME.cpp:788-805 calls it (unnormalised)."""
+    L = ref_fft_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libref_fft.so is not available")
+    a = np.ascontiguousarray(a, dtype=np.complex128).copy()
+    b = a.reshape((-1,) + a.shape[-3:])
+    assert L.ref_c2c_3d(b.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), b.shape[0], b.shape[1], b.shape[2], b.shape[3], int(bool(forward))) == 0
+    return a
+
+
 def fft3d(a, sign=-1):
     a = np.ascontiguousarray(a, dtype=np.complex128).copy()
     nx, ny, nz = a.shape

@@ -6,6 +6,7 @@ import bench, torch, oracle
 pkg = importlib.import_module("openmm-nonbonded-slicing_amd")
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 prec = sys.argv[2] if len(sys.argv) > 2 else "single"
+watch = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else []      # atoms to report in every decomposition
 n_target, Lbox, nsub, method, grid, dgrid, _ = bench.CONFIGS[name]
 w = bench.build_workload(n_target, Lbox, nsub, np.random.default_rng(bench.SEED))
 N = len(w['q']); S = nsub * (nsub + 1) // 2
@@ -46,5 +47,7 @@ for (d, r) in ((1, 0), (0, 1), (1, 1)):
                 rec["sliceE_max_rel"] = float(rel.max()); rec["sliceE_arg"] = [int(x) for x in np.unravel_index(rel.argmax(), rel.shape)]
                 rec["sliceE"] = se.tolist(); rec["sliceE_oracle"] = ss.tolist()
             res[key] = rec
+            for i in watch:
+                print("   atom %d  %s: |F_oracle| %.6g  |err| %.6g  f %s  oracle %s" % (i, key, np.linalg.norm(ff[i]), np.linalg.norm(f[i] - ff[i]), f[i].tolist(), ff[i].tolist()), flush=True)
             print(key, {k: v for k, v in rec.items() if not k.startswith("sliceE") or k in ("sliceE_max_rel", "sliceE_arg")}, flush=True)
 json.dump(res, open("gpurun_out/dbg_tail_%s_%s.json" % (name, prec), "w"), indent=1)
