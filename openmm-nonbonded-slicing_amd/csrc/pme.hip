@@ -351,7 +351,8 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
 template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
     if (p.sortNcx > 0 && p.colRange != nullptr) {
         const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
-        const bool fixed = std::is_same<Real, float>::value && p.d.nz % 2 == 0 && (p.d.nz / p.zSlabs) % 2 == 0;
+        static const bool noFixed = getenv("SNB_NO_FIXED_SPREAD") != nullptr;      // test switch: f64 LDS accumulation in single precision too
+        const bool fixed = std::is_same<Real, float>::value && !noFixed && p.d.nz % 2 == 0 && (p.d.nz / p.zSlabs) % 2 == 0;
         const size_t accBytes = fixed ? sizeof(int) : sizeof(double);
         const size_t brickBytes = (accBytes * (size_t)cx * cy * (p.d.nz / p.zSlabs) + 15) & ~(size_t)15;
         const size_t listBytes = sizeof(int) * 4096;

@@ -8,6 +8,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 prec = sys.argv[2] if len(sys.argv) > 2 else "single"
 watch = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else []      # atoms to report in every decomposition
 n_target, Lbox, nsub, method, grid, dgrid, _ = bench.CONFIGS[name]
+method = int(os.environ.get('SNB_DBG_METHOD', method))      # e.g. 4: the config's box with plain PME instead of LJPME
+parts = sys.argv[4] if len(sys.argv) > 4 else 'D,R,DR'
 w = bench.build_workload(n_target, Lbox, nsub, np.random.default_rng(bench.SEED))
 N = len(w['q']); S = nsub * (nsub + 1) // 2
 def orc(wv, d, r):
@@ -27,7 +29,7 @@ dt = torch.float64 if isd else torch.float32
 eng = bench.Engine(pkg, w, method, grid, dgrid, prec, 0, 0, 1, 0.1, 1 << 30)
 pos = torch.tensor(w['pos'], dtype=dt, device='cuda'); forces = torch.zeros((N, 3), dtype=dt, device='cuda')
 res = {}
-for (d, r) in ((1, 0), (0, 1), (1, 1)):
+for (d, r) in [x for x in ((1, 0), (0, 1), (1, 1)) if ('D' if x[0] else '') + ('R' if x[1] else '') in parts.split(',')]:
     fo, so = orc(w, d, r); fo2, so2 = (fo, so) if isd else orc(wf, d, r)
     for energy in (1, 0):
         eng.set_positions_device(pos.data_ptr(), isd)
