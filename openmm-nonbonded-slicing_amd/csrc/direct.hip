@@ -478,20 +478,12 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
     __shared__ float4 s_pos[4][64];
     __shared__ float2 s_se[4][64];
-    // Lattice-image shift of every 7-bit image code (125 in use), + ka a + kb b + kc c (rows of the cell), as a (hi, lo) pair of floats
-    // from the double cell.  Coordinates are taken RELATIVE to a point c next to the i-block (a coarse multiple of 1/64 nm, so that
-    // x - c and hi - c are exact in float): x_j' = (x_j + (hi - c)) + lo rounds once, at the magnitude of a neighbour distance (1e-7 nm),
-    // where x_j + shift rounded at the magnitude of the box (1.9e-6 nm at 21 nm) -- and the box length itself to float, 1e-6 nm on every
-    // pair across the boundary.  On a hydrogen-bonded O-H pair (gradient 1.6e4 kJ/mol/nm^2) 1e-6 nm is 0.016 kJ/mol/nm.
-    __shared__ float4 s_shift[128], s_shiftLo[128];
+    __shared__ float4 s_shift[128];      // lattice-image shift of every 7-bit image code (125 in use): + ka a + kb b + kc c (rows of p.box)
     if (threadIdx.x < 128) {
         const int sc = threadIdx.x;
         const int kx = sc / 25, ky = (sc - 25 * kx) / 5, kz = sc - 25 * kx - 5 * ky;
-        const double ka = double(kx - 2), kb = double(ky - 2), kc = double(kz - 2);
-        const double sx = ka * p.box64[0] + kb * p.box64[3] + kc * p.box64[6], sy = kb * p.box64[4] + kc * p.box64[7], sz = kc * p.box64[8];
-        const float hx = (float)sx, hy = (float)sy, hz = (float)sz;
-        s_shift[sc] = sc < 125 ? make_float4(hx, hy, hz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s_shiftLo[sc] = sc < 125 ? make_float4((float)(sx - (double)hx), (float)(sy - (double)hy), (float)(sz - (double)hz), 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float ka = float(kx - 2), kb = float(ky - 2), kc = float(kz - 2);
+        s_shift[sc] = sc < 125 ? make_float4(ka * p.box[0] + kb * p.box[3] + kc * p.box[6], kb * p.box[4] + kc * p.box[7], kc * p.box[8], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -505,10 +497,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
 
     const float4 pa = p.posq[I * 32 + c], pb = p.posq[I * 32 + 16 + c];
     const float2 sa = p.sigeps[I * 32 + c], sb = p.sigeps[I * 32 + 16 + c];
-    // the block's reference point: its first atom, rounded to 1/64 nm (uniform)
-    auto firstLane = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-    const float cx = firstLane(__builtin_rintf(pa.x * 64.f) * 0.015625f), cy = firstLane(__builtin_rintf(pa.y * 64.f) * 0.015625f), cz = firstLane(__builtin_rintf(pa.z * 64.f) * 0.015625f);
-    const v2f pix = {pa.x - cx, pb.x - cx}, piy = {pa.y - cy, pb.y - cy}, piz = {pa.z - cz, pb.z - cz};
+    const v2f pix = {pa.x, pb.x}, piy = {pa.y, pb.y}, piz = {pa.z, pb.z};
     const v2f qi = {pa.w * p.k4pe, pb.w * p.k4pe}, sigi = {sa.x, sb.x}, epsi = {sa.y, sb.y};
     v2f fix = {0.f, 0.f}, fiy = {0.f, 0.f}, fiz = {0.f, 0.f};
     const v2f c6i = {8.0f * sa.x * sa.x * sa.x * sa.y, 8.0f * sb.x * sb.x * sb.x * sb.y};      // LJPME: c6 of the two i-atoms
@@ -534,7 +523,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     // or converted before the trip in which it is consumed -- a copy (a loop-carried "next = loaded" move), the image shift added at
     // the load, or a uniform header moved to SGPRs behind its load each cost a full memory round trip per tile, atomics included,
     // because the wait counter is in-order.
-    struct TileRegs { int jcode, slice, maskIdx; float4 pj; float2 sej; float shx, shy, shz, slx, sly, slz; unsigned mA, mB; float2 lam; int need; };
+    struct TileRegs { int jcode, slice, maskIdx; float4 pj; float2 sej; float shx, shy, shz; unsigned mA, mB; float2 lam; int need; };
     TileRegs A, B;
     int vzero; asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));      // a zero the compiler cannot see through (keeps the header load in VGPRs)
     // (the j-force atomics of a tile are issued at the start of the NEXT trip: an atomic sits behind a conditional skip the wait-count
@@ -552,8 +541,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         flushPending();
         const int idx = code == -1 ? 0 : (code & SNB_JIDX_MASK);
         r.pj = p.posq[idx]; r.sej = p.sigeps[idx];
-        const float4 sh = s_shift[(code >> SNB_JSHIFT_BITS) & 127], sl = s_shiftLo[(code >> SNB_JSHIFT_BITS) & 127];      // lattice image of the entry (tables filled at kernel start)
-        r.shx = sh.x - cx; r.shy = sh.y - cy; r.shz = sh.z - cz; r.slx = sl.x; r.sly = sl.y; r.slz = sl.z;      // (hi - c: exact)
+        const float4 sh = s_shift[(code >> SNB_JSHIFT_BITS) & 127];      // lattice image of the entry (table filled at kernel start)
+        r.shx = sh.x; r.shy = sh.y; r.shz = sh.z;
         const int mi = r.maskIdx < 0 ? 0 : r.maskIdx;              // unconditional loads: a conditionally loaded register is a phi with a copy
         r.mA = p.masks[mi * 32 + c]; r.mB = p.masks[mi * 32 + 16 + c];
         r.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * (r.slice & 0xFFFF)]);      // (the slice index comes with the tile header, written by the builder)
@@ -565,7 +554,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         Staged st;
         __builtin_amdgcn_wave_barrier();
         st.code = R.jcode;
-        if (st.code != -1) { myPos[lane] = make_float4((R.pj.x + R.shx) + R.slx, (R.pj.y + R.shy) + R.sly, (R.pj.z + R.shz) + R.slz, R.pj.w); mySe[lane] = R.sej; }
+        if (st.code != -1) { myPos[lane] = make_float4(R.pj.x + R.shx, R.pj.y + R.shy, R.pj.z + R.shz, R.pj.w); mySe[lane] = R.sej; }
         else { myPos[lane] = make_float4(3e9f + 1e6f * c, -5e9f, 7e9f, 0.f); mySe[lane] = make_float2(0.f, 0.f); }      // padding slot: parked far away
         st.hasMask = R.maskIdx >= 0;
         st.maskA = st.hasMask ? R.mA >> (8 * row) : 0u; st.maskB = st.hasMask ? R.mB >> (8 * row) : 0u;   // my j-quarter's 8 bits

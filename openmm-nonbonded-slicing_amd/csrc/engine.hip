@@ -1305,7 +1305,7 @@ public:
             const bool sw = cfg.use_switch && cfg.method != SNB_NoCutoff && cfg.method != SNB_LJPME;
             p.useSwitch = sw ? 1 : 0; p.switchDist = (Real)cfg.switch_distance;
             p.invSwitchWidth = (Real)(sw ? 1.0 / (cfg.cutoff - cfg.switch_distance) : 0.0);
-            for (int i = 0; i < 9; i++) { p.box[i] = (Real)(gpuBuilt ? tileCell[i] : box[i]); p.box64[i] = gpuBuilt ? tileCell[i] : box[i]; }
+            for (int i = 0; i < 9; i++) p.box[i] = (Real)(gpuBuilt ? tileCell[i] : box[i]);
             if (isPeriodic()) { p.invBoxDiag[0] = (Real)(1.0 / box[0]); p.invBoxDiag[1] = (Real)(1.0 / box[4]); p.invBoxDiag[2] = (Real)(1.0 / box[8]); }
             p.boxDiag[0] = (Real)box[0]; p.boxDiag[1] = (Real)box[4]; p.boxDiag[2] = (Real)box[8];
             int mc = MC_NOCUTOFF;

@@ -65,7 +65,6 @@ template <typename Real> struct DirectParams {
     Real invCut6, multShift6;                              // LJPME potential shifts
     int useSwitch; Real switchDist, invSwitchWidth;
     Real box[9]; Real invBoxDiag[3];                       // for the per-pair wrap variant
-    double box64[9];                                       // the same cell in double: lattice shifts of the packed kernel as (hi, lo) float pairs
     Real boxDiag[3];                                       // rectangular box edge lengths (image codes are decoded against them)
 };
 

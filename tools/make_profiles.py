@@ -9,9 +9,11 @@ src = os.path.join(root, "gpurun_out", "final"); dst = os.path.join(root, "profi
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_%s_default_bench.json" % (tag, cfg)))
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_%s_default_bench_kernel_stats.csv" % (tag, cfg)))
 shutil.copy(os.path.join(src, "pmc_sq.txt"), os.path.join(dst, "%s_%s_pmc_sq.txt" % (tag, cfg)))
+if os.path.exists(os.path.join(src, "pmc_mfma.txt")):
+    shutil.copy(os.path.join(src, "pmc_mfma.txt"), os.path.join(dst, "%s_%s_pmc_mfma.txt" % (tag, cfg)))
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 hb = json.load(open(os.path.join(root, "gpurun_out", "hb_%s_hbm.json" % tag)))
-name = [k for k in hb if "k_directPacked" in k and "true, false, false" in k or "k_direct<double" in k][0]
+name = [k for k in hb if "k_directPacked" in k and "true, false, false, false" in k or "k_direct<double" in k][0]
 rec = hb[name]
 fetch, write = rec["FETCH_SIZE_per_launch_raw"], rec["WRITE_SIZE_per_launch_raw"]
 out = {"command": "tools/pmc_hbm.sh hb_%s --steps 40 --warmup 5  (rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE, over bench.py)" % tag,
