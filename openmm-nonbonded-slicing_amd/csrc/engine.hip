@@ -334,6 +334,10 @@ public:
     }
     ~Engine() override {
         (void)hipStreamSynchronize(stream);
+        if (dPmeTrace.p) {
+            long long g[8] = {0}; (void)hipMemcpy(g, dPmeTrace.p, 64, hipMemcpyDeviceToHost);
+            if (g[7] > 0) fprintf(stderr, "[snb] spreading bricks (busy ones): mean scan %.2f us, entries %.2f us, z FFT + store %.2f us per work-group (%lld work-groups)\n", g[4] / 100.0 / g[7], g[5] / 100.0 / g[7], g[6] / 100.0 / g[7], g[7]);
+        }
         if (dPmeTrace.p) { long long h[4] = {0, 0, 0, 0}; (void)hipMemcpy(h, dPmeTrace.p, 32, hipMemcpyDeviceToHost); if (h[2] > 0) fprintf(stderr, "[snb] interpolation bricks: mean load %.2f us, mean compute %.2f us per work-group (%lld work-groups)\n", h[0] / 100.0 / h[2], h[1] / 100.0 / h[2], h[2]); }
         dropGraph();
         if (sortGraphExec) { (void)hipGraphExecDestroy(sortGraphExec); sortGraphExec = nullptr; }
@@ -1105,7 +1109,7 @@ public:
     void fillPme(PmeParams<Real>& p, PmePlan<Real>& plan, bool wantEnergy) {
         p.d = plan.d; p.nsub = nGrids; p.natoms = Npad; p.posq = posq.p; p.sigeps = sigeps.p; p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p;
         p.cells = pmeCells.p;
-        { static const bool tr = getenv("SNB_PME_TRACE") != nullptr; if (tr) { if (!dPmeTrace.p) { dPmeTrace.resize(4); HIPCHECK(hipMemset(dPmeTrace.p, 0, 32)); } p.trace = dPmeTrace.p; } }
+        { static const bool tr = getenv("SNB_PME_TRACE") != nullptr; if (tr) { if (!dPmeTrace.p) { dPmeTrace.resize(8); HIPCHECK(hipMemset(dPmeTrace.p, 0, 64)); } p.trace = dPmeTrace.p; } }
         p.cellsReady = (!plan.dispersion && cellsFromGather) ? 1 : 0;
         p.fixDev = dFixScale.p ? dFixScale.p + (plan.dispersion ? 2 : 0) : nullptr;      // (k_fixScale keeps it in step with the parameters)
         p.gridReal = plan.gridReal.p; p.gridCplx = plan.gridCplx.p; p.twx = plan.twx.p; p.twy = plan.twy.p; p.twz = plan.twz.p;

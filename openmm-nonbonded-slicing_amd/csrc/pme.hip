@@ -131,7 +131,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_pmeCells(const
 // ---------------------------------------------------------------------------------------------------
 template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(512) void k_spreadBrick(const PmeParams<Real> p) {
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
-    constexpr int NT = 512, LISTCAP = 4096;
+    constexpr int NT = 512, LISTCAP = FIXED ? 8192 : 4096;      // (single precision: the list shares its LDS with the z-FFT buffers of the fused pass, which are larger)
     // a brick spans groupX x groupY sort columns (1 x 1 for the Coulomb mesh; more when a coarser mesh makes one column < 5 cells)
     const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
     const int cx = p.groupX * (p.d.nx / ncx), cy = p.groupY * (p.d.ny / ncy);       // brick size in cells of THIS mesh
@@ -197,46 +197,68 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
         }
         return;
     }
-    for (int base = 0; base < total; base += NT) {
+    const bool trace = p.trace != nullptr;      // SNB_PME_TRACE: wall-clock split of the busy work-groups (scan / entries / z FFT + store)
+    long long tT = trace ? (long long)wall_clock64() : 0, tScan = 0, tEnt = 0;
+    // Phase 1 takes SCAN candidates per thread and round: a round is a chain of dependent latencies (range lookup in LDS, the cell load,
+    // a six-step wave scan, an LDS atomic, two barriers: about 1 us whatever the work) and most candidates are rejected -- five of the nine
+    // scanned columns are there only for atoms that drifted across a column border since the last re-sort.
+    constexpr int SCAN = FIXED ? 2 : 1;
+    for (int base = 0; base < total; base += SCAN * NT) {
         // phase 1: one thread per candidate atom; every x-line (atom, ix) of its 5x5 footprint that falls inside the brick becomes a list entry
-        const int v = base + tid;
-        int nEnt = 0, ixLo = 0, aSel = 0;
-        if (v < total) {
-            int r = 0;
-            while (v >= s_rangePrefix[r + 1]) r++;
-            const int a = s_rangeBegin[r] + (v - s_rangePrefix[r]);
-            const int cell = p.cells[a];            // packed mesh cell of the atom (k_pmeCells), -1 = carries no charge on this mesh
+        int nEnt[SCAN], ixLo[SCAN], aSel[SCAN], cellOf[SCAN];
+#pragma unroll
+        for (int c = 0; c < SCAN; c++) {      // all loads of the round in flight together
+            const int v = base + c * NT + tid;
+            aSel[c] = 0; cellOf[c] = -1;
+            if (v < total) {
+                int r = 0;
+                while (v >= s_rangePrefix[r + 1]) r++;
+                aSel[c] = s_rangeBegin[r] + (v - s_rangePrefix[r]);
+                cellOf[c] = p.cells[aSel[c]];            // packed mesh cell of the atom (k_pmeCells), -1 = carries no charge on this mesh
+            }
+        }
+        int mine = 0;
+#pragma unroll
+        for (int c = 0; c < SCAN; c++) {
+            const int cell = cellOf[c];
+            nEnt[c] = 0; ixLo[c] = 0;
             const int idx[3] = {cell & 1023, (cell >> 10) & 1023, (cell >> 20) & 1023};
             int rx = idx[0] - x0; if (rx > hx) rx -= p.d.nx; else if (rx < -hx) rx += p.d.nx;
             int ry = idx[1] - y0; if (ry > hy) ry -= p.d.ny; else if (ry < -hy) ry += p.d.ny;
             int rz = idx[2] - z0; if (rz > hz) rz -= nz; else if (rz < -hz) rz += nz;
             const bool zHit = nSlabs == 1 || (rz + 4 >= 0 && rz < sz);
             if (cell >= 0 && zHit && rx + 4 >= 0 && rx < cx && ry + 4 >= 0 && ry < cy) {
-                ixLo = rx < 0 ? -rx : 0;                                                   // lines with 0 <= rx + ix < cx
-                nEnt = ((cx - rx < 5) ? cx - rx : 5) - ixLo;
-                aSel = a;
+                ixLo[c] = rx < 0 ? -rx : 0;                                                   // lines with 0 <= rx + ix < cx
+                nEnt[c] = ((cx - rx < 5) ? cx - rx : 5) - ixLo[c];
             }
+            mine += nEnt[c];
         }
         {   // wave-aggregated append: one LDS atomic per wave instead of one same-address atomic per lane
-            int incl = nEnt;
+            int incl = mine;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
             int waveBase = 0;
             if ((tid & 63) == 63 && incl > 0) waveBase = atomicAdd(&s_count, incl);
             waveBase = __shfl(waveBase, 63, 64);
-            const int slot0 = waveBase + incl - nEnt;
-            for (int k = 0; k < nEnt; k++) list[slot0 + k] = (aSel << 3) | (ixLo + k);
+            int slot0 = waveBase + incl - mine;
+#pragma unroll
+            for (int c = 0; c < SCAN; c++) { for (int k = 0; k < nEnt[c]; k++) list[slot0 + k] = (aSel[c] << 3) | (ixLo[c] + k); slot0 += nEnt[c]; }
         }
         __syncthreads();
         const int count = s_count;
         __syncthreads();                                                    // everyone has read the count before anyone appends again
-        if (count <= LISTCAP - 5 * NT && base + NT < total) continue;      // room for another round of candidates (uniform branch)
+        if (count <= LISTCAP - 5 * SCAN * NT && base + SCAN * NT < total) continue;      // room for another round of candidates (uniform branch)
+        if (trace) { const long long t = (long long)wall_clock64(); tScan += t - tT; tT = t; }
         // phase 2: one thread per (atom, x-line): weights, then the line's 5x5 (y,z) points that fall inside the brick into LDS
+        int eN = 0; Real qN = Real(0); typename Vec<Real>::T4 posN = {};
+        auto fetch = [&](int k) { if (k < count) { eN = list[k]; qN = pmeCharge(p, eN >> 3); posN = p.posq[eN >> 3]; } };
+        fetch(tid);
         for (int k = tid; k < count; k += NT) {
-            const int e = list[k];
-            const int a = e >> 3, ix = e & 7;
-            const Real q = pmeCharge(p, a);
-            const auto pos = p.posq[a];
+            const int e = eN;
+            const int ix = e & 7;
+            const Real q = qN;
+            const auto pos = posN;
+            fetch(k + NT);
             int idx[3]; Real fr[3];
             gridCoord<Real>(p.recip, p.recipLo, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
             int rx = idx[0] - x0; if (rx > hx) rx -= p.d.nx; else if (rx < -hx) rx += p.d.nx;
@@ -298,7 +320,15 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
         __syncthreads();
         if (tid == 0) s_count = 0;
         __syncthreads();
+        if (trace) { const long long t = (long long)wall_clock64(); tEnt += t - tT; tT = t; }
     }
+    auto traceOut = [&]() {
+        if (trace && tid == 0) {
+            const long long t = (long long)wall_clock64();
+            atomicAdd((unsigned long long*)&p.trace[4], (unsigned long long)tScan); atomicAdd((unsigned long long*)&p.trace[5], (unsigned long long)tEnt);
+            atomicAdd((unsigned long long*)&p.trace[6], (unsigned long long)(t - tT)); atomicAdd((unsigned long long*)&p.trace[7], 1ull);
+        }
+    };
     // Reading a point back.  Fixed point: the two halves of a 64-bit word were summed as ONE signed integer, hi * 2^32 + lo, so the upper
     // word holds hi - 1 whenever the lower half's sum is negative: the borrow is returned here.  (Without it every odd-z point beside a
     // negative even-z point was low by one unit, 1.2e-8 e: a uniform spurious charge of -1e-3 e per subset grid of c4, whose interaction
@@ -336,6 +366,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
                 out[((size_t)(x0 + lx1) * p.d.ny + (y0 + ly1)) * nzc + k] = {Real(0.5) * (z.y + m.y), Real(0.5) * (m.x - z.x)};
             }
         }
+        traceOut();
         return;
     }
     Real* g = p.gridReal + (size_t)slot * p.d.nx * p.d.ny * nz;
@@ -355,7 +386,7 @@ template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStrea
         const bool fixed = std::is_same<Real, float>::value && !noFixed && p.d.nz % 2 == 0 && (p.d.nz / p.zSlabs) % 2 == 0;
         const size_t accBytes = fixed ? sizeof(int) : sizeof(double);
         const size_t brickBytes = (accBytes * (size_t)cx * cy * (p.d.nz / p.zSlabs) + 15) & ~(size_t)15;
-        const size_t listBytes = sizeof(int) * 4096;
+        const size_t listBytes = sizeof(int) * (fixed ? 8192 : 4096);
         const int nbz = (cx * cy + 1) / 2;
         const size_t fftBytes = sizeof(Cx<Real>) * ((size_t)2 * p.d.nz * (nbz + 1) + p.d.nz);
         static const bool noFuse = getenv("SNB_NO_FUSED_Z") != nullptr;
