@@ -1256,8 +1256,9 @@ public:
             const double half = 0.5 * cfg.neighbor_padding;
             gc.fail2 = (Real)(half * half); gc.warn2 = (Real)(0.64 * half * half);      // rebuild request at 80 % of skin/2: the flag is read one step late
         }
+        if (energy && Npad > 0) { gc.clearE = sliceE.p; gc.nClearE = S * 2 * SNB_SLICE_E_PARTS; }
         launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, forceBuf.p, forceArrays(), gc, stream);
-        if (energy) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2 * SNB_SLICE_E_PARTS, stream));
+        if (energy && Npad <= 0) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2 * SNB_SLICE_E_PARTS, stream));
         const bool ew = cfg.method >= SNB_Ewald;
         // Opt-in (SNB_CONCURRENT_PME=1): forces-only graph steps run the reciprocal pipeline on a second stream beside the pair
         // kernel (disjoint force arrays fx.. / fpx..).  Timed (eager) steps stay serial so the per-kernel event timers stay clean.

@@ -776,7 +776,7 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
     Cx<Real>* B = A + (size_t)nx * BS;
     Cx<Real>* tw = B + (size_t)nx * BS;                                // [nx] roots of unity
     Real* et = reinterpret_cast<Real*>(tw + nx);                       // [nx][NB]
-    __shared__ double s_red[NT / 64];
+    __shared__ double s_red[(NT / 64) * 4];
     const size_t strideK = (size_t)nCols;                              // ny*nzc
     const size_t strideSub = (size_t)nx * nCols;
     Cx<Real>* g = reinterpret_cast<Cx<Real>*>(p.gridCplx);
@@ -812,34 +812,49 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
     // over the full grid => Hermitian weight 2 for interior kz planes.
     if (p.wantEnergy && p.mix) {   // sharded engines get the energies by interpolation instead (k_interpolate)
         const int term = p.dispersion ? 1 : 0;
-        for (int I = 0; I < nsub; I++)
-            for (int J = 0; J <= I; J++) {
-                {   // derivative-only steps ask for a few slices: the others' Gram sums (a pass over the spectra and two barriers each) are skipped
-                    const int gi = p.gridSubset[I], gj = p.gridSubset[J];
-                    if (!p.sliceNeed[gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi]) continue;      // (uniform)
-                }
-                double acc = 0;
-                for (int it = tid; it < nx * NB; it += NT) {
-                    const int kx = dNB.div(it), col = it - kx * NB;
-                    if (col >= nbc) continue;
-                    const int kz = (c0 + col) - dNzc.div(c0 + col) * p.d.nzc;
-                    const Real w = (kz == 0 || (2 * kz == p.d.nz)) ? Real(1) : Real(2);
-                    const Cx<Real> a = S[kx * BS + I * NB + col], b = S[kx * BS + J * NB + col];
-                    acc += (double)(w * et[it] * (a.x * b.x + a.y * b.y));
-                }
-                if (I == J) acc *= 0.5;
+        // The wanted (I, J) pairs four at a time: one pass over the spectra and one reduction per group (a pass and two barriers per
+        // slice cost the derivative step 12 us on c3; derivative-only steps ask for a few slices, the others are skipped altogether)
+        constexpr int G = 4;
+        int gI[G], gJ[G], ng = 0;
+        auto flushGroup = [&]() {      // (uniform: every thread holds the same group)
+            double acc[G] = {0, 0, 0, 0};
+            for (int it = tid; it < nx * NB; it += NT) {
+                const int kx = dNB.div(it), col = it - kx * NB;
+                if (col >= nbc) continue;
+                const int kz = (c0 + col) - dNzc.div(c0 + col) * p.d.nzc;
+                const Real w = ((kz == 0 || (2 * kz == p.d.nz)) ? Real(1) : Real(2)) * et[it];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                __syncthreads();
-                if ((tid & 63) == 0) s_red[tid >> 6] = acc;
-                __syncthreads();
-                if (tid == 0) {
-                    const int gi = p.gridSubset[I], gj = p.gridSubset[J];
-                    const int slice = gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi;
-                    double tot = 0; for (int w = 0; w < NT / 64; w++) tot += s_red[w];
-                    atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, p.nsubTotal * (p.nsubTotal + 1))[2 * slice + term], tot);
+                for (int u = 0; u < G; u++) if (u < ng) {
+                    const Cx<Real> a = S[kx * BS + gI[u] * NB + col], b = S[kx * BS + gJ[u] * NB + col];
+                    acc[u] += (double)(w * (a.x * b.x + a.y * b.y));
                 }
             }
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                if (gI[u] == gJ[u]) acc[u] *= 0.5;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, 64);
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) for (int u = 0; u < G; u++) s_red[(tid >> 6) * G + u] = acc[u];
+            __syncthreads();
+            if (tid < ng) {
+                const int gi = p.gridSubset[gI[tid]], gj = p.gridSubset[gJ[tid]];
+                const int slice = gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi;
+                double tot = 0; for (int w = 0; w < NT / 64; w++) tot += s_red[w * G + tid];
+                atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, p.nsubTotal * (p.nsubTotal + 1))[2 * slice + term], tot);
+            }
+            ng = 0;
+        };
+        for (int u = 0; u < G; u++) { gI[u] = 0; gJ[u] = 0; }
+        for (int I = 0; I < nsub; I++)
+            for (int J = 0; J <= I; J++) {
+                const int gi = p.gridSubset[I], gj = p.gridSubset[J];
+                if (!p.sliceNeed[gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi]) continue;      // (uniform)
+                gI[ng] = I; gJ[ng] = J; ng++;
+                if (ng == G) flushGroup();
+            }
+        if (ng > 0) flushGroup();
     }
     // convolution with the lambda mix:  O_I = eterm * sum_J lambda[slice(I,J)][term] * S_J   (mix=0: O_I = eterm * S_I)
     bool mixedOnMatrixCores = false;

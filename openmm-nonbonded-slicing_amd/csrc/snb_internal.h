@@ -247,6 +247,7 @@ template <typename Real> struct GatherCells {
     // displacement watch (posRef == nullptr: off): positions at the last rebuild; flags[0] |= 1 when an atom has moved further than
     // sqrt(warn2) (time to rebuild), flags[1] |= 1 beyond sqrt(fail2) = skin/2 (the list may already have missed a pair)
     const typename Vec<Real>::T4* posRef; int* flags; Real warn2, fail2;
+    double* clearE; int nClearE;      // energy steps: the slice-energy partitions, zeroed by this pass (a memset of their own was a 5 us launch)
 };
 
 template <typename Real> void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
