@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
     };
     struct TileHead { int slice, maskIdx; };
     // energy steps: a tile whose slice is not wanted (p.sliceNeed) runs the forces-only arithmetic
-    auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x & 0xFFFF, v.y}; };      // (slice of the tile [low 16 bits; the rest is the sub-tile occupancy of k_directSub], mask index)
+    auto loadHead = [&](int t) { const int4 v = p.tileInfo[t]; return TileHead{v.x & 0xFFFF, v.y}; };      // (slice of the tile, mask index)
     auto loadMask = [&](const TileHead& h) { return (h.maskIdx >= 0) ? p.masks[h.maskIdx * 32 + il] : 0u; };
     int jcode = p.tileJ[tBegin * 32 + stageJ];
     TileHead head = loadHead(tBegin);
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     auto requestList = [&](TileRegs& r, int t) {                    // list entry + header of tile t
         r.jcode = p.tileJ[t * 32 + stageJ];
         const int2 v = *reinterpret_cast<const int2*>(&p.tileInfo[t + vzero]);
-        r.slice = v.x; r.maskIdx = v.y;      // (bits 16.. of .x: sub-tile occupancy, used by k_directSub; masked off where the slice is consumed, never at the load)
+        r.slice = v.x; r.maskIdx = v.y;
     };
     auto requestAtoms = [&](TileRegs& r) {                          // needs r.jcode / r.slice / r.maskIdx (requested a tile earlier)
         const int code = r.jcode;
@@ -611,283 +611,6 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
 }
 
 
-// ---- single-precision tile kernel with sub-tile skipping (the production path for lists built on the GPU) -------------------------
-// A 32x32 tile is evaluated as 4 i-octets x 2 j-halves.  The builder orders the atoms of a block into four spatially compact octets
-// (neighbor.hip, k_nbBlockOrder), orders the gathered j-atoms of a block by WHICH octets they can reach within the list radius, and
-// records per tile an 8-bit occupancy (bit 4 h + g: some atom of j-half h is within the list radius of some atom of octet g); an
-// (octet, half) sub-tile whose bit is clear cannot hold a pair inside the cutoff for the lifetime of the list and is skipped --
-// 28 % of them on bulk water.  One wave-step = one sub-tile = 8 i x 16 j = 128 pair slots, packed fp32 over an i-PAIR:
-//   lane l: i-pair ip = l & 3 (atoms 8 g + 2 ip, 8 g + 2 ip + 1 of octet g), j-slot jl = l >> 2 (atom 16 h + jl of the tile).
-// The i-atoms of all four octets stay in registers for the whole work item (packed once); the two j-atoms of a lane are gathered
-// straight into its registers (no LDS staging; the four lanes of a quad issue the same address).  Both force accumulators are
-// lane-local: fi[g] += f d and fj += f d are packed FMAs -- no rotation, no cross-lane traffic per step.  A j-half ends with a
-// two-step quad reduction and ONE atomic instruction (lane ip writes component ip); the i-forces are reduced over the 16 j-slots
-// once per work item.  lambda is folded into the j-atom's charge and epsilon when the tile is staged.
-// ENERGY: raw pair energies per slice beside the forces (degree-13 erf polynomial), as in k_directPacked.
-__device__ inline float quadSwap1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }      // quad_perm [1,0,3,2]
-__device__ inline float quadSwap2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }      // quad_perm [2,3,0,1]
-__device__ inline float rowRor4(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true)); }
-
-template <int MC, bool MASKED, bool POLY, bool ENERGY, bool SWITCH>
-__device__ __forceinline__ void subStep(const DirectParams<float>& p, const v2f pix, const v2f piy, const v2f piz, const v2f sigi, const v2f epsi, const v2f qi, const v2f c6i,
-                                        const float4 xj, const float2 sj, const float lamC, const float lamL, const bool exA, const bool exB,
-                                        v2f& fix, v2f& fiy, v2f& fiz, v2f& fjx, v2f& fjy, v2f& fjz, v2f& ecl, v2f& elj) {
-    const v2f dx = pix - xj.x, dy = piy - xj.y, dz = piz - xj.z;
-    const v2f r2 = dx * dx + dy * dy + dz * dz;
-    const v2f invR = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
-    // Lennard-Jones (sigeps holds sigma/2 and 2 sqrt(eps); forces-only: the j epsilon already carries lambda_vdW)
-    v2f s2 = (sigi + sj.x) * invR; s2 = s2 * s2;
-    const v2f s6 = s2 * s2 * s2;
-    const v2f es6 = (epsi * sj.y) * s6;
-    v2f fl = es6 * (s6 * 12.0f - 6.0f);
-    v2f eLJ = {0.f, 0.f}, eC = {0.f, 0.f};
-    if (ENERGY) eLJ = es6 * (s6 - 1.0f);
-    if (SWITCH) {      // (ReferenceSlicedLJCoulombIxn.cpp:380-384, 428-431): branch-free, tt clamps to 0 below the switching distance
-        const v2f r = r2 * invR;
-        v2f tt = (r - p.switchDist) * p.invSwitchWidth;
-        tt.x = tt.x > 0.0f ? tt.x : 0.0f; tt.y = tt.y > 0.0f ? tt.y : 0.0f;
-        const v2f t2 = tt * tt;
-        const v2f sw = (t2 * tt) * ((tt * -6.0f + 15.0f) * tt + -10.0f) + 1.0f;
-        const v2f dsw = t2 * ((tt * -30.0f + 60.0f) * tt + -30.0f) * p.invSwitchWidth;
-        fl = fl * sw - (es6 * (s6 - 1.0f)) * (dsw * r);
-        if (ENERGY) eLJ = eLJ * sw;
-    }
-    const v2f invR2 = invR * invR;
-    if (MC == MC_LJPME) {      // (ReferenceSlicedLJCoulombIxn.cpp:398-426)
-        const v2f dar2 = r2 * (p.alphaD * p.alphaD), dar4 = dar2 * dar2;
-        const float sj3 = sj.x * sj.x * sj.x;
-        const v2f c6 = c6i * (8.0f * sj3 * sj.y);
-        const v2f coef = (invR2 * invR2 * invR2) * c6;
-        const v2f ed = dar2 * -1.4426950408889634f;
-        const v2f expd = {__builtin_amdgcn_exp2f(ed.x), __builtin_amdgcn_exp2f(ed.y)};
-        const v2f epre = dar4 * 0.5f + dar2 + 1.0f;
-        const v2f dpre = (dar4 * dar2) * (1.0f / 6.0f) + epre;
-        fl = fl + (coef * 6.0f) * (1.0f - expd * dpre);
-        if (ENERGY) {
-            const v2f sg = sigi + sj.x;
-            v2f sg2 = sg * sg; const v2f sg6 = (sg2 * sg2 * sg2) * p.invCut6;
-            eLJ = eLJ + coef * (1.0f - expd * epre) + (epsi * sj.y) * ((1.0f - sg6) * sg6) - c6 * p.multShift6;
-        }
-    }
-    // Coulomb: fc = (dE/dr)/r of the method's pair term (forces-only: the j charge carries lambda_elec and 1/(4 pi eps0))
-    const v2f qq = qi * xj.w;
-    v2f fc;
-    if ((MC == MC_EWALD || MC == MC_LJPME) && POLY) {
-        const v2f t = r2 * p.ewScale - 1.0f;
-        v2f bt = t * p.ewPoly[11] + p.ewPoly[10];
-#pragma unroll
-        for (int k = 9; k >= 0; k--) bt = bt * t + p.ewPoly[k];
-        fc = qq * (invR2 * invR - bt);
-        if (ENERGY) {
-            v2f et = t * p.ewPolyE[13] + p.ewPolyE[12];
-#pragma unroll
-            for (int k = 11; k >= 0; k--) et = et * t + p.ewPolyE[k];
-            eC = qq * (invR - et);
-        }
-    } else if (MC == MC_EWALD || MC == MC_LJPME) {
-        const v2f ar = (r2 * invR) * p.alpha;
-        const v2f e2 = r2 * (-p.alpha2l2e);
-        const v2f ex = {__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
-        const v2f den = ar * 0.3275911f + 1.0f;
-        const v2f tt = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-        v2f poly = tt * 1.061405429f + (-1.453152027f);
-        poly = poly * tt + 1.421413741f;
-        poly = poly * tt + (-0.284496736f);
-        poly = poly * tt + 0.254829592f;
-        const v2f erfcv = poly * tt * ex;
-        fc = ((qq * invR) * (erfcv + (ar * ex) * 1.1283791670955126f)) * invR2;
-        if (ENERGY) eC = (qq * invR) * erfcv;
-    } else {      // MC_RF
-        fc = (qq * (invR - r2 * (2.0f * p.krf))) * invR2;
-        if (ENERGY) eC = qq * (invR + r2 * p.krf - p.crf);
-    }
-    v2f f;
-    if (ENERGY) f = (fl * invR2) * lamL + fc * lamC;      // raw parameters on energy steps: lambda applied here
-    else f = fl * invR2 + fc;
-    bool inA = r2.x < p.cutoff2, inB = r2.y < p.cutoff2;
-    if (MASKED) { inA = inA && !exA; inB = inB && !exB; }
-    f.x = inA ? f.x : 0.0f; f.y = inB ? f.y : 0.0f;
-    if (ENERGY) {
-        eC.x = inA ? eC.x : 0.0f; eC.y = inB ? eC.y : 0.0f; eLJ.x = inA ? eLJ.x : 0.0f; eLJ.y = inB ? eLJ.y : 0.0f;
-        ecl = ecl + eC; elj = elj + eLJ;
-    }
-    fix = fix + f * dx; fiy = fiy + f * dy; fiz = fiz + f * dz;
-    fjx = fjx + f * dx; fjy = fjy + f * dy; fjz = fjz + f * dz;
-}
-
-template <int MC, bool POLY, bool ENERGY, bool SWITCH>
-__global__ __launch_bounds__(256, 3) void k_directSub(const DirectParams<float> p, const PairListParams<float> q, const int nExclBlocks, const int nListBlocks) {
-    if ((int)blockIdx.x < nListBlocks) {
-        if ((int)blockIdx.x < nExclBlocks) { PairListParams<float> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<float, false>(qe, blockIdx.x); }
-        else exceptionsBody<float, false>(q, blockIdx.x - nExclBlocks);
-        return;
-    }
-    const int tileBlock = blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
-    double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
-    __shared__ float4 s_shift[128];             // lattice-image shift of every 7-bit image code
-    __shared__ float4 s_iatoms[4][16][3];       // per wave: the block's 16 i-pairs, packed: (x0,x1,y0,y1) (z0,z1,q0,q1) (sig0,sig1,eps0,eps1)
-    __shared__ uint2 s_rows[4][16];             // per wave: exclusion-mask words of the current tile, two i-rows per entry
-    if (threadIdx.x < 128) {
-        const int sc = threadIdx.x;
-        const int kx = sc / 25, ky = (sc - 25 * kx) / 5, kz = sc - 25 * kx - 5 * ky;
-        const float ka = float(kx - 2), kb = float(ky - 2), kc = float(kz - 2);
-        s_shift[sc] = sc < 125 ? make_float4(ka * p.box[0] + kb * p.box[3] + kc * p.box[6], kb * p.box[4] + kc * p.box[7], kc * p.box[8], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ip = lane & 3, jl = lane >> 2;
-    float* const fcomp = ip == 0 ? p.fx : (ip == 1 ? p.fy : p.fz);      // the force component this lane scatters for its j-atom
-    const float4 (*iat)[3] = s_iatoms[wid];
-    uint2* rows = s_rows[wid];
-    int4 wiNext = p.workItems[p.workStart + (tileBlock * 4 + wid < p.numWork ? tileBlock * 4 + wid : 0) * p.workStride];
-    for (int item = tileBlock * 4 + wid; item < p.numWork; item += nTileBlocks * 4) {
-        const int4 wi = wiNext;
-        { const int nx = item + nTileBlocks * 4; wiNext = p.workItems[p.workStart + (nx < p.numWork ? nx : item) * p.workStride]; }      // the next item's descriptor travels during this one
-        const int I = __builtin_amdgcn_readfirstlane(wi.x);
-        const int tBegin = __builtin_amdgcn_readfirstlane(wi.y), tEnd = tBegin + __builtin_amdgcn_readfirstlane(wi.z);
-        // the block's own atoms and the first list entry are requested together (one memory round trip, not two)
-        float4 ipa, ipb, ise;
-        {
-            const int a0 = I * 32 + 2 * (lane & 15);      // i-pair (lane & 15) = atoms 2 k, 2 k + 1 (octet k >> 2, pair k & 3)
-            ipa = p.posq[a0]; ipb = p.posq[a0 + 1]; ise = *reinterpret_cast<const float4*>(&p.sigeps[a0]);
-        }
-        v2f fix[4], fiy[4], fiz[4];
-#pragma unroll
-        for (int g = 0; g < 4; g++) { fix[g] = v2f{0.f, 0.f}; fiy[g] = v2f{0.f, 0.f}; fiz[g] = v2f{0.f, 0.f}; }
-        v2f ecl = {0.f, 0.f}, elj = {0.f, 0.f};
-        int curSlice = -1;
-        auto flushEnergy = [&]() {
-            if (curSlice >= 0) {
-                const double a = waveSum((double)ecl.x + (double)ecl.y), b = waveSum((double)elj.x + (double)elj.y);
-                if (lane == 0) { atomicAdd(&sliceE[2 * curSlice], a); atomicAdd(&sliceE[2 * curSlice + 1], b); }
-            }
-            ecl = {0.f, 0.f}; elj = {0.f, 0.f};
-        };
-        // Software pipeline over the item's tiles (the wait counter of gfx950 is in-order: every wait must come when nothing younger than
-        // its target is in flight except a known number of requests):
-        //   trip t:  [touch the list entry of t+1]  [j-force atomics of t-1]  [request the atoms of t+1]  [request the list entry of t+2]
-        //            [evaluate t from staged registers + LDS]  [stage t+1: wait for its atoms -- a whole tile old, three requests younger]
-        // Two list sets alternate (the loop is unrolled by two) so that no requested register is ever copied.
-        struct ListRegs { int code0, code1, head, maskIdx; };
-        struct AtomRegs { float4 pj0, pj1; float2 se0, se1; unsigned mrow; float2 lam; int need; };
-        struct Staged { float4 xj0, xj1; float2 sj0, sj1; int idx0, idx1; unsigned mrow; float lamC, lamL; int sm, slice; bool hasMask; };
-        ListRegs LA, LB; AtomRegs AT; Staged st;
-        int vzero; asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-        float pend0 = 0.f, pend1 = 0.f; int pendIdx0 = -1, pendIdx1 = -1;
-        auto requestList = [&](ListRegs& r, int t) {
-            r.code0 = p.tileJ[t * 32 + jl]; r.code1 = p.tileJ[t * 32 + 16 + jl];
-            const int2 v = *reinterpret_cast<const int2*>(&p.tileInfo[t + vzero]);
-            r.head = v.x; r.maskIdx = v.y;
-        };
-        auto requestAtoms = [&](const ListRegs& r) {
-            const int c0 = r.code0, c1 = r.code1;
-            asm volatile("" :: "v"(c0), "v"(c1), "v"(r.head), "v"(r.maskIdx));      // the wait for the list entry belongs HERE, before anything younger is issued
-            if (pendIdx0 >= 0) gAdd(&fcomp[pendIdx0 * p.fs], pend0);
-            if (pendIdx1 >= 0) gAdd(&fcomp[pendIdx1 * p.fs], pend1);
-            const int i0 = c0 == -1 ? 0 : (c0 & SNB_JIDX_MASK), i1 = c1 == -1 ? 0 : (c1 & SNB_JIDX_MASK);
-            AT.pj0 = p.posq[i0]; AT.se0 = p.sigeps[i0]; AT.pj1 = p.posq[i1]; AT.se1 = p.sigeps[i1];
-            const int mi = r.maskIdx < 0 ? 0 : r.maskIdx;
-            AT.mrow = p.masks[mi * 32 + (lane & 31)];      // i-row (lane & 31) of the tile's exclusion mask (unconditional: no phi, exact wait counts)
-            AT.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * (r.head & 0xFFFF)]);
-            if (ENERGY) AT.need = p.sliceNeed[r.head & 0xFFFF];
-        };
-        auto stage = [&](const ListRegs& r) {      // atoms of the tile whose list entry is r -> evaluation-ready registers
-            const float4 sh0 = s_shift[(r.code0 >> SNB_JSHIFT_BITS) & 127], sh1 = s_shift[(r.code1 >> SNB_JSHIFT_BITS) & 127];
-            st.lamC = AT.lam.x; st.lamL = AT.lam.y;
-            const float qs = ENERGY ? p.k4pe : p.k4pe * st.lamC, es = ENERGY ? 1.0f : st.lamL;
-            const bool v0 = r.code0 != -1, v1 = r.code1 != -1;      // padding slots: parked far away, no charge, no LJ
-            st.xj0 = v0 ? make_float4(AT.pj0.x + sh0.x, AT.pj0.y + sh0.y, AT.pj0.z + sh0.z, AT.pj0.w * qs) : make_float4(3e9f + 1e6f * lane, -5e9f, 7e9f, 0.f);
-            st.xj1 = v1 ? make_float4(AT.pj1.x + sh1.x, AT.pj1.y + sh1.y, AT.pj1.z + sh1.z, AT.pj1.w * qs) : make_float4(3e9f + 1e6f * lane, 5e9f, -7e9f, 0.f);
-            st.sj0 = v0 ? make_float2(AT.se0.x, AT.se0.y * es) : make_float2(0.f, 0.f);
-            st.sj1 = v1 ? make_float2(AT.se1.x, AT.se1.y * es) : make_float2(0.f, 0.f);
-            st.idx0 = (ip < 3 && v0) ? (r.code0 & SNB_JIDX_MASK) : -1; st.idx1 = (ip < 3 && v1) ? (r.code1 & SNB_JIDX_MASK) : -1;
-            st.mrow = AT.mrow;
-            st.sm = __builtin_amdgcn_readfirstlane(r.head >> 16) & 0xFF;
-            st.slice = __builtin_amdgcn_readfirstlane(r.head) & 0xFFFF;
-            st.hasMask = __builtin_amdgcn_readfirstlane(r.maskIdx) >= 0;
-        };
-        // the eight sub-tiles of the staged tile; the i-pair of the NEXT position is read from LDS before the current one is evaluated
-        auto evaluate = [&](auto maskedTag) {
-            constexpr bool MASKED = decltype(maskedTag)::value;
-            const int sm = st.sm;
-            const float lamC = st.lamC, lamL = st.lamL;
-            float4 ia = iat[ip][0], ib = iat[ip][1], ic = iat[ip][2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const float4 xj = h ? st.xj1 : st.xj0; const float2 sj = h ? st.sj1 : st.sj0;
-                v2f fjx = {0.f, 0.f}, fjy = {0.f, 0.f}, fjz = {0.f, 0.f};
-                const unsigned jmask = 1u << (16 * h + jl);
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const float4 ca = ia, cb = ib, cc = ic;
-                    const int gn = (g + 1) & 3;
-                    __builtin_amdgcn_sched_barrier(0);      // (keeps the scheduler from hoisting all eight positions' reads to the top: 96 live registers)
-                    ia = iat[4 * gn + ip][0]; ib = iat[4 * gn + ip][1]; ic = iat[4 * gn + ip][2];
-                    __builtin_amdgcn_sched_barrier(0);
-                    if ((sm >> (4 * h + g)) & 1) {
-                        const v2f pix = {ca.x, ca.y}, piy = {ca.z, ca.w}, piz = {cb.x, cb.y}, qi = {cb.z, cb.w}, sigi = {cc.x, cc.y}, epsi = {cc.z, cc.w};
-                        v2f c6i = {0.f, 0.f};
-                        if (MC == MC_LJPME) c6i = v2f{8.0f * cc.x * cc.x * cc.x * cc.z, 8.0f * cc.y * cc.y * cc.y * cc.w};
-                        bool exA = false, exB = false;
-                        if (MASKED) { const uint2 mr = rows[4 * g + ip]; exA = (mr.x & jmask) != 0u; exB = (mr.y & jmask) != 0u; }
-                        subStep<MC, MASKED, POLY, ENERGY, SWITCH>(p, pix, piy, piz, sigi, epsi, qi, c6i, xj, sj, lamC, lamL, exA, exB, fix[g], fiy[g], fiz[g], fjx, fjy, fjz, ecl, elj);
-                    }
-                }
-                // the two i-atoms of the lane, then the four i-pairs of the quad; lane ip keeps component ip
-                float sx = fjx.x + fjx.y, sy = fjy.x + fjy.y, sz = fjz.x + fjz.y;
-                sx += quadSwap1(sx); sy += quadSwap1(sy); sz += quadSwap1(sz);
-                sx += quadSwap2(sx); sy += quadSwap2(sy); sz += quadSwap2(sz);
-                const float v = -(ip == 0 ? sx : (ip == 1 ? sy : sz));
-                if (h == 0) { pend0 = v; pendIdx0 = st.idx0; } else { pend1 = v; pendIdx1 = st.idx1; }
-            }
-        };
-        auto trip = [&](ListRegs& Lnext, ListRegs& Lafter, const int t) {      // Lnext: list entry of t+1 (loaded), Lafter: receives the one of t+2
-            requestAtoms(Lnext);
-            requestList(Lafter, t + 2 < tEnd ? t + 2 : tEnd - 1);
-            if (ENERGY && st.slice != curSlice) { flushEnergy(); curSlice = st.slice; }
-            if (st.hasMask) {
-                __builtin_amdgcn_wave_barrier();
-                if (lane < 32) reinterpret_cast<unsigned*>(rows)[lane] = st.mrow;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                evaluate(std::true_type{});
-            } else evaluate(std::false_type{});
-            stage(Lnext);
-        };
-        requestList(LA, tBegin);
-        __builtin_amdgcn_wave_barrier();      // (the previous item's readers of the i-atom table are done)
-        if (lane < 16) { s_iatoms[wid][lane][0] = make_float4(ipa.x, ipb.x, ipa.y, ipb.y); s_iatoms[wid][lane][1] = make_float4(ipa.z, ipb.z, ipa.w, ipb.w); s_iatoms[wid][lane][2] = make_float4(ise.x, ise.z, ise.y, ise.w); }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        requestAtoms(LA);
-        requestList(LB, tBegin + 1 < tEnd ? tBegin + 1 : tBegin);
-        stage(LA);
-        for (int t = tBegin; t < tEnd; t += 2) {
-            trip(LB, LA, t);
-            if (t + 1 < tEnd) trip(LA, LB, t + 1);
-        }
-        if (pendIdx0 >= 0) gAdd(&fcomp[pendIdx0 * p.fs], pend0);
-        if (pendIdx1 >= 0) gAdd(&fcomp[pendIdx1 * p.fs], pend1);
-        pendIdx0 = pendIdx1 = -1;
-        // i-forces: sum over the 16 j-slots (lanes with the same ip), then lane (jl = g, ip) adds octet g's pair
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            float v[6] = {fix[g].x, fix[g].y, fiy[g].x, fiy[g].y, fiz[g].x, fiz[g].y};
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                v[k] += rowRor4(v[k]); v[k] += rowRor8(v[k]);
-                v[k] += __shfl_xor(v[k], 16, 64); v[k] += __shfl_xor(v[k], 32, 64);
-            }
-            if (jl == g) {
-                const int a0 = I * 32 + 8 * g + 2 * ip;
-                fAdd(p, p.fx, a0, v[0]); fAdd(p, p.fy, a0, v[2]); fAdd(p, p.fz, a0, v[4]); fAdd(p, p.fx, (a0 + 1), v[1]); fAdd(p, p.fy, (a0 + 1), v[3]); fAdd(p, p.fz, (a0 + 1), v[5]);
-            }
-        }
-        if (ENERGY) { flushEnergy(); curSlice = -1; }
-    }
-}
-
 // evStart/evStop (both or neither): hipExtLaunchKernelGGL stamps them with the kernel's own begin and end -- the duration rocprofv3 reports,
 // without the marker-packet overhead of hipEventRecord pairs around the launch.  *timed tells the caller whether a kernel took them.
 #define SNB_LAUNCH_LDS(KERNEL, GRID, LDS, ...) do { if (evStart) { hipExtLaunchKernelGGL(KERNEL, GRID, block, LDS, s, evStart, evStop, 0, __VA_ARGS__); *timed = true; } \
@@ -909,20 +632,6 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
             const size_t listLds = (lists && energy) ? sizeof(double) * 2 * q.nSlices : 0;      // the energy list bodies reduce per slice in LDS
             dim3 gridAll(nwg + nListBlocks);
             const bool poly = (MC == MC_EWALD || MC == MC_LJPME) && p.ewUsePoly;
-            if constexpr (MC != MC_NOCUTOFF) {
-                if (p.subTiles) {      // lists built on the GPU carry octet-ordered blocks and sub-tile occupancies
-#define SNB_SUB(P, E, S) SNB_LAUNCH((k_directSub<MC, P, E, S>), gridAll, p, q, nExclBlocks, nListBlocks)
-                    if (p.useSwitch && MC != MC_LJPME) {
-                        if (energy) { if (poly) SNB_SUB(true, true, true); else SNB_SUB(false, true, true); }
-                        else { if (poly) SNB_SUB(true, false, true); else SNB_SUB(false, false, true); }
-                    } else {
-                        if (energy) { if (poly) SNB_SUB(true, true, false); else SNB_SUB(false, true, false); }
-                        else { if (poly) SNB_SUB(true, false, false); else SNB_SUB(false, false, false); }
-                    }
-#undef SNB_SUB
-                    return lists != nullptr && !energy;
-                }
-            }
 #define SNB_PACKED(P, E, S) do { if (p.fixed) SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S, true>), gridAll, listLds, p, q, nExclBlocks, nListBlocks); \
                                  else SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S, false>), gridAll, listLds, p, q, nExclBlocks, nListBlocks); } while (0)
             if constexpr (MC == MC_NOCUTOFF) { if (energy) SNB_PACKED(false, true, false); else SNB_PACKED(false, false, false); }

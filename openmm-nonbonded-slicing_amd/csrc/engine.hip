@@ -207,22 +207,7 @@ public:
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // views of forceBuf (7 Npad values, cleared by the position-gather pass)
-    int fstride = 1;      // direct-space accumulators: 1 = three arrays (fx | fy | fz | -), 4 = one (x, y, z, -) record per atom
-    // The sub-tile pair kernel scatters a j-atom's three components from three adjacent lanes: with one record per atom they fall into
-    // one 16-byte slot, i.e. ONE atomic request per j-atom wherever it lies; three separate arrays cost three, and the gathered j-atoms
-    // of a signature-ordered tile are not neighbours in memory (measured: 0.35 ms against 0.25 with the unordered list).
-    // The sub-tile pair kernel (direct.hip, k_directSub) and the list order it needs are an EXPERIMENT kept behind SNB_SUBTILES (1: octet
-    // order + signature-ordered j entries, 2: octet order only): measured on c3 it evaluates 28 % fewer pair slots with 30 % fewer VALU
-    // instructions than k_directPacked and is still slower, 0.258 ms against 0.205 -- its gathers and j-force atomics lose the locality
-    // of the column-ordered list and it becomes bound by the memory pipeline.
-    static int subTileMode() {
-        static const int mode = [] { const char* e = getenv("SNB_SUBTILES"); const int v = e ? atoi(e) : 0; return v == 1 ? 3 : (v == 2 ? 1 : 0); }();
-        return mode;
-    }
-    bool recordForces() const {
-        static const bool soa = getenv("SNB_FORCE_SOA") != nullptr;
-        return sizeof(Real) == 4 && cfg.precision != SNB_MIXED && cfg.method != SNB_NoCutoff && !cfg.host_neighbor_build && subTileMode() != 0 && !soa;
-    }
+    int fstride = 1;      // index stride of an atom in the direct-space accumulators (three arrays fx | fy | fz: 1)
     // SNB_MIXED: single-precision arithmetic, direct-space forces accumulated in 64-bit fixed point (direct.hip, fAdd) -- three arrays of
     // Npad 64-bit words (6 Npad floats, one spare), then the three reciprocal arrays: 10 Npad floats, all cleared by the gather pass
     bool fixedForces() const { return sizeof(Real) == 4 && cfg.precision == SNB_MIXED; }
@@ -235,11 +220,11 @@ public:
             fpx.p = forceBuf.p + 7 * (size_t)Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
             return;
         }
-        fstride = recordForces() ? 4 : 1;
-        fx.p = forceBuf.p; fy.p = fx.p + (fstride == 4 ? 1 : Npad); fz.p = fx.p + (fstride == 4 ? 2 : 2 * (size_t)Npad);
+        fstride = 1;
+        fx.p = forceBuf.p; fy.p = fx.p + Npad; fz.p = fx.p + 2 * (size_t)Npad;
         fpx.p = forceBuf.p + 4 * (size_t)Npad; fpy.p = fpx.p + Npad; fpz.p = fpy.p + Npad;
     }
-    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC, dAtomCell, dExtent, dPermOf;
+    DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC, dAtomCell, dExtent;
     double tileCell[9] = {0};      // the cell the tile image codes refer to (the box; an enclosing cell for CutoffNonPeriodic)
     DevBuf<long long> dNbTrace, dPmeTrace;
     bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
@@ -986,8 +971,6 @@ public:
         p.slotOfSubset = dSlotOfSubset.p;
         p.wrapped = dWrapped.p; p.offsetU = dOffsetU.p; p.keysIn = dKeysIn.p; p.keysOut = dKeysOut.p; p.valsIn = dValsIn.p; p.valsOut = dValsOut.p;
         p.segKey = dValsIn.p; p.segStart = dScanA.p; p.padExtra = dScanB.p; p.padBefore = dScanA.p;   // valsIn is dead once the sort has run
-        p.slotMap = dScanB.p;      // (padExtra is dead once phase A has produced the padded count)
-        p.orderBlocks = subTileMode();      // bit 0: octet order inside blocks, bit 1: j entries ordered by octet signature (0: neither, the default)
         dScanC.resize(N); p.blockWide = dScanC.p; p.blockWideOut = dScanC.p;
         for (int d = 0; d < 3; d++) p.maxHalfExtent[d] = (float)(0.45 * (box[4 * d] - 2.0 * R));   // extent <= 0.9 (L - 2R)
         p.userToSorted = dUserToSorted.p; p.colRange = colRange.p; p.zIndex = dZIndex.p; p.counters = dCounters.p;
@@ -1049,7 +1032,6 @@ public:
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;
             dAtomCell.resize(Npad); p.atomCell = dAtomCell.p;
-            dPermOf.resize(Npad); p.permOf = dPermOf.p;
             static const bool nbTrace = getenv("SNB_NB_TRACE") != nullptr;
             if (nbTrace) { dNbTrace.resize((size_t)4 * numBlocks); p.dbgOut = dNbTrace.p; }
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.workItems = workItems.p; p.workItemsStage = workItemsStage.p; p.workItemsPartial = workItemsPartial.p; p.counters = dCounters.p;
@@ -1291,7 +1273,6 @@ public:
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.fs = fstride; p.fixed = fixedForces(); p.sliceE = sliceE.p; p.lambdas = dLambdas.p; p.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p;
             const int r = cfg.shard_rank, c = cfg.shard_count;
             (void)r; (void)c;
-            p.subTiles = (gpuBuilt && !wrapMode && subTileMode() != 0 && !fixedForces()) ? 1 : 0;
             p.workStart = 0; p.workStride = 1; p.numWork = numWorkItems;      // the lists hold only the i-blocks this engine owns (block % shard_count == shard_rank)
             p.nsub = nsub;
             p.cutoff2 = (Real)(cfg.cutoff * cfg.cutoff);

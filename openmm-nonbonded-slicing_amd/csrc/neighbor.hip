@@ -119,81 +119,6 @@ template <typename Real> __global__ void k_nbPadTotal(const NbParams<Real> p) {
     if (blockIdx.x == 0 && threadIdx.x == 0) p.counters[7] = p.nAtoms + p.padBefore[p.nAtoms - 1] + p.padExtra[p.nAtoms - 1];
 }
 
-// ---- 1c. compact octets inside every block ---------------------------------------------------------------------------
-// The pair kernel evaluates a 32x32 tile as 4 i-octets x 2 j-halves and skips the sub-tiles in which no pair can come within the list
-// radius (direct.hip, k_directSub).  That only pays if the 8 atoms of an octet are close together: here the 32 atoms of a block -- a
-// z-sorted piece of a column, i.e. a stack of thin slabs -- are re-ordered by two median cuts (the block's widest axis, then each
-// half's widest axis) into four compact groups of (up to) 8: slots 0-7, 8-15, 16-23, 24-31.  One 32-lane half-wave per block, lanes =
-// the block's padded slots.  Blocks that hold atoms of two (subset, column) runs keep their order (4 % of them): the PME brick kernels
-// and the candidate search rely on every run being ONE interval of the padded order.  slotMap[t] = padded index of sorted rank t.
-template <typename Real> __global__ __launch_bounds__(256) void k_nbBlockOrder(const NbParams<Real> p) {
-    const int lane = threadIdx.x & 63, k = lane & 31;
-    const int b = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-    const int base = lane & 32;                                   // first lane of my half-wave
-    // first sorted rank whose padded index is >= 32 b (padded indices ascend with the rank)
-    int lo = 0, hi = p.nAtoms;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (mid + p.padBefore[mid] < 32 * b) lo = mid + 1; else hi = mid; }
-    const int t = lo + k;
-    const bool valid = b < p.nBlocks && t < p.nAtoms && (t + p.padBefore[t] == 32 * b + k);
-    float c[3] = {0.f, 0.f, 0.f};
-    unsigned long long run = 0ull;
-    if (valid) {
-        const int u = p.valsOut[t];
-        c[0] = (float)p.wrapped[3 * (size_t)u]; c[1] = (float)p.wrapped[3 * (size_t)u + 1]; c[2] = (float)p.wrapped[3 * (size_t)u + 2];
-        run = p.keysOut[t] >> 20;
-    }
-    const unsigned long long vmask64 = __ballot(valid);
-    const unsigned vmask = (unsigned)(vmask64 >> base);
-    const int cnt = __popc(vmask);
-    // relative to the block's first atom, nearest image (a block of a sparse subset may straddle the periodic boundary)
-    {
-        const float ox = __shfl(c[0], base, 64), oy = __shfl(c[1], base, 64), oz = __shfl(c[2], base, 64);
-        float dx = c[0] - ox, dy = c[1] - oy, dz = c[2] - oz;
-        minImage(dx, dy, dz, latticeOf(p));
-        c[0] = dx; c[1] = dy; c[2] = dz;
-    }
-    const unsigned long long run0 = __shfl(run, base, 64);
-    const bool sameRun = ((unsigned)(__ballot(valid && run != run0) >> base)) == 0u;
-    int slot = k;
-    if (p.orderBlocks && sameRun && cnt > 8) {         // (uniform over the half-wave)
-        // widest axis of a set of lanes (given as a 32-bit mask of my half-wave), as seen by every lane
-        auto widestAxis = [&](unsigned set) {
-            float best = -1.f; int axis = 0;
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                float mn = ((set >> k) & 1u) ? c[d] : 3e38f, mx = ((set >> k) & 1u) ? c[d] : -3e38f;
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
-                if (mx - mn > best) { best = mx - mn; axis = d; }
-            }
-            return axis;
-        };
-        // rank of my coordinate `v` among the lanes of `set` (ties broken by slot)
-        auto rankIn = [&](unsigned set, float v) {
-            int r = 0;
-            for (int j = 0; j < 32; j++) {
-                const float o = __shfl(v, base + j, 64);
-                if (((set >> j) & 1u) && (o < v || (o == v && j < k))) r++;
-            }
-            return r;
-        };
-        const int a1 = widestAxis(vmask);
-        const float v1 = a1 == 0 ? c[0] : (a1 == 1 ? c[1] : c[2]);
-        const int r1 = rankIn(vmask, v1);
-        const int nL = cnt < 16 ? cnt : 16;
-        const bool left = valid && r1 < nL;
-        const unsigned lmask = (unsigned)(__ballot(left) >> base), rmask = vmask & ~lmask;
-        const int aL = widestAxis(lmask), aR = rmask ? widestAxis(rmask) : 0;
-        const int a2 = left ? aL : aR;
-        const float v2 = a2 == 0 ? c[0] : (a2 == 1 ? c[1] : c[2]);
-        const int rl = rankIn(lmask, v2), rr = rankIn(rmask, v2);
-        // left half -> octets 0 (first 8) and 1, right half -> octets 2 and 3
-        if (left) slot = rl;                                        // ranks 0..nL-1 fill slots 0..nL-1: octet 0 first, then octet 1
-        else slot = 16 + rr;                                        // ranks 0..nR-1 fill slots 16..: octet 2 first, then octet 3
-    }
-    if (valid) p.slotMap[t] = 32 * b + slot;
-}
-
 // ---- 2. scatter into the padded sorted order ---------------------------------------------------------------------
 template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,7 +128,7 @@ template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     const int s = (int)(key >> (20 + p.colBits));
     const int serp = (int)((key >> 20) & ((1u << p.colBits) - 1u));
     const int si0 = t + p.padBefore[t];           // padded index in sorted order
-    const int si = p.orderBlocks ? p.slotMap[t] : si0;      // ... and after the in-block octet ordering (same block)
+    const int si = si0;
     if ((si0 & 31) == 0) p.blockSubset[si0 >> 5] = s;
     p.sortedToUser[si] = u; p.userToSorted[u] = si;
     typename Vec<Real>::T4 v; v.x = p.wrapped[3 * (size_t)u]; v.y = p.wrapped[3 * (size_t)u + 1]; v.z = p.wrapped[3 * (size_t)u + 2]; v.w = p.uCharge[u];
@@ -235,18 +160,12 @@ template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     const int col = cx * p.ncy + cy;
     // z-bucket index of the (subset, column) run: 64 buckets of the key's 20-bit z (already direction-flipped for odd columns, so every
     // run ascends in it).  zIndex[b] = first padded index (IN SORTED ORDER, si0) of the run with bucket >= b (k_nbZPrefix fills the empty
-    // buckets); positions, not counts, because segment padding may sit inside a run.  The candidate search walks intervals of the sorted
-    // order and finds the atoms through permOf[si0] = slot after the octet ordering.
-    p.permOf[si0] = si;
+    // buckets); positions, not counts, because segment padding may sit inside a run.
     atomicMin(&p.zIndex[((size_t)s * p.ncx * p.ncy + col) * 65 + (int)((key & 0xFFFFF) >> 14)], si0);
     // the run's interval of the padded order
-    if (p.orderBlocks) {      // min / max over its atoms (a re-ordered block lies inside ONE run, so runs stay disjoint)
-        atomicMin(&p.colRange[(size_t)s * p.ncx * p.ncy + col].x, si);
-        atomicMax(&p.colRange[(size_t)s * p.ncx * p.ncy + col].y, si + 1);
-    } else {                  // sorted order: the run's first and last atom
-        if ((t == 0) || ((p.keysOut[t - 1] >> 20) != (key >> 20))) p.colRange[(size_t)s * p.ncx * p.ncy + col].x = si;
-        if ((t == p.nAtoms - 1) || ((p.keysOut[t + 1] >> 20) != (key >> 20))) p.colRange[(size_t)s * p.ncx * p.ncy + col].y = si + 1;
-    }
+    // sorted order: the run's first and last atom
+    if ((t == 0) || ((p.keysOut[t - 1] >> 20) != (key >> 20))) p.colRange[(size_t)s * p.ncx * p.ncy + col].x = si;
+    if ((t == p.nAtoms - 1) || ((p.keysOut[t + 1] >> 20) != (key >> 20))) p.colRange[(size_t)s * p.ncx * p.ncy + col].y = si + 1;
 }
 
 template <typename Real> __global__ void k_nbZPrefix(const NbParams<Real> p) {
@@ -328,13 +247,10 @@ template <typename Real> __device__ inline int runLowerBound(const NbParams<Real
     return lo;
 }
 
-template <typename Real, bool SUB> __global__ __launch_bounds__(256) void k_nbBuildTiles(const NbParams<Real> p) {      // SUB: octet signatures / signature order / sub-tile occupancies (SNB_SUBTILES experiment)
+template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(const NbParams<Real> p) {
     __shared__ int s_list[4][NB_CAP];
     __shared__ unsigned s_mask[4][NB_MAXT][32];
     __shared__ int s_tileSub[4][NB_MAXT];
-    __shared__ unsigned char s_sig[4][SUB ? NB_CAP : 4];      // (LDS decides how many work-groups share a CU: the default build carries none of this)      // per gathered entry: which of the block's four octets it reaches within R (bit g)
-    __shared__ unsigned char s_tileSm[4][SUB ? NB_MAXT : 4];  // per tile: occupancy of its 8 sub-tiles, bit 4 h + g = (j-half h, i-octet g)
-    __shared__ int s_hist[4][SUB ? 16 : 1];
     __shared__ int s_query[4][128];      // exclusion partners (sorted index) still to be located in the gathered list
     __shared__ int s_qrow[4][128];       // ... and the i-row each belongs to
     __shared__ int s_imgI[4][27][5]; __shared__ float s_imgF[4][27][2];      // surviving lattice images of the block (see below)
@@ -351,7 +267,6 @@ template <typename Real, bool SUB> __global__ __launch_bounds__(256) void k_nbBu
     int* list = s_list[wid];
     unsigned (*mask)[32] = s_mask[wid];
     int* tileSub = s_tileSub[wid];
-    unsigned char* sig = s_sig[wid]; unsigned char* tileSm = s_tileSm[wid]; int* hist = s_hist[wid];
     int* query = s_query[wid];
     int* qrow = s_qrow[wid];
     int* cmbStart = s_cmb[wid][0]; int* cmbPrefix = s_cmb[wid][1]; int* cmbCode = s_cmb[wid][2];
@@ -454,20 +369,10 @@ template <typename Real, bool SUB> __global__ __launch_bounds__(256) void k_nbBu
             const int t = t2 + half;
             if (t < nT && ((anyBits >> t) & 1ull)) p.masks[(size_t)(mi0 + __popcll(anyBits & ((1ull << t) - 1ull))) * 32 + il] = mask[t][il];
         }
-        // sub-tile occupancy of every tile: OR of the entries' octet signatures over each 16-entry half
-        if constexpr (SUB) for (int t2 = 0; t2 < nT; t2 += 2) {
-            const int t = t2 + half;
-            int x = (t < nT) ? (int)sig[t * 32 + il] : 0;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) x |= __shfl_xor(x, o, 64);
-            const int hi = __shfl_down(x, 16, 64);
-            if (il == 0 && t < nT) tileSm[t] = (unsigned char)(x | (hi << 4));
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int subIb = p.blockSubset[I];
-        // tileInfo.x = slice | sub-tile occupancy << 16
-        for (int t = lane; t < nT; t += 64) p.tileInfo[first + t] = make_int4(nbSliceOf(subIb, tileSub[t]) | (SUB ? ((int)tileSm[t] << 16) : 0), ((anyBits >> t) & 1ull) ? mi0 + __popcll(anyBits & ((1ull << t) - 1ull)) : -1, tileSub[t], 0);
+        for (int t = lane; t < nT; t += 64) p.tileInfo[first + t] = make_int4(nbSliceOf(subIb, tileSub[t]), ((anyBits >> t) & 1ull) ? mi0 + __popcll(anyBits & ((1ull << t) - 1ull)) : -1, tileSub[t], 0);
         const int subI = p.blockSubset[I];      // carried in the work item: the pair kernel needs it before the block's atoms arrive
         for (int k = lane; k < nFull; k += 64) p.workItemsStage[w0 + k] = make_int4(I, first + CH * k, CH, subI);
         if (nPart && lane == 0) p.workItemsPartial[wp] = make_int4(I, first + CH * nFull, nT % CH, subI);
@@ -476,7 +381,7 @@ template <typename Real, bool SUB> __global__ __launch_bounds__(256) void k_nbBu
 
     const long long tProlog = p.dbgOut ? (long long)wall_clock64() : 0;
     // diagonal tile
-    if (lane < 32) { list[lane] = (uI >= 0) ? ((I * 32 + lane) | (SNB_JCODE_CENTER << SNB_JSHIFT_BITS)) : -1; if constexpr (SUB) sig[lane] = 0xF; }
+    if (lane < 32) { list[lane] = (uI >= 0) ? ((I * 32 + lane) | (SNB_JCODE_CENTER << SNB_JSHIFT_BITS)) : -1; }
     if (lane == 0) tileSub[0] = p.blockSubset[I];
     int count = 32;
     bool hasDiag = true;
@@ -540,32 +445,18 @@ template <typename Real, bool SUB> __global__ __launch_bounds__(256) void k_nbBu
                 px = (float)q.x + kx * Lt.ax + ky * Lt.bx + kz * Lt.cx; py = (float)q.y + ky * Lt.by + kz * Lt.cy; pz = (float)q.z + kz * Lt.cz;
             }
             typedef float v2f __attribute__((ext_vector_type(2)));
-            int sgv;
-            if constexpr (SUB) {      // sub-tile experiment: which octets of the block the atom reaches
-                float best[4] = {3e38f, 3e38f, 3e38f, 3e38f};      // per octet of the block (atoms 8 g .. 8 g + 7 = pairs 4 g .. 4 g + 3)
-#pragma unroll
-                for (int a = 0; a < 16; a++) {                // two i-atoms per pass (packed fp32), LDS broadcast reads
-                    const float4 xy = ipos[a]; const float2 zz = iposZ[a];
-                    const v2f ddx = v2f{xy.x, xy.y} - px, ddy = v2f{xy.z, xy.w} - py, ddz = v2f{zz.x, zz.y} - pz;
-                    const v2f d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-                    best[a >> 2] = fminf(best[a >> 2], fminf(d2.x, d2.y));
-                }
-                sgv = (best[0] < R2 ? 1 : 0) | (best[1] < R2 ? 2 : 0) | (best[2] < R2 ? 4 : 0) | (best[3] < R2 ? 8 : 0);
-            } else {
-                float best = 3e38f;
+            float best = 3e38f;
 #pragma unroll 8
-                for (int a = 0; a < 16; a++) {
-                    const float4 xy = ipos[a]; const float2 zz = iposZ[a];
-                    const v2f ddx = v2f{xy.x, xy.y} - px, ddy = v2f{xy.z, xy.w} - py, ddz = v2f{zz.x, zz.y} - pz;
-                    const v2f d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-                    best = fminf(best, fminf(d2.x, d2.y));
-                }
-                sgv = best < R2 ? 0xF : 0;
+            for (int a = 0; a < 16; a++) {                // two i-atoms per pass (packed fp32), LDS broadcast reads
+                const float4 xy = ipos[a]; const float2 zz = iposZ[a];
+                const v2f ddx = v2f{xy.x, xy.y} - px, ddy = v2f{xy.z, xy.w} - py, ddz = v2f{zz.x, zz.y} - pz;
+                const v2f d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                best = fminf(best, fminf(d2.x, d2.y));
             }
-            keep = keep && sgv != 0;
+            keep = keep && best < R2;
             __builtin_amdgcn_wave_barrier();             // every lane has read its entry before the slots below it are rewritten
             const unsigned long long m = __ballot(keep);
-            if (keep) { const int o = out + lanePrefix(m); list[o] = e; if constexpr (SUB) sig[o] = (unsigned char)sgv; }
+            if (keep) { const int o = out + lanePrefix(m); list[o] = e; }
             out += __popcll(m);
         }
         count = out; filtered = out;
@@ -601,7 +492,7 @@ template <typename Real, bool SUB> __global__ __launch_bounds__(256) void k_nbBu
                     int k = 0;     // last run whose exclusive prefix is <= v (empty runs are never queued)
 #pragma unroll
                     for (int st = 32; st > 0; st >>= 1) if (k + st < 64 && cmbPrefix[k + st] <= v) k += st;
-                    j = cmbStart[k] + (v - cmbPrefix[k]); if (p.orderBlocks) j = p.permOf[j]; code = cmbCode[k];      // sorted padded index -> the atom's slot after the octet ordering (same block)
+                    j = cmbStart[k] + (v - cmbPrefix[k]); code = cmbCode[k];
                     const int J = j >> 5;
                     ok = (J != I) && ownsPair(I, J);
                 }
@@ -624,12 +515,12 @@ template <typename Real, bool SUB> __global__ __launch_bounds__(256) void k_nbBu
                 if (count + nNew > NB_CAP - 32) {
                     // list full: close the current segment, publish this chunk and start a fresh list
                     const int padded = (count + 31) & ~31;
-                    for (int k = count + lane; k < padded; k += 64) { list[k] = -1; if constexpr (SUB) sig[k] = 0; }
+                    for (int k = count + lane; k < padded; k += 64) list[k] = -1;
                     for (int t = (segStart >> 5) + lane; t < (padded >> 5); t += 64) tileSub[t] = s;
                     flush(padded, hasDiag);
                     hasDiag = false; count = 0; segStart = 0; filtered = 0;
                 }
-                if (ok) { const int o = count + lanePrefix(m); list[o] = j | (code << SNB_JSHIFT_BITS); if constexpr (SUB) sig[o] = 0xF; }      // (the exact filter narrows the signature)
+                if (ok) { const int o = count + lanePrefix(m); list[o] = j | (code << SNB_JSHIFT_BITS); }
                 count += nNew;
             }
             __builtin_amdgcn_wave_barrier();
@@ -653,7 +544,7 @@ template <typename Real, bool SUB> __global__ __launch_bounds__(256) void k_nbBu
                         int blo = ((int)(fa * 1048575.0f) >> 14) - 1, bhi = ((int)(fb * 1048575.0f) >> 14) + 1;   // one bucket of slack for float rounding
                         blo = blo < 0 ? 0 : blo; bhi = bhi > 63 ? 63 : bhi;
                         const int* zi = zIndex + (size_t)col * 65;
-                        cStart = zi[blo]; cLen = zi[bhi + 1] - zi[blo];      // an interval of the SORTED padded order (see permOf below)
+                        cStart = zi[blo]; cLen = zi[bhi + 1] - zi[blo];      // an interval of the sorted padded order
                     }
                 }
                 const unsigned long long mq = __ballot(cLen > 0);
@@ -665,54 +556,9 @@ template <typename Real, bool SUB> __global__ __launch_bounds__(256) void k_nbBu
         }
         if (nCmb > 0 && !failed) runCandidates();
         if (exact && !failed) exactFilter();
-        // Order the segment's entries by signature (counting sort, 16 bins): entries that reach the same octets end up in the same
-        // 16-entry halves, so that whole (octet, half) sub-tiles come out empty -- 28 % of them on the bulk-water workload
-        // (tools/sim_fill2.py) -- and the pair kernel skips them.
-        if (SUB && exact && !failed && (p.orderBlocks & 2) && count - segStart > 16) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 16) hist[lane] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // STABLE (entries of one signature keep their order: they follow the sorted atom order, and the pair kernel's gathers of a
-            // tile stay within a few cache lines): pass 1 counts per signature, pass 2 ranks every entry inside its signature by ballots
-            int ent[NB_CAP / 64], sg[NB_CAP / 64];
-#pragma unroll
-            for (int r = 0; r < NB_CAP / 64; r++) {
-                const int k = segStart + lane + 64 * r;
-                ent[r] = 0; sg[r] = -1;
-                if (k < count) { ent[r] = list[k]; sg[r] = sig[k]; atomicAdd(&hist[sg[r]], 1); }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) { int acc = 0; for (int v = 0; v < 16; v++) { const int c = hist[v]; hist[v] = acc; acc += c; } }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            int running = lane < 16 ? hist[lane] : 0;      // lane v < 16 keeps the next free position of signature v
-#pragma unroll
-            for (int r = 0; r < NB_CAP / 64; r++) {
-                unsigned long long todo = __ballot(sg[r] >= 0);
-                int dest = -1;
-                while (todo) {
-                    const int v = __shfl(sg[r], __builtin_ctzll(todo), 64);      // a signature still to be placed in this round
-                    const unsigned long long m = __ballot(sg[r] == v);
-                    const int basePos = __shfl(running, v, 64);
-                    if (sg[r] == v) dest = basePos + lanePrefix(m);
-                    if (lane == v) running += __popcll(m);
-                    todo &= ~m;
-                }
-                sg[r] = dest >= 0 ? ((sg[r] << 16) | dest) : -1;
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < NB_CAP / 64; r++)
-                if (sg[r] >= 0) { const int o = segStart + (sg[r] & 0xFFFF); list[o] = ent[r]; sig[o] = (unsigned char)(sg[r] >> 16); }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
         // close the subset segment: pad to a whole tile, record the tiles' subset
         const int padded = (count + 31) & ~31;
-        for (int k = count + lane; k < padded; k += 64) { list[k] = -1; if constexpr (SUB) sig[k] = 0; }
+        for (int k = count + lane; k < padded; k += 64) list[k] = -1;
         for (int t = (segStart >> 5) + lane; t < (padded >> 5); t += 64) tileSub[t] = s;
         count = padded; filtered = padded;
     }
@@ -729,7 +575,7 @@ template <typename Real> __global__ void k_nbClear(const NbParams<Real> p) {
     if (i < 7 || (i >= 32 && i < (size_t)32 * (1 + NB_PARTS))) p.counters[i] = 0;
     if (i < nCols) p.colRange[i] = make_int2(0x7FFFFFFF, 0);      // atomicMin / atomicMax targets of k_nbScatter; k_nbZPrefix turns empty runs into (0, 0)
     if (i < nCols * 65) p.zIndex[i] = 0x7F7F7F7F;
-    if (i < (size_t)p.nPadded) { p.sortedToUser[i] = -1; p.permOf[i] = (int)i; }
+    if (i < (size_t)p.nPadded) p.sortedToUser[i] = -1;
 }
 
 // ---- 5. work items of the 64 partitions -> one contiguous array, full (8-tile) items first; totals into counters[0..7] ------------
@@ -801,15 +647,13 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipSt
         hipLaunchKernelGGL((k_nbClear<Real>), dim3((unsigned)((most + 255) / 256)), block, 0, s, p);
     }
     if (n > 0) {
-        if (p.orderBlocks) hipLaunchKernelGGL((k_nbBlockOrder<Real>), dim3((p.nBlocks + 7) / 8), block, 0, s, p);
         hipLaunchKernelGGL((k_nbScatter<Real>), gridN, block, 0, s, p);
         hipLaunchKernelGGL((k_nbPad<Real>), dim3((p.nPadded + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbZPrefix<Real>), dim3((p.nSubsets * p.ncx * p.ncy + 255) / 256), block, 0, s, p);
         hipLaunchKernelGGL((k_nbBounds<Real>), dim3((p.nBlocks + 7) / 8), block, 0, s, p);
         const int nOwned = (p.nBlocks / p.shardPeriod) * p.shardWidth + std::min(std::max(p.nBlocks % p.shardPeriod - p.shardBegin, 0), p.shardWidth);
         if (nOwned > 0) {
-            if (p.orderBlocks) hipLaunchKernelGGL((k_nbBuildTiles<Real, true>), dim3((nOwned + 3) / 4), block, 0, s, p);
-            else hipLaunchKernelGGL((k_nbBuildTiles<Real, false>), dim3((nOwned + 3) / 4), block, 0, s, p);
+            hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((nOwned + 3) / 4), block, 0, s, p);
         }
         hipLaunchKernelGGL((k_nbCompactWork<Real>), dim3(2 * NB_PARTS), block, 0, s, p);
     }

@@ -55,7 +55,6 @@ template <typename Real> struct DirectParams {
     const Real* lambdas;      // [S*2]
     const int* sliceNeed;     // [S] energy steps: non-zero = this slice's raw energies are wanted (derivative-only steps ask for a few slices)
     int numWork, workStart, workStride;   // sharding: items workStart, workStart+workStride, ...
-    int subTiles;             // the lists carry octet-ordered blocks and sub-tile occupancies (GPU builder): k_directSub applies
     int nsub;
     Real cutoff2, krf, crf, alpha, alphaD, k4pe;          // k4pe = ONE_4PI_EPS0
     Real alpha2l2e;                                        // alpha^2 * log2(e)
@@ -163,8 +162,6 @@ template <typename Real> struct NbParams {
     const int* uExclStart; const int* uExclList;
     const int* slotOfSubset;
     int* blockSubset;
-    int* permOf;                     // [nPadded] sorted padded index -> padded index after the octet ordering (identity for padding slots)
-    int* slotMap; int orderBlocks;   // [nAtoms] padded index of sorted rank t after the in-block octet ordering (k_nbBlockOrder; may alias padExtra, dead by then)
     int* segKey; int* segStart; int* padExtra; int* padBefore;   // block segmentation scratch (segStart and padBefore may alias)
     const int* blockWide; int* blockWideOut;                     // [nAtoms] flags of over-extended blocks of the first segmentation pass
     float maxHalfExtent[3];                                      // a block is over-extended when an atom is further than this from its first atom
