@@ -148,7 +148,7 @@ CONFIGS = {
     "c3l": (300000, 14.42, 4, 5, 120, 60, "single"),     # c3 with LJPME (dispersion mesh 60^3)
 }
 # 1-GPU rates of this build on MI355X (bench.py --config <name>, round 2, random-walk coordinates), quoted beside N > 1 results of the same workload
-ONE_GPU_NS_DAY = {"c4": 245.2, "c3": 374.1, "c2": 906.2}
+ONE_GPU_NS_DAY = {"c4": 256.6, "c3": 374.1, "c2": 900.3}
 ALPHA = 2.6283
 CUTOFF = 1.0
 
