@@ -394,8 +394,12 @@ def main():
             eng.set_shard_blocks(block_ranges[rank][0], block_ranges[rank][1], period)
     # Untimed pre-conditioning before the W warm-up steps: a fresh process starts with the GPU at idle clocks (kernel stamps of the first
     # ~100 ms read 15 % long: 0.239 ms for the pair kernel against 0.204 sustained) and with list buffers that still grow at the first few
-    # rebuilds; 240 steps (12 rebuilds, ~0.12 s) bring both to their steady state.  Then W warm-up steps, then exactly K timed steps.
-    precondition = max(0, 240 - args.warmup) if not os.environ.get("SNB_BENCH_NO_PRECONDITION") else 0
+    # rebuilds; 250 steps (13 rebuilds, ~0.12 s) bring both to their steady state.  Then W warm-up steps, then exactly K timed steps.
+    # (250 steps before the timed region, not 240: with a rebuild every 20 steps the region would otherwise START with a rebuild, issued into
+    # a GPU the synchronisation in front of the region has just drained -- a host-bound millisecond at idle clocks that a long run pays once
+    # and a 20-step region pays in full: measured 1.7 ms per region on c4, 0.2 ms on c3.  Now the region's rebuilds fall mid-region, with the
+    # queue full, as every rebuild of a long run does; their number per 20 steps is unchanged.)
+    precondition = max(0, 250 - args.warmup) if not os.environ.get("SNB_BENCH_NO_PRECONDITION") else 0
     for i in range(precondition):
         fenced_step(1 << 20 | i)
     for i in range(1, args.warmup + 1):
