@@ -247,7 +247,7 @@ template <typename Real> __device__ inline int runLowerBound(const NbParams<Real
     return lo;
 }
 
-template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(const NbParams<Real> p) {
+template <typename Real> __global__ __launch_bounds__(256, 4) void k_nbBuildTiles(const NbParams<Real> p) {
     __shared__ int s_list[4][NB_CAP];
     __shared__ unsigned s_mask[4][NB_MAXT][32];
     __shared__ int s_tileSub[4][NB_MAXT];
@@ -260,7 +260,10 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbBuildTiles(c
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // sharded engines build only the i-blocks they own, I % shardPeriod in [shardBegin, shardBegin + shardWidth) (a deterministic
     // rule, the same on every rank); the grid is sized for the owned blocks so that every wave of a work-group has work
-    const int kOwned = blockIdx.x * 4 + wid;
+    // (in DESCENDING order of the owned blocks: the sorted order ends with the small subsets, whose blocks see several j-subsets and take
+    // up to twice the median time -- started last they were the tail of the launch, SNB_NB_TRACE: span 451 us with the last start at 285)
+    const int kOwned = p.nOwned - 1 - (blockIdx.x * 4 + wid);
+    if (kOwned < 0) return;
     const int I = (kOwned / p.shardWidth) * p.shardPeriod + p.shardBegin + kOwned % p.shardWidth;
     if (I >= p.nBlocks) return;
     const long long tStart = p.dbgOut ? (long long)wall_clock64() : 0;
@@ -653,7 +656,8 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipSt
         hipLaunchKernelGGL((k_nbBounds<Real>), dim3((p.nBlocks + 7) / 8), block, 0, s, p);
         const int nOwned = (p.nBlocks / p.shardPeriod) * p.shardWidth + std::min(std::max(p.nBlocks % p.shardPeriod - p.shardBegin, 0), p.shardWidth);
         if (nOwned > 0) {
-            hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((nOwned + 3) / 4), block, 0, s, p);
+            NbParams<Real> pb = p; pb.nOwned = nOwned;
+            hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((nOwned + 3) / 4), block, 0, s, pb);
         }
         hipLaunchKernelGGL((k_nbCompactWork<Real>), dim3(2 * NB_PARTS), block, 0, s, p);
     }

@@ -163,6 +163,7 @@ template <typename Real> struct NbParams {
     const int* slotOfSubset;
     int* blockSubset;
     int* segKey; int* segStart; int* padExtra; int* padBefore;   // block segmentation scratch (segStart and padBefore may alias)
+    int nOwned;                                                  // i-blocks this engine builds (set by the launcher)
     const int* blockWide; int* blockWideOut;                     // [nAtoms] flags of over-extended blocks of the first segmentation pass
     float maxHalfExtent[3];                                      // a block is over-extended when an atom is further than this from its first atom
     // scratch
