@@ -641,7 +641,7 @@ __device__ __forceinline__ void batchedCopy(const int begin, const int end, cons
 // travel as the real and imaginary part of complex line c (z = a + i b, Z = A + i B with A, B Hermitian), so the z passes do half
 // the butterflies of a zero-imaginary transform.  forward: A_k = (Z_k + conj Z_{n-k})/2, B_k = (Z_k - conj Z_{n-k})/(2i);
 // inverse: Z_k = A_k + i B_k for k <= n/2 and conj(A_{n-k}) + i conj(B_{n-k}) above, then a = Re z, b = Im z.
-template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bounds__(256) void k_fftZ(const PmeParams<Real> p, int NL) {
+template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bounds__(512) void k_fftZ(const PmeParams<Real> p, int NL) {
     const int nz = p.d.nz, nzc = p.d.nzc;
     const int NC = NL >> 1;
     const int BS = NC + 1;   // padded batch stride (bank spread for the transposing LDS accesses)
@@ -652,21 +652,21 @@ template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bound
     const size_t line0 = (size_t)blockIdx.x * NL;
     const int nl = (int)((nlines - line0) < (size_t)NL ? (nlines - line0) : (size_t)NL);   // real lines here
     const int nb = (nl + 1) >> 1;                                                           // complex lines here
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NT = blockDim.x;
     const FastDiv dz(nz), dzc(nzc);
-    for (int k = tid; k < nz; k += 256) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
+    for (int k = tid; k < nz; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
     if (FORWARD) {
         const Real* in = p.gridReal + line0 * nz;
-        for (int it = tid; it < nb * nz; it += 256) {
+        for (int it = tid; it < nb * nz; it += NT) {
             const int c = dz.div(it), k = it - c * nz;
             const Real a = in[(2 * c) * nz + k];
             const Real b = (2 * c + 1 < nl) ? in[(2 * c + 1) * nz + k] : Real(0);
             A[k * BS + c] = {a, b};
         }
-        Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, 256);
+        Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, NT);
         __syncthreads();
         Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.gridCplx) + line0 * nzc;
-        for (int it = tid; it < nb * nzc; it += 256) {
+        for (int it = tid; it < nb * nzc; it += NT) {
             const int c = dzc.div(it), k = it - c * nzc;
             const Cx<Real> z = R[k * BS + c], m = R[(k == 0 ? 0 : nz - k) * BS + c];
             out[(2 * c) * nzc + k] = {Real(0.5) * (z.x + m.x), Real(0.5) * (z.y - m.y)};
@@ -675,7 +675,7 @@ template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bound
     } else {
         const Cx<Real>* in = reinterpret_cast<const Cx<Real>*>(p.gridCplx) + line0 * nzc;
         struct Two { Cx<Real> a, b; };
-        batchedCopy<4, Two>(tid, nb * nzc, 256,
+        batchedCopy<4, Two>(tid, nb * nzc, NT,
             [&](int it) {
                 const int c = dzc.div(it), k = it - c * nzc;
                 Two t; t.a = in[(2 * c) * nzc + k]; t.b = {Real(0), Real(0)};
@@ -688,10 +688,10 @@ template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bound
                 A[k * BS + c] = {a.x - b.y, a.y + b.x};                                         // A_k + i B_k
                 if (k > 0 && nz - k >= nzc) A[(nz - k) * BS + c] = {a.x + b.y, b.x - a.y};      // conj(A_k) + i conj(B_k)
             });
-        Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, +1, tw, nb, BS, tid, 256);
+        Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, +1, tw, nb, BS, tid, NT);
         __syncthreads();
         Real* out = p.gridReal + line0 * nz;
-        for (int it = tid; it < nb * nz; it += 256) {
+        for (int it = tid; it < nb * nz; it += NT) {
             const int c = dz.div(it), k = it - c * nz;
             const Cx<Real> z = R[k * BS + c];
             out[(2 * c) * nz + k] = z.x;
@@ -702,7 +702,7 @@ template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bound
 
 // ---- strided axis (y): tiles of NB adjacent lines (adjacent = consecutive complex elements in memory) ----
 // address(a, b, k) = a*strideA + b + k*strideK, b in [0, nbTotal)
-template <typename Real, int R1, int R2> __global__ __launch_bounds__(256) void k_fftStrided(const PmeParams<Real> p, int n, size_t strideA, int nbTotal, size_t strideK,
+template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void k_fftStrided(const PmeParams<Real> p, int n, size_t strideA, int nbTotal, size_t strideK,
                                                                           int NB, int tilesPerA, int sign, int axis) {
     const int a = blockIdx.x / tilesPerA, tile = blockIdx.x - a * tilesPerA;
     const int b0 = tile * NB;
@@ -711,15 +711,15 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(256) void 
     Cx<Real>* B = A + (size_t)n * NB;
     Cx<Real>* tw = B + (size_t)n * NB;
     Cx<Real>* g = reinterpret_cast<Cx<Real>*>(p.gridCplx) + (size_t)a * strideA + b0;
-    const int tid = threadIdx.x;
-    for (int k = tid; k < n; k += 256) tw[k] = reinterpret_cast<const Cx<Real>*>(axis == 1 ? p.twy : p.twx)[k];
+    const int tid = threadIdx.x, NT = blockDim.x;      // 256 or 512 threads over the same LDS tile (launcher)
+    for (int k = tid; k < n; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(axis == 1 ? p.twy : p.twx)[k];
     const FastDiv dnb(nb);
-    batchedCopy<8, Cx<Real>>(tid, n * nb, 256,
+    batchedCopy<8, Cx<Real>>(tid, n * nb, NT,
         [&](int it) { const int k = dnb.div(it), b = it - k * nb; return g[(size_t)k * strideK + b]; },
         [&](int it, const Cx<Real>& v) { const int k = dnb.div(it), b = it - k * nb; A[k * NB + b] = v; });
-    Cx<Real>* R = fftLines<Real, R1, R2>(A, B, n, axis == 1 ? p.d.fy : p.d.fx, axis == 1 ? p.d.nfy : p.d.nfx, sign, tw, nb, NB, tid, 256);
+    Cx<Real>* R = fftLines<Real, R1, R2>(A, B, n, axis == 1 ? p.d.fy : p.d.fx, axis == 1 ? p.d.nfy : p.d.nfx, sign, tw, nb, NB, tid, NT);
     __syncthreads();
-    for (int it = tid; it < n * nb; it += 256) {
+    for (int it = tid; it < n * nb; it += NT) {
         const int k = dnb.div(it), b = it - k * nb;
         g[(size_t)k * strideK + b] = R[k * NB + b];
     }
@@ -935,6 +935,10 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
 }
 
 // ---- launch dispatch over the instantiated (R1, R2) pairs ------------------------------------------
+// threads per work-group of the y FFT pass: 512 over the same LDS tile (two rounds of register sub-transforms become one and twice the
+// waves hide the tile's load latency: 24.4 -> 22.4 us per pass on c3; SNB_FFT_THREADS=256 restores the narrower groups).  The z pass
+// was measured the other way round (16.9 us with 256 threads, 20.9 with 512) and keeps 256.
+static int fftyThreads() { static const int n = getenv("SNB_FFT_THREADS") ? atoi(getenv("SNB_FFT_THREADS")) : 512; return n == 256 ? 256 : 512; }
 template <typename Real, bool FWD> static void launchFftZ(int r1, int r2, dim3 grid, size_t lds, hipStream_t s, const PmeParams<Real>& p, int NL) {
 #define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, FWD, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((k_fftZ<Real, FWD, A, B>), grid, dim3(256), lds, s, p, NL); return; }
     SNB_FFT_PAIRS(X)
@@ -944,11 +948,11 @@ template <typename Real, bool FWD> static void launchFftZ(int r1, int r2, dim3 g
 }
 template <typename Real> static void launchFftStrided(int r1, int r2, dim3 grid, size_t lds, hipStream_t s, const PmeParams<Real>& p, int n, size_t strideA, int nbTotal, size_t strideK, int NB,
                                                       int tilesPerA, int sign, int axis) {
-#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((k_fftStrided<Real, A, B>), grid, dim3(256), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis); return; }
+#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((k_fftStrided<Real, A, B>), grid, dim3(fftyThreads()), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis); return; }
     SNB_FFT_PAIRS(X)
 #undef X
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_fftStrided<Real, 0, 0>), grid, dim3(256), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis);
+    hipLaunchKernelGGL((k_fftStrided<Real, 0, 0>), grid, dim3(fftyThreads()), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis);
 }
 template <typename Real> static void launchConvolveX(int r1, int r2, dim3 grid, size_t lds, hipStream_t s, const PmeParams<Real>& p, int NB, int nCols) {
 #define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((k_convolveX<Real, A, B>), grid, dim3(512), lds, s, p, NB, nCols); return; }
