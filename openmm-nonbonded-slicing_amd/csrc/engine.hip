@@ -854,8 +854,13 @@ public:
             if (nGlobals > 0) HIPCHECK(hipMemcpyAsync(dGlobals.p, gValues.data(), sizeof(double) * nGlobals, hipMemcpyHostToDevice, stream));      // (gValues is a member: it outlives the copy)
             globalsDirty = false;
         }
-        if (particles) launchParticleParams<Real>(N, nsub, dBaseP.p, offP.empty() ? nullptr : dOffPStart.p, dOffPGlobal.p, dOffPDelta.p, dGlobals.p, dUSubset.p, dUCharge.p, dUSigEps.p,
-                                                  dParamSums.p, dFixScale.p, stream);
+        if (particles) {
+            // headroom of the spreader's 32-bit fixed point, per mesh: max(16, 8 x atoms per mesh cell) (misc.hip, k_fixScale)
+            static const double forced = getenv("SNB_FIX_HEADROOM") ? atof(getenv("SNB_FIX_HEADROOM")) : 0.0;      // test switch: a fixed headroom (16 = the rule before the mesh-dependent one)
+            auto headroom = [&](const PmePlanDims& d) { const double cells = (double)std::max(d.nx, 1) * std::max(d.ny, 1) * std::max(d.nz, 1); return forced > 0 ? forced : std::max(16.0, 8.0 * (double)N / cells); };
+            launchParticleParams<Real>(N, nsub, dBaseP.p, offP.empty() ? nullptr : dOffPStart.p, dOffPGlobal.p, dOffPDelta.p, dGlobals.p, dUSubset.p, dUCharge.p, dUSigEps.p,
+                                       dParamSums.p, dFixScale.p, headroom(pme.d), headroom(dpme.d), stream);
+        }
         if (exceptions) launchExceptionParams<Real>(n14, dBase14.p, offE.empty() ? nullptr : dOff14Start.p, dOff14Global.p, dOff14Delta.p, dGlobals.p, dSlice14.p, params14.p, stream);
     }
     // New parameter VALUES with the same subsets / exception pairs (copyParametersToContext, parameter offsets: the reference recomputes

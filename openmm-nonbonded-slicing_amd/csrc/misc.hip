@@ -183,8 +183,10 @@ __global__ void __launch_bounds__(1024) k_paramSums(int n, int nsub, const Real*
     for (int i = threadIdx.x; i < 3 * nsub; i += blockDim.x) row[i] = s_sums[i];
     if (threadIdx.x < 2) reinterpret_cast<int*>(row + 3 * nsub)[threadIdx.x] = s_max[threadIdx.x];
 }
-// fixed point: 16 x the largest per-atom value fits 31 bits (a grid point collects at most a few atoms' weights, each <= 1)
-template <typename Real> __global__ void k_fixScale(const double* __restrict__ partials, int rows, int nsub, double* __restrict__ sums, Real* __restrict__ fix) {
+// fixed point: headroom x the largest per-atom value fits 31 bits.  A mesh point collects sum_a q_a w_a <= max|q| sum_a w_a, and the weights of
+// all atoms at one point add up to the local number of atoms per mesh cell (partition of unity): the headroom is max(16, 8 x atoms per cell of
+// THAT mesh) -- 16 for the usual 0.1 nm Coulomb mesh (0.17 atoms per cell), more for a coarse mesh, whose points collect many atoms
+template <typename Real> __global__ void k_fixScale(const double* __restrict__ partials, int rows, int nsub, double* __restrict__ sums, Real* __restrict__ fix, double headQ, double headC) {
     const int w = 3 * nsub + 1, lane = threadIdx.x & 63;      // four waves share the columns; every wave finds the maxima, the first writes them
     for (int i = threadIdx.x >> 6; i < 3 * nsub; i += 4) {
         double a = 0;
@@ -202,14 +204,14 @@ template <typename Real> __global__ void k_fixScale(const double* __restrict__ p
     for (int o = 32; o > 0; o >>= 1) { mq = max(mq, __shfl_xor(mq, o, 64)); mc = max(mc, __shfl_xor(mc, o, 64)); }
     if (threadIdx.x < 2) {
         const double m = fmax((double)__int_as_float(threadIdx.x ? mc : mq), 1e-30);
-        const Real sc = (Real)(1073741824.0 / (16.0 * m));
+        const Real sc = (Real)(1073741824.0 / ((threadIdx.x ? headC : headQ) * m));
         fix[2 * threadIdx.x] = sc; fix[2 * threadIdx.x + 1] = (Real)(1.0 / (double)sc);
         reinterpret_cast<int*>(sums + 3 * nsub)[threadIdx.x] = threadIdx.x ? mc : mq;
     }
 }
 template <typename Real>
 void launchParticleParams(int n, int nsub, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals,
-                          const int* uSubset, Real* uCharge, typename Vec<Real>::T2* uSigEps, double* sums, Real* fix, hipStream_t s) {
+                          const int* uSubset, Real* uCharge, typename Vec<Real>::T2* uSigEps, double* sums, Real* fix, double headQ, double headC, hipStream_t s) {
     // sums: [3 nsub + 1] totals, then SNB_PARAM_SUM_ROWS rows of [3 nsub + 1] partials
     double* partials = sums + 3 * (size_t)nsub + 1;
     const int rows = std::min((n + 1023) / 1024, SNB_PARAM_SUM_ROWS);
@@ -217,15 +219,15 @@ void launchParticleParams(int n, int nsub, const double* base, const int* offSta
         hipLaunchKernelGGL((k_particleParams<Real>), dim3((n + 255) / 256), dim3(256), 0, s, n, base, offStart, offGlobal, offDelta, globals, uCharge, uSigEps);
         hipLaunchKernelGGL((k_paramSums<Real>), dim3(rows), dim3(1024), sizeof(double) * 3 * nsub, s, n, nsub, uCharge, uSigEps, uSubset, partials);
     }
-    hipLaunchKernelGGL((k_fixScale<Real>), dim3(1), dim3(256), 0, s, partials, rows, nsub, sums, fix);
+    hipLaunchKernelGGL((k_fixScale<Real>), dim3(1), dim3(256), 0, s, partials, rows, nsub, sums, fix, headQ, headC);
 }
 template <typename Real>
 void launchExceptionParams(int n, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals, const int* slice,
                            typename Vec<Real>::T4* out, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL((k_exceptionParams<Real>), dim3((n + 255) / 256), dim3(256), 0, s, n, base, offStart, offGlobal, offDelta, globals, slice, out);
 }
-template void launchParticleParams<float>(int, int, const double*, const int*, const int*, const double*, const double*, const int*, float*, Vec<float>::T2*, double*, float*, hipStream_t);
-template void launchParticleParams<double>(int, int, const double*, const int*, const int*, const double*, const double*, const int*, double*, Vec<double>::T2*, double*, double*, hipStream_t);
+template void launchParticleParams<float>(int, int, const double*, const int*, const int*, const double*, const double*, const int*, float*, Vec<float>::T2*, double*, float*, double, double, hipStream_t);
+template void launchParticleParams<double>(int, int, const double*, const int*, const int*, const double*, const double*, const int*, double*, Vec<double>::T2*, double*, double*, double, double, hipStream_t);
 template void launchExceptionParams<float>(int, const double*, const int*, const int*, const double*, const double*, const int*, Vec<float>::T4*, hipStream_t);
 template void launchExceptionParams<double>(int, const double*, const int*, const int*, const double*, const double*, const int*, Vec<double>::T4*, hipStream_t);
 

@@ -268,7 +268,7 @@ void launchFinishSliceEnergies(const double* parts, double* out, int n, const Sl
 #define SNB_PARAM_SUM_ROWS 256      // work-groups of k_paramSums, each leaving one row of partial sums
 template <typename Real>
 void launchParticleParams(int n, int nsub, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals,
-                          const int* uSubset, Real* uCharge, typename Vec<Real>::T2* uSigEps, double* sums, Real* fix, hipStream_t s);
+                          const int* uSubset, Real* uCharge, typename Vec<Real>::T2* uSigEps, double* sums, Real* fix, double headQ, double headC, hipStream_t s);
 template <typename Real>
 void launchExceptionParams(int n, const double* base, const int* offStart, const int* offGlobal, const double* offDelta, const double* globals, const int* slice,
                            typename Vec<Real>::T4* out, hipStream_t s);

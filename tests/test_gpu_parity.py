@@ -764,3 +764,19 @@ def test_mixed_precision_forces_are_reproducible_bit_for_bit(snb):
     for a, b in zip(*outs):
         assert np.abs(a).max() > 1.0
         assert np.array_equal(a, b), "max difference %g" % np.abs(a - b).max()
+
+
+def test_coarse_mesh_keeps_the_fixed_point_spreader_in_range(snb, F, oev):
+    """The single-precision spreader accumulates 32-bit fixed point with a headroom of max(16, 8 x atoms per mesh cell) times the largest
+    per-atom value (misc.hip, k_fixScale): a mesh point collects the weights of every atom within its stencil, and on a COARSE mesh they add
+    up to many atoms' worth.  36 atoms per cell, every charge +0.4, i.e. 14.4 units of charge per mesh point: a fixed headroom of 16 (31 bits at a
+    scale of 2^30 / (16 max|q|): 12.8 units) wraps around on most points -- SNB_FIX_HEADROOM=16 restores that rule and fails this test; the
+    energies and forces must match the oracle on the same mesh."""
+    n, L = 36000, 6.8
+    force, pos, box = systems.random_box(F, n, 2, 4, L, 1.0, pme=(2.6283, 10, 10, 10))
+    for i in range(n):
+        q, sg, ep = force.getParticleParameters(i)
+        force.setParticleParameters(i, 0.4, sg, ep)
+    for prec in ("single", "mixed"):
+        r, o = _compare(make_ev(snb, prec), oev, force, pos, box, TOLS[prec])
+        assert r["stats"].n_host_rebuilds == 0
