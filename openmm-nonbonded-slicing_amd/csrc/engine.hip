@@ -557,7 +557,8 @@ public:
             };
             const int px = pick(pme.d.nx, box[0]), py = pick(pme.d.ny, box[4]);
             const size_t brickBytes = sizeof(double) * (size_t)px * py * pme.d.nz;
-            if (px > 0 && py > 0 && brickBytes <= 60 * 1024) { colCells[0] = px; colCells[1] = py; ncx = pme.d.nx / px; ncy = pme.d.ny / py; }
+            if (px > 0 && py > 0 && brickBytes <= 60 * 1024 && std::max(pme.d.nx, std::max(pme.d.ny, pme.d.nz)) < 1024) {      // (the packed mesh cell of an atom holds 10 bits per axis)
+            colCells[0] = px; colCells[1] = py; ncx = pme.d.nx / px; ncy = pme.d.ny / py; }
         }
         std::vector<uint64_t> key(N);
         std::vector<int> colOfAtom(N);
@@ -953,7 +954,8 @@ public:
                 return best;
             };
             const int px = pick(pme.d.nx, box[0]), py = pick(pme.d.ny, box[4]);
-            if (px > 0 && py > 0 && sizeof(double) * (size_t)px * py * pme.d.nz <= 60 * 1024) { colCells[0] = px; colCells[1] = py; ncx = pme.d.nx / px; ncy = pme.d.ny / py; }
+            if (px > 0 && py > 0 && sizeof(double) * (size_t)px * py * pme.d.nz <= 60 * 1024 && std::max(pme.d.nx, std::max(pme.d.ny, pme.d.nz)) < 1024) {      // (the packed mesh cell of an atom holds 10 bits per axis)
+            colCells[0] = px; colCells[1] = py; ncx = pme.d.nx / px; ncy = pme.d.ny / py; }
         }
         // phase A: sort and block segmentation (the padded atom count depends on where the sorted order jumps)
         dUserToSorted.resize(N);
