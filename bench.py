@@ -151,6 +151,9 @@ CONFIGS = {
 ONE_GPU_NS_DAY = {"c4": 256.6, "c3": 374.1, "c2": 900.3}
 ALPHA = 2.6283
 CUTOFF = 1.0
+# configs whose BASELINE.json line names energy-parameter derivatives ("300k-atom solvated protein, 4 subsets with lambda_elec/lambda_vdW derivatives"):
+# their headline step is the derivative-carrying one
+DERIVATIVE_CONFIGS = ("c3", "c3t", "c3l")
 
 
 def workload_box(w):
@@ -307,12 +310,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-balance", action="store_true", help="N > 1: keep the even i-block split instead of balancing direct-space work against the ranks' reciprocal work")
     ap.add_argument("--check", action="store_true", help="also compare forces/energies with the CPU oracle (slow at full size)")
+    ap.add_argument("--no-double", action="store_true", help="skip the double-precision leg (the `double_precision` object of the JSON line)")
     args = ap.parse_args()
 
-    import torch
+    # --gpus N > 1 without a launcher: start the N ranks ourselves (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1)
+    # BEFORE anything in this process touches the GPU, relay rank 0's JSON line and exit with the launcher's code.  Never fall through to a
+    # one-GPU run that would print n_gpus: 1, never re-exec a process that has initialised HIP.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE does not match --gpus")
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d does not match --gpus %d (launch with --nproc-per-node %d, or drop the launcher and let bench.py start the ranks)" % (world, args.gpus, args.gpus))
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -408,25 +426,48 @@ def main():
     if world > 1:
         dist.barrier()
     eng.set_timing_interval(int(os.environ.get("SNB_BENCH_TIMING_INTERVAL", max(1, min(32, args.steps // 5)))))      # >= 5 timed (eager) steps with kernel stamps even in a short region
-    eng.reset_timers()
-    rebuilds_before = int(eng.stats().n_rebuilds)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        fenced_step(args.warmup + 1 + i)
-    eng.sync(); torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    st = eng.stats()
-    ms_per_step = elapsed * 1e3 / args.steps
+    # derivatives are requested for the scaling parameters of the workload: the slices whose lambda differs from 1
+    deriv_slices = (np.abs(w["lam"] - 1.0).max(axis=1) > 0).astype(np.int32)
+    eng.set_energy_slices(deriv_slices)
+
+    def timed_region(first, derivatives):
+        """EXACTLY K steps bracketed by barrier + synchronize on both sides; MAX over ranks.  Returns (ms per step, engine stats of the region)."""
+        eng.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        eng.reset_timers()
+        before = int(eng.stats().n_rebuilds)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            fenced_step(first + i, derivatives=derivatives)
+        eng.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        stx = eng.stats()
+        return elapsed * 1e3 / args.steps, stx, int(stx.n_rebuilds) - before
+
+    # Two regions of K steps each, same walk, same rebuild cadence:
+    #  * forces only -- snb_execute(include_energy = 0);
+    #  * the step BASELINE.json config 3 names, "with lambda_elec / lambda_vdW derivatives": a force that requests energy-parameter derivatives
+    #    accumulates the raw per-slice energies on EVERY step (the reference does, CommonNonbondedSlicingKernels.cpp:712-718); the sums stay on
+    #    the device (read once at the end, outside the region).
+    # `value` is the region the config names (c3 family: derivatives; the others: forces only); the other one is reported beside it.
+    plain_ms, st, rebuilds_plain = timed_region(args.warmup + 1, False)
+    for i in range(4):
+        fenced_step(args.warmup + args.steps + 1 + i, derivatives=True)
+    deriv_ms, st_d, rebuilds_deriv = timed_region(args.warmup + args.steps + 5, True)
+    headline_deriv = cfg_name in DERIVATIVE_CONFIGS
+    ms_per_step = deriv_ms if headline_deriv else plain_ms
+    st_head = st_d if headline_deriv else st
+    rebuilds_in_region = rebuilds_deriv if headline_deriv else rebuilds_plain
     resident_ms = None
-    deriv_ms = None
     allreduce_ms = None
     if world > 1:
         # the exchange alone: K all-reduces of the force array back to back (its share of ms_per_step, for the record)
@@ -436,29 +477,6 @@ def main():
             dist.all_reduce(forces)
         torch.cuda.synchronize()
         allreduce_ms = (time.perf_counter() - ta) * 1e3 / args.steps
-    # The step BASELINE.json config 3 names -- "with lambda_elec / lambda_vdW derivatives": a force that requests energy-parameter
-    # derivatives accumulates the raw per-slice energies on EVERY step (the reference does, CommonNonbondedSlicingKernels.cpp:712-718).
-    # Same walk, same rebuild cadence, K steps; the sums stay on the device (read once at the end, outside the region).
-    # derivatives are requested for the scaling parameters of the workload: the slices whose lambda differs from 1
-    deriv_slices = (np.abs(w["lam"] - 1.0).max(axis=1) > 0).astype(np.int32)
-    eng.set_energy_slices(deriv_slices)
-    for i in range(4):
-        fenced_step(args.warmup + args.steps + 1 + i, derivatives=True)
-    eng.sync(); torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    td = time.perf_counter()
-    for i in range(args.steps):
-        fenced_step(args.warmup + args.steps + 5 + i, derivatives=True)
-    eng.sync(); torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    deriv_elapsed = time.perf_counter() - td
-    if world > 1:
-        tt = torch.tensor([deriv_elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        deriv_elapsed = float(tt.item())
-    deriv_ms = deriv_elapsed * 1e3 / args.steps
     overruns = int(eng.stats().n_list_overruns)
     if world == 1:
         # For the record (never `value`): the same evaluations fed from two coordinate sets generated beforehand, i.e. nothing but
@@ -475,14 +493,59 @@ def main():
         eng.sync(); torch.cuda.synchronize()
         resident_ms = (time.perf_counter() - tr) * 1e3 / n_res
     ns_day = 86.4 * 2.0 / ms_per_step
-    T = int(st.n_tiles)
-    direct_ms = st.sum_direct_ms / max(st.n_timed, 1)
-    recip_ms = st.sum_recip_ms / max(st.n_timed, 1)
-    gpu_ms = st.sum_total_ms / max(st.n_timed, 1)
+    T = int(st_head.n_tiles)
     itemsize = 8 if is_double else 4
-    # N*(posq+sigeps+subset) + N*24 force write + T*32*(posq+sigeps+subset+index) + T*32*24 j-force scatter
-    bytes_direct = N * ((4 + 2) * itemsize + 4) + N * 24 + T * 32 * ((4 + 2) * itemsize + 4 + 4) + T * 32 * 24
-    achieved = bytes_direct / (direct_ms * 1e-3) / 1e9 if direct_ms > 0 else 0.0
+    G = grid ** 3; Gh = grid * grid * (grid // 2 + 1)
+
+    def pair_roofline(stx, derivatives):
+        """N*(posq+sigeps+subset) + N*24 force write + T*32*(posq+sigeps+subset+index) + T*32*24 j-force scatter, over the
+        average launch duration of the pair kernel on the region's eager steps (begin/end stamps of hipExtLaunchKernelGGL)."""
+        Tx = int(stx.n_tiles)
+        d_ms = stx.sum_direct_ms / max(stx.n_timed, 1)
+        nbytes = N * ((4 + 2) * itemsize + 4) + N * 24 + Tx * 32 * ((4 + 2) * itemsize + 4 + 4) + Tx * 32 * 24
+        ach = nbytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
+        if is_double:
+            kern = "snb::k_direct<double, %d, false, %s>" % (2 if method == 4 else 3, "true" if derivatives else "false")
+        else:
+            kern = "snb::k_directPacked<%d, true, %s, false, %s>" % (2 if method == 4 else 3, "true" if derivatives else "false", "true" if precision == "mixed" else "false")
+        return {"bound": "hbm", "kernel": kern, "step": "with derivatives (energies on the tiles of the bound slices)" if derivatives else "forces only",
+                "timing": "kernel begin/end stamps of hipExtLaunchKernelGGL on the eager steps of the timed region (snb_set_timing_interval: at least 5 of them)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes": int(nbytes), "tiles": Tx, "avg_launch_ms": round(d_ms, 4), "timed_launches": int(stx.n_timed)}
+
+    def pme_rooflines(stx, nheld):
+        """The reciprocal pipeline kernel by kernel, from the engine's own per-kernel stamps (snb_stats.sum_kernel_ms): algorithmic bytes of
+        DESIGN.md section 4 / SURVEY 8(d) over the mean launch duration, against the same HBM peak."""
+        rows = []
+        def add(slot, name, nbytes):
+            cnt = int(stx.n_kernel_timed[slot])
+            if cnt <= 0:
+                return
+            ms = stx.sum_kernel_ms[slot] / cnt
+            rows.append({"kernel": name, "algorithmic_bytes": int(nbytes), "avg_launch_us": round(ms * 1e3, 2),
+                         "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None, "timed_launches": cnt})
+        r = itemsize
+        add(0, "k_gatherPositions (+ force clear + mesh cells)", N * (3 * r + 4 + 4 * r + 3 * r + 3 * r + 4))
+        meshes = [(0, grid, "")] + ([(8, dgrid, " [dispersion mesh]")] if method == 5 else [])
+        for off, g, tag in meshes:
+            Gm = g ** 3; Ghm = g * g * (g // 2 + 1)
+            fused = int(stx.n_kernel_timed[off + 2]) == 0
+            add(off + 1, "k_spreadBrick" + (" (+ forward z FFT)" if fused else "") + tag, N * (4 * r + 4) + (nheld * Ghm * 2 * r if fused else nheld * Gm * r))
+            add(off + 2, "k_fftZ forward" + tag, nheld * (Gm * r + Ghm * 2 * r))
+            add(off + 3, "k_fftStrided (y, forward)" + tag, nheld * Ghm * 4 * r)
+            add(off + 4, "k_convolveX (x FFT + slice energies + lambda mix + inverse x FFT)" + tag, nheld * Ghm * 4 * r)
+            add(off + 5, "k_fftStrided (y, inverse)" + tag, nheld * Ghm * 4 * r)
+            add(off + 6, "k_fftZ inverse" + tag, nheld * (Gm * r + Ghm * 2 * r))
+            add(off + 7, "k_interpolateBricks (+ user-order force write)" + tag, N * (4 * r + 3 * r + 4 + 3 * r + 3 * r) + nheld * Gm * r)
+        return rows
+
+    nheld = len([s_ for s_ in range(nsub) if s_ % world == rank]) if world > 1 else nsub
+    roof_plain = pair_roofline(st, False)
+    roof_deriv = pair_roofline(st_d, True)
+    roof = roof_deriv if headline_deriv else roof_plain
+    direct_ms = st_head.sum_direct_ms / max(st_head.n_timed, 1)
+    recip_ms = st_head.sum_recip_ms / max(st_head.n_timed, 1)
+    gpu_ms = st_head.sum_total_ms / max(st_head.n_timed, 1)
 
     # one energy evaluation for the record (per-slice energies)
     eng.rebuild()
@@ -495,30 +558,35 @@ def main():
         "metric": "ns/day (force evaluation only, dt = 2 fs)", "value": round(ns_day, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64" if is_double else "f32", "data": "synthetic",
+        "value_step": "with lambda derivatives (snb_execute include_energy = 2 every step)" if headline_deriv else "forces only",
+        "value_forces_only": round(86.4 * 2.0 / plain_ms, 3), "ms_per_step_forces_only": round(plain_ms, 4),
         "value_with_derivatives": round(86.4 * 2.0 / deriv_ms, 3), "ms_per_step_with_derivatives": round(deriv_ms, 4),
         "config": {"workload": ("%s: %d-atom " + ("triclinic cell a=(L,0,0) b=(L/3,L,0) c=(-L/4,L/4,L)" if "box" in w else "cubic box") + " L=%.3f nm, %d subsets, %s %d^3%s, cutoff 1.0 nm, alpha 2.6283/nm, %d exclusions, list skin %.2f nm")
                    % (cfg_name, N, Lbox, nsub, "PME" if method == 4 else "LJPME", st.grid[0], (" + dispersion %d^3" % st.dgrid[0]) if method == 5 else "",
                       len(w["exc_qq"]), args.padding),
-                   "tiles_32x32": T, "blocks": int(st.n_blocks), "rebuild_interval": args.rebuild_interval, "rebuilds_in_timed_region": int(st.n_rebuilds) - rebuilds_before, "host_rebuilds": int(st.n_host_rebuilds), "neighbor_rebuild_ms": round(st.last_rebuild_ms, 2),
+                   "tiles_32x32": T, "blocks": int(st.n_blocks), "rebuild_interval": args.rebuild_interval, "rebuilds_in_timed_region": rebuilds_in_region, "host_rebuilds": int(st.n_host_rebuilds), "neighbor_rebuild_ms": round(st.last_rebuild_ms, 2),
                    "ms_per_step_resident_coordinates": round(resident_ms, 4) if resident_ms is not None else None,
                    "derivative_slices": [int(i) for i in np.nonzero(deriv_slices)[0]], "list_overruns": overruns, "preconditioning_steps": precondition, "allreduce_ms": round(allreduce_ms, 4) if allreduce_ms is not None else None,
                    "first_call_ms": round(first_ms, 1), "energy_step_ms": round(energy_ms, 3), "energy_step_gpu_ms": round(eng.stats().last_total_ms, 3),
                    "gpu_ms_per_step": round(gpu_ms, 4), "direct_kernel_ms": round(direct_ms, 4), "reciprocal_ms": round(recip_ms, 4),
                    "parallelism": ("subset-grid + i-block sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},
-        "roofline": {"bound": "hbm", "kernel": ("snb::k_directPacked<%d, true, false, false, %s>" % (2 if method == 4 else 3, "true" if precision == "mixed" else "false")) if not is_double else "snb::k_direct<double, ...>",
-                     "timing": "kernel begin/end stamps of hipExtLaunchKernelGGL on the eager steps of the timed region (snb_set_timing_interval: at least 5 of them)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(bytes_direct), "avg_launch_ms": round(direct_ms, 4)},
+        "roofline": roof,
+        "roofline_other_step": roof_plain if headline_deriv else roof_deriv,
+        "roofline_pme": pme_rooflines(st_head, nheld),
     }
-    # HBM-side traffic of the same kernel: PMC passes cannot run inside this process, so the figure comes from the committed
-    # summary of `tools/pmc_hbm.sh` (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes over this command)
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_%s_pmc_hbm.json" % cfg_name)
-    if os.path.exists(pmc_file) and world == 1:
-        try:
-            rec = json.load(open(pmc_file))["k_direct_forces"]
-            out["roofline"]["traffic"] = int(rec["traffic_bytes_per_launch"])
-            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_file) + ": " + rec["formula"]
-        except Exception as exc:   # a malformed summary must not hide the measurement
-            out["roofline"]["traffic_source"] = "unreadable %s (%s)" % (pmc_file, exc)
+    # HBM-side traffic of the pair kernel: PMC passes cannot run inside this process (rocprofv3 --pmc wraps the whole command, in separate
+    # FETCH_SIZE / WRITE_SIZE passes: tools/pmc_hbm.sh).  `traffic` therefore stays null here; the figure of the committed profile of this
+    # command is quoted under its own key, with the tile count it was taken at.
+    for tag in ("r03", "r02"):
+        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "%s_%s_pmc_hbm.json" % (tag, cfg_name))
+        if os.path.exists(pmc_file) and world == 1:
+            try:
+                rec = json.load(open(pmc_file))["k_direct_forces"]
+                out["roofline"]["traffic_from_profile"] = {"bytes_per_launch": int(rec["traffic_bytes_per_launch"]), "source": "profiles/" + os.path.basename(pmc_file) + ": " + rec["formula"],
+                                                           "tiles_in_that_run": rec.get("tiles"), "measured_in_this_run": False}
+            except Exception as exc:   # a malformed summary must not hide the measurement
+                out["roofline"]["traffic_from_profile"] = {"error": "unreadable %s (%s)" % (pmc_file, exc)}
+            break
     if block_ranges is not None:
         out["config"]["i_block_ranges_of_128"] = [list(r) for r in block_ranges]
     if world > 1 and cfg_name in ONE_GPU_NS_DAY:
@@ -527,11 +595,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: the same workload generator at 24k atoms (same density, cutoff, alpha, grid spacing), a few evaluations
         ws = build_workload(24000, 6.2145, min(nsub, 4), np.random.default_rng(SEED))
+        ws["pos"] = np.ascontiguousarray(ws["pos"].astype(np.float32).astype(np.float64))      # float-representable coordinates: the oracle and engines of either precision see identical inputs
         import oracle as _o
         cores = int(_o.lib().orc_num_threads())
         reps = 10; tsum = 0.0; pairs = 0
+        fo_s = so_s = None
         for _ in range(reps):
-            _, _, dt, pairs = oracle_eval(ws, 4 if method == 4 else 5, 54, 27 if method == 5 else 0)
+            fo_s, so_s, dt, pairs = oracle_eval(ws, 4 if method == 4 else 5, 54, 27 if method == 5 else 0)
             tsum += dt
         cpu_ms = tsum / reps * 1e3
         cpu_full_ms = cpu_ms * N / len(ws["q"])
@@ -540,6 +610,55 @@ def main():
                                          "%d evaluations of a %d-atom/%d-subset box of the same generator (density, cutoff, alpha, 54^3 grid): %.0f ms per evaluation, %d pairs; "
                                          "value = the per-atom cost scaled to the full workload: %.0f ms per evaluation" % (reps, len(ws["q"]), ws["nsub"], cpu_ms, pairs, cpu_full_ms),
                                "ms_per_step_sample": round(cpu_ms, 1), "ms_per_step_scaled": round(cpu_ms * N / len(ws["q"]), 1)}
+    if rank == 0 and world == 1 and not args.no_double and not is_double:
+        # north_star couples the roofline target with "per-slice energies to 1e-5", which only double precision delivers: the same workload in
+        # SNB_DOUBLE beside the headline (its own K-step regions, same walk and cadence), the pair kernel against the double-precision byte
+        # model (76 N + 2560 T), and the worst slice-energy / force error of both precisions against the oracle on the 24k-atom sample.
+        eng.close()
+        K2 = max(10, min(args.steps, 60))
+        engd = Engine(pkg, w, method, grid, dgrid, "double", local, 0, 1, args.padding, args.rebuild_interval, stream=torch.cuda.current_stream().cuda_stream)
+        posd = pos0.double().clone(); forcesd = torch.zeros((N, 3), dtype=torch.float64, device=dev)
+        walkd = [x.double() for x in walk[:4]]
+        engd.set_force_output(forcesd.data_ptr(), True)
+        engd.set_energy_slices(deriv_slices)
+
+        def dstep(i, derivatives):
+            posd.add_(walkd[i % 4], alpha=float(walk_sign[i % len(walk_sign)]))
+            engd.set_positions_device(posd.data_ptr(), True)
+            engd.execute(2, fetch=False) if derivatives else engd.execute(False)
+            engd.forces_to(forcesd.data_ptr(), True)
+        res = {}
+        engd.set_timing_interval(max(1, K2 // 5))
+        for name, derivatives in (("forces_only", False), ("with_derivatives", True)):
+            for i in range(25):
+                dstep(i, derivatives)
+            engd.sync(); torch.cuda.synchronize(); engd.reset_timers()
+            td0 = time.perf_counter()
+            for i in range(K2):
+                dstep(25 + i, derivatives)
+            engd.sync(); torch.cuda.synchronize()
+            ms = (time.perf_counter() - td0) * 1e3 / K2
+            sd = engd.stats()
+            d_ms = sd.sum_direct_ms / max(sd.n_timed, 1); Td = int(sd.n_tiles)
+            nb = N * (6 * 8 + 4) + N * 24 + Td * 32 * (6 * 8 + 4 + 4) + Td * 32 * 24
+            res[name] = {"ms_per_step": round(ms, 4), "ns_day": round(86.4 * 2.0 / ms, 2), "direct_kernel_ms": round(d_ms, 4), "reciprocal_ms": round(sd.sum_recip_ms / max(sd.n_timed, 1), 4),
+                         "pair_kernel_algorithmic_bytes": int(nb), "pair_kernel_frac_of_hbm_peak": round(nb / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if d_ms > 0 else None, "tiles": Td}
+        engd.close()
+        out["double_precision"] = {"workload": cfg_name + " in SNB_DOUBLE (same atoms, mesh, walk and rebuild cadence)", "steps": K2, **res,
+                                   "byte_model": "76*N + 2560*T (SURVEY 8d with 32-byte positions and 8-byte reals)"}
+        if not args.no_cpu_baseline and fo_s is not None:
+            par = {}
+            for pr in ("double", "single"):
+                e24 = Engine(pkg, ws, 4 if method == 4 else 5, 54, 27 if method == 5 else 0, pr, local, 0, 1, 0.1, 1 << 30, stream=torch.cuda.current_stream().cuda_stream)
+                dtp = torch.float64 if pr == "double" else torch.float32
+                p24 = torch.tensor(ws["pos"], dtype=dtp, device=dev); f24 = torch.zeros((len(ws["q"]), 3), dtype=dtp, device=dev)
+                e24.set_positions_device(p24.data_ptr(), pr == "double"); e24.execute(True); e24.forces_to(f24.data_ptr(), pr == "double"); e24.sync()
+                se = e24.slice_energies(so_s.shape[0]); f = f24.double().cpu().numpy()
+                par[pr] = {"max_slice_energy_rel_err": float(np.max(np.abs(se - so_s) / np.maximum(np.abs(so_s), 1.0))),
+                           "max_force_rel_err": float(np.max(np.linalg.norm(f - fo_s, axis=1) / np.maximum(np.linalg.norm(fo_s, axis=1), 1.0)))}
+                e24.close()
+            out["double_precision"]["parity_vs_oracle_24k_atoms"] = par
+        eng = None
     if args.check and rank == 0 and world == 1:
         # parity at full size, as tests/test_gpu_fullsize.py does it: the oracle on the coordinates the engine was given (float-rounded in
         # single precision), the pairs within float rounding of the cutoff accounted for one by one (tests/parity_tools.py)
@@ -548,6 +667,8 @@ def main():
         fo, so, _, _ = oracle_eval(wc, method, grid, dgrid)
         fa, ea, nband = pt.band_allowance(wc, method, grid, dgrid, pt.band_rel(wc, precision))
         tol = 1e-5 if is_double else 1e-3
+        if eng is None:
+            eng = Engine(pkg, w, method, grid, dgrid, precision, local, rank, world, args.padding, args.rebuild_interval, stream=torch.cuda.current_stream().cuda_stream)
         eng.rebuild()
         eng.set_positions_device(pos0.data_ptr(), is_double); eng.execute(True); eng.forces_to(forces.data_ptr(), is_double); eng.sync()
         rec_e = pt.compare(forces.double().cpu().numpy(), eng.slice_energies(so.shape[0]), fo, so, tol, fa, ea)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SNB_ABI_VERSION 5
+#define SNB_ABI_VERSION 6
 
 typedef struct snb_engine* snb_handle;
 
@@ -103,7 +103,22 @@ typedef struct {
     int64_t n_host_rebuilds;    /* rebuilds that fell back to the host builder (triclinic / non-periodic / tiny boxes) */
     int64_t n_list_overruns;    /* list lifetimes in which an atom moved more than neighbor_padding / 2 (pairs may have been missed:
                                  * shorten rebuild_interval, widen the padding, or use the automatic mode)                */
+    /* (ABI 6) per-kernel begin/end stamps of the timed (eager) steps, cumulative since snb_reset_timers.  Slots (SNB_K_*): 0 position
+     * gather, 1 charge spreading (+ fused forward z FFT), 2 forward z FFT when separate, 3 forward y FFT, 4 x FFT + slice energies +
+     * lambda mix + inverse x FFT, 5 inverse y FFT, 6 inverse z FFT, 7 force interpolation (+ user-order force write); 8..15 the same
+     * for the LJPME dispersion mesh (8 unused). */
+    double  sum_kernel_ms[16];
+    int64_t n_kernel_timed[16];
 } snb_stats;
+#define SNB_K_GATHER 0
+#define SNB_K_SPREAD 1
+#define SNB_K_FFT_Z_FWD 2
+#define SNB_K_FFT_Y_FWD 3
+#define SNB_K_CONVOLVE_X 4
+#define SNB_K_FFT_Y_INV 5
+#define SNB_K_FFT_Z_INV 6
+#define SNB_K_INTERPOLATE 7
+#define SNB_K_DISPERSION_MESH 8
 
 /* -- lifetime ---------------------------------------------------------------------------------- */
 snb_status snb_create(const snb_config* cfg, snb_handle* out);

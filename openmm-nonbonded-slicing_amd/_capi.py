@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNB_LIB_PATH") or os.path.join(_HERE, "libsnb_hip.so")      # (SNB_LIB_PATH: an experimental build of the same ABI, tools/ only)
-SNB_ABI_VERSION = 5
+SNB_ABI_VERSION = 6
 
 # every symbol include/snb.h declares (tests check the library exports each one)
 SYMBOLS = [
@@ -43,7 +43,9 @@ class SnbStats(ctypes.Structure):
         ("dgrid", ctypes.c_int32 * 3), ("last_direct_ms", ctypes.c_double), ("last_recip_ms", ctypes.c_double),
         ("last_total_ms", ctypes.c_double), ("last_rebuild_ms", ctypes.c_double), ("sum_direct_ms", ctypes.c_double),
         ("sum_recip_ms", ctypes.c_double), ("sum_total_ms", ctypes.c_double), ("n_timed", ctypes.c_int64), ("n_host_rebuilds", ctypes.c_int64), ("n_list_overruns", ctypes.c_int64),
+        ("sum_kernel_ms", ctypes.c_double * 16), ("n_kernel_timed", ctypes.c_int64 * 16),
     ]
+KERNEL_SLOTS = ("gather", "spread", "fft_z_forward", "fft_y_forward", "convolve_x", "fft_y_inverse", "fft_z_inverse", "interpolate")
 
 
 def build(force: bool = False) -> str:

@@ -46,6 +46,28 @@ template <typename T> struct DevBuf {
     }
 };
 
+// Small asynchronous host-to-device updates (lambdas, energy-slice mask, dispersion coefficients, global parameter values) go through a ring
+// of pinned slots, one per in-flight update, each guarded by an event: the setter's own vector may be overwritten by the next call while an
+// earlier copy is still queued, and a copy from pageable memory is either staged synchronously by the runtime or reads the source late
+// (ADVICE r02).  A slot is reused only after its copy has completed; with 8 slots that wait never happens in practice.
+struct PinnedRing {
+    static constexpr int SLOTS = 8;
+    struct Slot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    Slot slots[SLOTS]; int next = 0;
+    ~PinnedRing() { for (auto& s : slots) { if (s.ev) (void)hipEventDestroy(s.ev); if (s.p) (void)hipHostFree(s.p); } }
+    void copy(void* dst, const void* src, size_t bytes, hipStream_t st) {
+        if (bytes == 0) return;
+        Slot& s = slots[next]; next = (next + 1) % SLOTS;
+        if (s.pending) { HIPCHECK(hipEventSynchronize(s.ev)); s.pending = false; }
+        if (s.cap < bytes) { if (s.p) (void)hipHostFree(s.p); s.p = nullptr; s.cap = std::max<size_t>(bytes, 4096); HIPCHECK(hipHostMalloc(&s.p, s.cap, hipHostMallocDefault)); }
+        if (!s.ev) HIPCHECK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+        std::memcpy(s.p, src, bytes);
+        HIPCHECK(hipMemcpyAsync(dst, s.p, bytes, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipEventRecord(s.ev, st)); s.pending = true;
+    }
+    template <typename T> void upload(DevBuf<T>& d, const std::vector<T>& h, hipStream_t st) { d.resize(h.size()); copy(d.p, h.data(), sizeof(T) * h.size(), st); }
+};
+
 struct EngineBase {
     snb_config cfg;
     std::string err;
@@ -192,12 +214,12 @@ public:
     // measured on c3: serial 0.80 ms/step, forked 0.87 (default priority) / 1.32 (high or low priority): the graph's cross-stream
     // dependencies cost more than the overlap returns, so the fork is opt-in
     bool concurrentPme = getenv("SNB_CONCURRENT_PME") && atoi(getenv("SNB_CONCURRENT_PME"));
-    struct EvSet { hipEvent_t e[5]; bool pending = false; };   // start, direct0, direct1(=recip0 after pair lists), recip1, end
+    struct EvSet { hipEvent_t e[5]; bool pending = false; KernelStamps ks; };   // start, direct0, direct1(=recip0 after pair lists), recip1, end; per-kernel stamps (snb_stats.sum_kernel_ms)
     std::vector<EvSet> ring; int ringPos = 0;
     // host-side definition
     std::vector<double> charge, sigma, epsilon; std::vector<int32_t> subset;
     std::vector<int32_t> excPairs; std::vector<double> excQQ, excSigma, excEps; std::vector<int32_t> excForce14;
-    std::vector<double> lambdas, dispCoef; std::vector<Real> hLambdas;
+    std::vector<double> lambdas, dispCoef; std::vector<Real> hLambdas; PinnedRing pinned;
     double box[9] = {0}; bool haveBox = false, haveParticles = false;
     // positions
     const void* devUserPos = nullptr; int posIsDouble = 1, posStride4 = 0; bool havePositions = false;
@@ -286,7 +308,7 @@ public:
         HIPCHECK(hipSetDevice(c.device));
         if (c.stream) stream = (hipStream_t)c.stream; else { HIPCHECK(hipStreamCreate(&stream)); ownStream = true; }
         ring.resize(RING);
-        for (auto& r : ring) for (int k = 0; k < 5; k++) HIPCHECK(hipEventCreate(&r.e[k]));
+        for (auto& r : ring) { for (int k = 0; k < 5; k++) HIPCHECK(hipEventCreate(&r.e[k])); for (int k = 0; k < 16; k++) { HIPCHECK(hipEventCreate(&r.ks.start[k])); HIPCHECK(hipEventCreate(&r.ks.stop[k])); } }
         charge.assign(N, 0.0); sigma.assign(N, 1.0); epsilon.assign(N, 0.0); subset.assign(N, 0);
         lambdas.assign((size_t)S * 2, 1.0); dispCoef.assign(S, 0.0); hostSliceE.assign((size_t)S * 2, 0.0);
         sliceE.resize((size_t)S * 2 * SNB_SLICE_E_PARTS); sliceTotal.resize((size_t)S * 2);
@@ -326,7 +348,7 @@ public:
         if (dPmeTrace.p) { long long h[4] = {0, 0, 0, 0}; (void)hipMemcpy(h, dPmeTrace.p, 32, hipMemcpyDeviceToHost); if (h[2] > 0) fprintf(stderr, "[snb] interpolation bricks: mean load %.2f us, mean compute %.2f us per work-group (%lld work-groups)\n", h[0] / 100.0 / h[2], h[1] / 100.0 / h[2], h[2]); }
         dropGraph();
         if (sortGraphExec) { (void)hipGraphExecDestroy(sortGraphExec); sortGraphExec = nullptr; }
-        for (auto& r : ring) for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]);
+        for (auto& r : ring) { for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]); for (int k = 0; k < 16; k++) { (void)hipEventDestroy(r.ks.start[k]); (void)hipEventDestroy(r.ks.stop[k]); } }
         for (int k = 0; k < 3; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
         for (int k = 0; k < 2; k++) if (evStepDone[k]) (void)hipEventDestroy(evStepDone[k]);
         if (hDispFlags) (void)hipHostFree(hDispFlags);
@@ -408,6 +430,7 @@ public:
     void setExceptions(int32_t m, const int32_t* pairs, const double* qq, const double* sg, const double* ep, const int32_t* f14) override {
         for (int k = 0; k < m; k++)
             if (pairs[2 * k] < 0 || pairs[2 * k] >= N || pairs[2 * k + 1] < 0 || pairs[2 * k + 1] >= N || pairs[2 * k] == pairs[2 * k + 1]) throw HipError{"exception particle index out of range"};
+        for (auto& o : offE) if (o.target >= m) throw HipError{"snb_set_exceptions: a parameter offset refers to an exception past the new count (clear or re-send the offsets first)"};
         std::vector<int32_t> np(pairs, pairs + 2 * (size_t)m);
         const bool pairsChanged = !haveExceptions || np != excPairs;      // the exclusion masks live in the tiles
         excPairs.swap(np); excQQ.assign(qq, qq + m); excSigma.assign(sg, sg + m); excEps.assign(ep, ep + m);
@@ -451,16 +474,16 @@ public:
     }
     void setLambdas(const double* l) override {
         lambdas.assign(l, l + (size_t)S * 2);
-        hLambdas.assign(lambdas.begin(), lambdas.end());      // (a member: the staging array outlives the asynchronous copy; no synchronisation per lambda change)
-        dLambdas.upload(hLambdas, stream);
+        hLambdas.assign(lambdas.begin(), lambdas.end());
+        pinned.upload(dLambdas, hLambdas, stream);      // (pinned slot per in-flight update: no synchronisation per lambda change, and the next call may overwrite hLambdas)
     }
     void setEnergySlices(const int32_t* m) override {
         for (int i = 0; i < S; i++) sliceNeedSel[i] = m[i] != 0;
-        dSliceNeedSel.upload(sliceNeedSel, stream);      // (a member: outlives the copy; same buffer, so captured graphs stay valid)
+        pinned.upload(dSliceNeedSel, sliceNeedSel, stream);      // (same device buffer, so captured graphs stay valid)
     }
     void setDispersion(const double* c) override {
         if (c) dispCoef.assign(c, c + S); else dispCoef.assign(S, 0.0);
-        dDispCoef.upload(dispCoef, stream);      // (a member: outlives the copy); read by the last kernel of an energy step
+        pinned.upload(dDispCoef, dispCoef, stream);      // read by the last kernel of an energy step
         dropGraph();
     }
     void setBox(const double* b) override {
@@ -807,6 +830,9 @@ public:
     // Structure only (pairs, slices, base values, offsets in CSR per 1-4 entry); the values are formed on the device (syncParameters).
     void upload14() {
         const size_t m = excPairs.size() / 2;
+        // captured step graphs bake in the 1-4 count, the list pointers and the grid of the list blocks: same pairs with a different set of
+        // non-zero / flagged exceptions changes all three, so the graphs go whenever any of them moved
+        const int oldN14 = n14; const void* const oldPairs = pairs14.p; const void* const oldParams = params14.p;
         std::vector<char> hasOffset(m, 0);
         for (auto& o : offE) hasOffset[o.target] = 1;
         std::vector<int2> p14; std::vector<double> b14; std::vector<int> sl14, where(m, -1);
@@ -831,6 +857,7 @@ public:
         stats.n_14 = n14; stats.n_exclusions = nExcl;
         HIPCHECK(hipStreamSynchronize(stream));      // (host staging vectors go out of scope)
         baseEDirty = false;
+        if (n14 != oldN14 || pairs14.p != oldPairs || params14.p != oldParams) dropGraph();
     }
     void uploadParticleBase() {
         std::vector<double> hb(3 * (size_t)N);
@@ -852,7 +879,7 @@ public:
         if (baseEDirty) { upload14(); exceptions = true; }
         if (globalsDirty) {
             dGlobals.resize(std::max(nGlobals, 1));
-            if (nGlobals > 0) HIPCHECK(hipMemcpyAsync(dGlobals.p, gValues.data(), sizeof(double) * nGlobals, hipMemcpyHostToDevice, stream));      // (gValues is a member: it outlives the copy)
+            if (nGlobals > 0) pinned.copy(dGlobals.p, gValues.data(), sizeof(double) * nGlobals, stream);
             globalsDirty = false;
         }
         if (particles) {
@@ -1131,6 +1158,7 @@ public:
 
     void execute(int includeForces, int includeEnergy, int includeDirect, int includeRecip, double* energyOut) override {
         (void)includeForces;
+        if (includeEnergy == 2 && energyOut) { err = "snb_execute: include_energy == 2 (derivative-only step) delivers no total energy; pass energy = NULL"; throw (int)SNB_ERR_INVALID_ARGUMENT; }
         if (!haveParticles) throw HipError{"snb_execute: particles were not set"};
         if (!havePositions) throw HipError{"snb_execute: positions were not set"};
         if (isPeriodic()) {
@@ -1225,6 +1253,9 @@ public:
     }
 
     void enqueueStep(bool energy, bool includeDirect, bool includeRecip, EvSet* ev) {
+        struct StampScope { StampScope(KernelStamps* k) { g_stamps = k; } ~StampScope() { g_stamps = nullptr; } };
+        if (ev) for (int k = 0; k < 16; k++) ev->ks.used[k] = false;
+        StampScope stampScope(ev ? &ev->ks : nullptr);
         if (ev) HIPCHECK(hipEventRecord(ev->e[0], stream));
         // one pass: sorted positions, cleared force arrays, and (PME on the brick path) the packed Coulomb-mesh cell of every atom
         GatherCells<Real> gc;
@@ -1383,10 +1414,15 @@ public:
         HIPCHECK(hipEventElapsedTime(&c, ev.e[0], ev.e[4]));
         stats.last_direct_ms = a; stats.last_recip_ms = b; stats.last_total_ms = c;
         stats.sum_direct_ms += a; stats.sum_recip_ms += b; stats.sum_total_ms += c; stats.n_timed++;
+        for (int k = 0; k < 16; k++) if (ev.ks.used[k]) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev.ks.start[k], ev.ks.stop[k]) == hipSuccess) { stats.sum_kernel_ms[k] += t; stats.n_kernel_timed[k]++; }
+            ev.ks.used[k] = false;
+        }
         ev.pending = false;
     }
     // (also restarts the eager-step cadence: the first step after a reset is a timed one, so even a short measured region has a sample)
-    void resetTimers() override { for (auto& r : ring) if (r.pending) harvest(r); stats.sum_direct_ms = stats.sum_recip_ms = stats.sum_total_ms = 0; stats.n_timed = 0; execCount = 0; }
+    void resetTimers() override { for (auto& r : ring) if (r.pending) harvest(r); stats.sum_direct_ms = stats.sum_recip_ms = stats.sum_total_ms = 0; stats.n_timed = 0; for (int k = 0; k < 16; k++) { stats.sum_kernel_ms[k] = 0; stats.n_kernel_timed[k] = 0; } execCount = 0; }
 
     bool runPme(PmeParams<Real>& pp, hipStream_t st) {      // true: its interpolation kernel delivered the user-order forces (pp.outForces)
         const bool zDone = launchPmeSpread<Real>(pp, st);

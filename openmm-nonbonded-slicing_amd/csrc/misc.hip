@@ -48,8 +48,8 @@ void launchGatherPositions(const void* userPos, int isDouble, int stride4, const
     if (nPadded <= 0) return;
     dim3 grid((nPadded + 255) / 256), block(256);
     const int stride = stride4 ? 4 : 3;
-    if (isDouble) hipLaunchKernelGGL((k_gatherPositions<Real, double>), grid, block, 0, s, (const double*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, nClear, gc);
-    else hipLaunchKernelGGL((k_gatherPositions<Real, float>), grid, block, 0, s, (const float*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, nClear, gc);
+    if (isDouble) SNB_STAMPED_LAUNCH(0, (k_gatherPositions<Real, double>), grid, block, 0, s, (const double*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, nClear, gc);
+    else SNB_STAMPED_LAUNCH(0, (k_gatherPositions<Real, float>), grid, block, 0, s, (const float*)userPos, stride, sortedToUser, imageOffset, posq, nPadded, forces, nClear, gc);
 }
 
 // In-place refresh of the sorted per-atom parameters from the user-order values (parameter offsets / updateParametersInContext)

@@ -23,6 +23,9 @@
 
 namespace snb {
 
+thread_local KernelStamps* g_stamps = nullptr;
+template <typename Real> static inline int stampSlot(const PmeParams<Real>& p, int k) { return k + (p.dispersion ? 8 : 0); }
+
 // x / d for 0 <= x < 2^22 without the ~35-instruction integer division: (x + 0.5) * (1/d) never lands within rounding error of an integer
 struct FastDiv {
     float inv; int d;
@@ -395,7 +398,7 @@ template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStrea
         const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * p.zSlabs;
         if (!p.cellsReady) hipLaunchKernelGGL((k_pmeCells<Real>), dim3((p.natoms + 255) / 256), dim3(256), 0, s, p);
 #define SNB_SPREAD(FX, FZ) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real, FX, FZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                             hipLaunchKernelGGL((k_spreadBrick<Real, FX, FZ>), dim3(nblocks), dim3(512), lds, s, p); }
+                             SNB_STAMPED_LAUNCH(stampSlot(p, 1), (k_spreadBrick<Real, FX, FZ>), dim3(nblocks), dim3(512), lds, s, p); }
         if constexpr (std::is_same<Real, float>::value) {
             if (fixed) { if (fuse) SNB_SPREAD(true, true) else SNB_SPREAD(true, false) return fuse; }
         }
@@ -406,7 +409,7 @@ template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStrea
     // fallback (triclinic boxes, meshes without a usable column divisor): global float atomics
     hipMemsetAsync(p.gridReal, 0, sizeof(Real) * (size_t)p.nsub * p.d.nx * p.d.ny * p.d.nz, s);
     if (p.natoms <= 0) return false;
-    hipLaunchKernelGGL((k_spread<Real>), dim3((p.natoms + 7) / 8), dim3(256), 0, s, p);
+    SNB_STAMPED_LAUNCH(stampSlot(p, 1), (k_spread<Real>), dim3((p.natoms + 7) / 8), dim3(256), 0, s, p);
     return false;
 }
 
@@ -940,26 +943,26 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
 // was measured the other way round (16.9 us with 256 threads, 20.9 with 512) and keeps 256.
 static int fftyThreads() { static const int n = getenv("SNB_FFT_THREADS") ? atoi(getenv("SNB_FFT_THREADS")) : 512; return n == 256 ? 256 : 512; }
 template <typename Real, bool FWD> static void launchFftZ(int r1, int r2, dim3 grid, size_t lds, hipStream_t s, const PmeParams<Real>& p, int NL) {
-#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, FWD, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((k_fftZ<Real, FWD, A, B>), grid, dim3(256), lds, s, p, NL); return; }
+#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, FWD, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); SNB_STAMPED_LAUNCH(stampSlot(p, FWD ? 2 : 6), (k_fftZ<Real, FWD, A, B>), grid, dim3(256), lds, s, p, NL); return; }
     SNB_FFT_PAIRS(X)
 #undef X
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZ<Real, FWD, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_fftZ<Real, FWD, 0, 0>), grid, dim3(256), lds, s, p, NL);
+    SNB_STAMPED_LAUNCH(stampSlot(p, FWD ? 2 : 6), (k_fftZ<Real, FWD, 0, 0>), grid, dim3(256), lds, s, p, NL);
 }
 template <typename Real> static void launchFftStrided(int r1, int r2, dim3 grid, size_t lds, hipStream_t s, const PmeParams<Real>& p, int n, size_t strideA, int nbTotal, size_t strideK, int NB,
                                                       int tilesPerA, int sign, int axis) {
-#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((k_fftStrided<Real, A, B>), grid, dim3(fftyThreads()), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis); return; }
+#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); SNB_STAMPED_LAUNCH(axis == 1 ? stampSlot(p, sign < 0 ? 3 : 5) : -1, (k_fftStrided<Real, A, B>), grid, dim3(fftyThreads()), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis); return; }
     SNB_FFT_PAIRS(X)
 #undef X
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftStrided<Real, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_fftStrided<Real, 0, 0>), grid, dim3(fftyThreads()), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis);
+    SNB_STAMPED_LAUNCH(axis == 1 ? stampSlot(p, sign < 0 ? 3 : 5) : -1, (k_fftStrided<Real, 0, 0>), grid, dim3(fftyThreads()), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis);
 }
 template <typename Real> static void launchConvolveX(int r1, int r2, dim3 grid, size_t lds, hipStream_t s, const PmeParams<Real>& p, int NB, int nCols) {
-#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((k_convolveX<Real, A, B>), grid, dim3(512), lds, s, p, NB, nCols); return; }
+#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_convolveX<Real, A, B>), grid, dim3(512), lds, s, p, NB, nCols); return; }
     SNB_FFT_PAIRS(X)
 #undef X
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_convolveX<Real, 0, 0>), grid, dim3(512), lds, s, p, NB, nCols);
+    SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_convolveX<Real, 0, 0>), grid, dim3(512), lds, s, p, NB, nCols);
 }
 
 static size_t ldsBudget() { return 96 * 1024; }
@@ -1312,8 +1315,10 @@ template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBr
                     const Real gx = p.fpx[a] + ql * (fx * nx * p.recip[0]);
                     const Real gy = p.fpy[a] + ql * (fx * nx * p.recip[3] + fy * ny * p.recip[4]);
                     const Real gz = p.fpz[a] + ql * (fx * nx * p.recip[6] + fy * ny * p.recip[7] + fz * nzr * p.recip[8]);
+                    // (the reciprocal force is stored even when this kernel also delivers the step's user-order force: snb_get_forces into
+                    // ANOTHER buffer rebuilds the force from the direct accumulators + fpx..)
+                    p.fpx[a] = gx; p.fpy[a] = gy; p.fpz[a] = gz;
                     if (p.outForces) deliver(gx, gy, gz);
-                    else { p.fpx[a] = gx; p.fpy[a] = gy; p.fpz[a] = gz; }
                     if (wantE) __hip_atomic_fetch_add(&sE[2 * slice + term], 0.5 * (double)q * (double)psi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -1344,12 +1349,12 @@ template <typename Real> static bool launchInterpolateBricks(const PmeParams<Rea
             const int nblocks = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * zSlabs;
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBricks<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (!p.mix) p.outForces = nullptr;      // (sharded engines visit an atom once per held grid: the separate finish pass stays)
-            hipLaunchKernelGGL((k_interpolateBricks<Real>), dim3(nblocks), dim3(1024), lds, s, p, zSlabs);
+            SNB_STAMPED_LAUNCH(stampSlot(p, 7), (k_interpolateBricks<Real>), dim3(nblocks), dim3(1024), lds, s, p, zSlabs);
             return p.outForces != nullptr;
         }
     }
     const size_t lds = (!p.mix && p.wantEnergy) ? sizeof(double) * p.nsubTotal * (p.nsubTotal + 1) : 0;
-    hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
+    SNB_STAMPED_LAUNCH(stampSlot(p, 7), (k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
     return false;
 }
 
@@ -1372,7 +1377,7 @@ template <typename Real> bool launchPmeInterpolate(const PmeParams<Real>& p, hip
         return launchInterpolateBricks<Real>(q, s);
     }
     const size_t lds = (!p.mix && p.wantEnergy) ? sizeof(double) * p.nsubTotal * (p.nsubTotal + 1) : 0;
-    hipLaunchKernelGGL((k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
+    SNB_STAMPED_LAUNCH(stampSlot(p, 7), (k_interpolate<Real>), dim3((p.natoms + 7) / 8), dim3(256), lds, s, p);
     return false;
 }
 

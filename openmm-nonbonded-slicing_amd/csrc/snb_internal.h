@@ -13,6 +13,7 @@
 //     masks    : uint32[M][32] bit j of word i set = pair (i,j) excluded
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -97,6 +98,16 @@ struct PmePlanDims {
     int fx[16], fy[16], fz[16];
     int rx1, rx2, ry1, ry2, rz1, rz2;   // two-pass register-FFT split n = r1*r2 per axis (0 = use the staged Stockham path)
 };
+
+// Per-kernel begin/end stamps of a timed (eager) step: the engine points g_stamps at a set of event pairs before it enqueues the step;
+// the launchers below it stamp their kernel with hipExtLaunchKernelGGL (the duration rocprofv3 reports, no marker-packet overhead) when
+// a slot is offered.  Host-side only; null on graph-captured steps.
+struct KernelStamps { hipEvent_t start[16] = {}, stop[16] = {}; bool used[16] = {}; };
+extern thread_local KernelStamps* g_stamps;
+#define SNB_STAMPED_LAUNCH(SLOT, KERNEL, GRID, BLOCK, LDS, STREAM, ...) do { \
+        snb::KernelStamps* ks_ = snb::g_stamps; const int slot_ = (SLOT); \
+        if (ks_ && slot_ >= 0 && slot_ < 16 && ks_->start[slot_] && !ks_->used[slot_]) { ks_->used[slot_] = true; hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ks_->start[slot_], ks_->stop[slot_], 0, __VA_ARGS__); } \
+        else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__); } while (0)
 
 template <typename Real> struct PmeParams {
     PmePlanDims d;

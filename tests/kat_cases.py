@@ -702,3 +702,53 @@ def testScalingParameterSeparation(ev, F, method, exceptions, pme=None, ljpme=No
         assertEqualTo(d1["lambda"], d2["lambdaCoulomb"] + d2["lambdaLJ"], tol)
         assertEqualTo(r1["energy"], lam * d1["lambda"] + value * (d1["alpha"] + d1["beta"]), tol)
         assertEqualTo(d1["alpha"] + d1["beta"], d2["gamma"], tol)
+
+
+# --- independent absolute pin of the Ewald / PME half (not in the reference's suite) -----------------------------
+# Rock salt: simple-cubic sites of spacing r0 with alternating charges +-1.  Published constants:
+#   E / ion pair            = -M k / r0,            M = 1.7475645946331822  (Madelung constant of NaCl)
+#   like-charge sub-lattice = fcc one-component plasma in its neutralising background: E / ion = -0.8958736152 k / r_s
+#                             (r_s = Wigner-Seitz radius of the fcc lattice; Fuchs 1935, e.g. Baus & Hansen, Phys. Rep. 59 (1980) table 1)
+# With cations and anions as two subsets the diagonal slices carry the fcc sums (which exercises the per-slice background term, Q3) and
+# the cross slice the rest.  The paths pinned: ReferencePME.cpp:400-496, 598-702 and ReferenceSlicedLJCoulombIxn.cpp:203-222, 256-358.
+MADELUNG_NACL = 1.7475645946331822
+MADELUNG_FCC_OCP = 0.8958736152
+
+
+def rockSalt(F, nsub, method, cells=4, r0=0.25, cutoff=0.9, alpha=4.8, grid=96, shift=(0.013, 0.007, 0.021)):
+    m = 2 * cells
+    L = m * r0
+    idx = np.stack(np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij"), -1).reshape(-1, 3)
+    sign = np.where(idx.sum(1) % 2 == 0, 1.0, -1.0)
+    pos = idx * r0 + np.asarray(shift)
+    ff = F(nsub)
+    ff.setNonbondedMethod(method); ff.setCutoffDistance(cutoff); ff.setUseDispersionCorrection(False)
+    ff.setPMEParameters(alpha, grid, grid, grid)
+    if method == 5:
+        ff.setLJPMEParameters(alpha, grid // 2, grid // 2, grid // 2)
+    for i, s in enumerate(sign):
+        ff.addParticle(float(s), 0.2, 0.0)
+        if nsub == 2:
+            ff.setParticleSubset(i, 0 if s > 0 else 1)
+    return ff, pos, cubic(L), len(sign)
+
+
+def testMadelung(ev, F, method, nsub, tol=1e-5, force_tol=None, cells=4, grid=96, **kw):
+    ff, pos, box, n = rockSalt(F, nsub, method, cells=cells, grid=grid)
+    r0 = 0.25
+    r = ev(ff, pos, box, **kw)
+    total = -(n / 2) * MADELUNG_NACL * ONE_4PI_EPS0 / r0
+    assertEqualTo(total, r["energy"], tol)
+    # every ion sits on an inversion centre: the forces vanish (scale: the nearest-neighbour pair force k / r0^2)
+    fscale = ONE_4PI_EPS0 / r0 ** 2
+    assert np.abs(r["forces"]).max() <= (force_tol if force_tol is not None else tol) * fscale, np.abs(r["forces"]).max() / fscale
+    se = np.asarray(r["slice_energies"])
+    if nsub == 1:
+        assertEqualTo(total, se[0, 0], tol)
+    else:
+        rs = (3.0 / (4.0 * math.pi) * (2 * r0) ** 3 / 4.0) ** (1.0 / 3.0)
+        like = -(n / 2) * MADELUNG_FCC_OCP * ONE_4PI_EPS0 / rs
+        assertEqualTo(like, se[0, 0], tol)              # cation-cation
+        assertEqualTo(like, se[2, 0], tol)              # anion-anion
+        assertEqualTo(total - 2 * like, se[1, 0], tol)  # cross slice
+    assert np.abs(se[:, 1]).max() <= tol * abs(total)   # no Lennard-Jones / dispersion energy (eps = 0)

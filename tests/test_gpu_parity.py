@@ -69,6 +69,20 @@ def test_reference_kat(case, snb, F, prec):
     getattr(K, case)(make_ev(snb, prec), F, **kw)
 
 
+@pytest.mark.parametrize("method", [3, 4, 5])
+@pytest.mark.parametrize("nsub", [1, 2])
+def test_madelung_constants(method, nsub, snb, F, prec):
+    """The engine against two published lattice constants (no oracle involved): rock salt's Madelung constant for the total energy and
+    the cross slice, the fcc one-component-plasma constant (neutralising background) for the like-charge slices; forces vanish by
+    symmetry.  512 ions exercise the small-box paths (host tile lists, per-pair wrap, atomic spreader), 13 824 ions the GPU builder and
+    the brick kernels.  Classic Ewald, PME and LJPME (eps = 0)."""
+    tol = 1e-5 if prec == "double" else 1e-3
+    ev = make_ev(snb, prec, kmax=(24, 24, 24)) if method == 3 else make_ev(snb, prec)
+    K.testMadelung(ev, F, method, nsub, tol=tol)
+    if method != 3:
+        K.testMadelung(ev, F, method, nsub, tol=tol, cells=12, grid=160)
+
+
 def test_switching_function(snb, F, prec):
     tol = K.TOL                                       # TestSlicedNonbondedForce.h:800 (TOL) and :811 (finite difference, 1e-3), all platforms
     K.testSwitchingFunction(make_ev(snb, prec), F, 1, tol=tol, fd_tol=1e-3)
@@ -780,3 +794,112 @@ def test_coarse_mesh_keeps_the_fixed_point_spreader_in_range(snb, F, oev):
     for prec in ("single", "mixed"):
         r, o = _compare(make_ev(snb, prec), oev, force, pos, box, TOLS[prec])
         assert r["stats"].n_host_rebuilds == 0
+
+
+def test_exception_becoming_nonzero_between_replayed_steps(snb):
+    """snb_set_exceptions with the SAME pairs but a different set of non-zero exceptions changes the 1-4 list's length and
+    buffers without a neighbour rebuild; captured step graphs baked the old count and pointers in.  Flip a third of the zero exceptions
+    to non-zero (and some 1-4s to zero) between graph-replayed steps and compare with the oracle for the new definition."""
+    import ctypes
+    import torch
+    import bench
+    w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+    n = len(w["q"])
+    eng = bench.Engine(snb, w, 4, 54, 0, "double", 0, 0, 1, 0.1, 1 << 30)
+    pos = torch.tensor(w["pos"], dtype=torch.float64, device="cuda"); forces = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+    eng.set_positions_device(pos.data_ptr(), True)
+    for _ in range(4):                     # rebuild step, capture, replays
+        eng.execute(False)
+    eng.sync()
+    n14_before = eng.stats().n_14
+    rebuilds = eng.stats().n_rebuilds
+    w2 = dict(w)
+    qq = w["exc_qq"].copy(); ee = w["exc_eps"].copy()
+    zero = np.flatnonzero((qq == 0.0) & (ee == 0.0)); nonzero = np.flatnonzero((qq != 0.0) | (ee != 0.0))
+    assert len(zero) > 10 and len(nonzero) > 10
+    for k in zero[::3]:
+        a, b = w["exc_pairs"][2 * k], w["exc_pairs"][2 * k + 1]
+        qq[k] = 0.5 * w["q"][a] * w["q"][b]      # (Coulomb only: these are bonded neighbours at 0.1 nm)
+    qq[nonzero[::4]] = 0.0; ee[nonzero[::4]] = 0.0
+    w2["exc_qq"] = qq; w2["exc_eps"] = ee
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)); ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    eng.ok(eng.L.snb_set_exceptions(eng.h, len(qq), ip(w["exc_pairs"]), dp(qq), dp(w["exc_sigma"]), dp(ee), None))
+    fo, so, _, _ = bench.oracle_eval(w2, 4, 54, 0)
+    for step in range(3):                  # replayed (re-captured) steps with the new 1-4 list
+        eng.execute(False); eng.forces_to(forces.data_ptr(), True); eng.sync()
+        f = forces.cpu().numpy()
+        ferr = np.max(np.linalg.norm(f - fo, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0))
+        assert ferr < 1e-5, (step, ferr)
+    st = eng.stats()
+    assert st.n_14 != n14_before and st.n_rebuilds == rebuilds, "same pairs: the 1-4 membership changes without a neighbour rebuild"
+    eng.execute(True); eng.sync()
+    se = eng.slice_energies(so.shape[0])
+    assert np.max(np.abs(se - so) / np.maximum(np.abs(so), 1.0)) < 1e-5
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["single", "mixed", "double"])
+@pytest.mark.parametrize("method,dgrid", [(4, 0), (5, 27)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_fused_force_output_and_get_forces_elsewhere(precision, method, dgrid, accumulate, snb):
+    """The interpolation kernel of the step's last mesh delivers the user-order force into the buffer named by snb_set_force_output
+    (the path bench.py times).  All precisions (the SNB_MIXED branch reads 64-bit fixed-point accumulators), PME and LJPME (two meshes,
+    atoms with eps == 0 take the q == 0 hand-over on the dispersion mesh), accumulate on and off; and snb_get_forces into ANOTHER
+    buffer after such a step must still return the complete force (the fused path used to leave fpx.. without the last
+    mesh's part)."""
+    import torch
+    import bench
+    w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+    n = len(w["q"])
+    isd = precision == "double"
+    dt = torch.float64 if isd else torch.float32
+    pos = torch.tensor(w["pos"], dtype=dt, device="cuda")
+    ref = bench.Engine(snb, w, method, 54, dgrid, precision, 0, 0, 1, 0.1, 1 << 30)
+    eng = bench.Engine(snb, w, method, 54, dgrid, precision, 0, 0, 1, 0.1, 1 << 30)
+    fr = torch.zeros((n, 3), dtype=dt, device="cuda")
+    out = torch.full((n, 3), 1.5 if accumulate else float("nan"), dtype=dt, device="cuda")
+    other = torch.zeros((n, 3), dtype=dt, device="cuda")
+    eng.set_force_output(out.data_ptr(), isd, accumulate)
+    tol = 1e-9 if isd else 2e-4            # same kernels; in float only the atomic summation order differs
+    for step in range(3):                  # rebuild step (eager), captured step, replayed step
+        ref.set_positions_device(pos.data_ptr(), isd); ref.execute(False); ref.forces_to(fr.data_ptr(), isd); ref.sync()
+        if accumulate:
+            out.fill_(1.5)
+        eng.set_positions_device(pos.data_ptr(), isd); eng.execute(False); eng.sync()
+        a = fr.double().cpu().numpy(); b = out.double().cpu().numpy() - (1.5 if accumulate else 0.0)
+        assert np.isfinite(b).all()
+        err = np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(a, axis=1), 1.0)
+        assert err.max() < max(tol, 2e-6 if accumulate else 0), (step, err.max())
+        eng.forces_to(other.data_ptr(), isd); eng.sync()          # a different target: rebuilt from the accumulators + fpx..
+        c = other.double().cpu().numpy()
+        err = np.linalg.norm(a - c, axis=1) / np.maximum(np.linalg.norm(a, axis=1), 1.0)
+        assert err.max() < tol, ("get_forces elsewhere", step, err.max())
+        host = np.zeros((n, 3), dtype=np.float64 if isd else np.float32)
+        eng.ok(eng.L.snb_get_forces(eng.h, host.ctypes.data_as(__import__("ctypes").c_void_p), 0, int(isd), 0))
+        err = np.linalg.norm(a - host.astype(float), axis=1) / np.maximum(np.linalg.norm(a, axis=1), 1.0)
+        assert err.max() < tol, ("get_forces to the host", step, err.max())
+    assert eng.stats().n_host_rebuilds == 0
+    ref.close(); eng.close()
+
+
+def test_derivative_only_step_rejects_an_energy_pointer(snb):
+    """include/snb.h: include_energy == 2 produces the selected raw slice energies only; asking it for the total energy is an error
+    (it used to return a lambda-weighted sum over unspecified slices)."""
+    import ctypes
+    import torch
+    import bench
+    w = bench.build_workload(6000, 3.915, 2, np.random.default_rng(bench.SEED))
+    eng = bench.Engine(snb, w, 4, 36, 0, "single", 0, 0, 1, 0.1, 1 << 30)
+    pos = torch.tensor(w["pos"], dtype=torch.float32, device="cuda")
+    eng.set_positions_device(pos.data_ptr(), False)
+    e = ctypes.c_double(0.0)
+    assert eng.L.snb_execute(eng.h, 1, 2, 1, 1, ctypes.byref(e)) == eng.capi.SNB_ERR_INVALID_ARGUMENT
+    assert eng.L.snb_execute(eng.h, 1, 2, 1, 1, None) == 0
+    # and a parameter offset must not outlive the exception it points at
+    m = len(w["exc_qq"])
+    ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)); dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    tgt = np.array([m - 1], dtype=np.int32); glob = np.array([0], dtype=np.int32); delta = np.array([0.1, 0.0, 0.0])
+    eng.ok(eng.L.snb_set_parameter_offsets(eng.h, 1, 0, None, None, None, 1, ip(tgt), ip(glob), dp(delta)))
+    st = eng.L.snb_set_exceptions(eng.h, m - 1, ip(w["exc_pairs"]), dp(w["exc_qq"]), dp(w["exc_sigma"]), dp(w["exc_eps"]), None)
+    assert st == eng.capi.SNB_ERR_INVALID_ARGUMENT, st
+    eng.close()

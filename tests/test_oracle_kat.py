@@ -30,6 +30,17 @@ def test_reference_kat(case, ev, F):
     getattr(K, case)(ev, F)
 
 
+@pytest.mark.parametrize("method", [3, 4, 5])
+@pytest.mark.parametrize("nsub", [1, 2])
+def test_madelung_constants(method, nsub, ev, F):
+    """Independent absolute pin of the oracle's Ewald k-sum, PME and LJPME paths: the Madelung constant of rock salt and, with cations and
+    anions as two subsets, the fcc one-component-plasma constant on the diagonal slices (per-slice background term included)."""
+    kw = dict(kmax=(24, 24, 24)) if method == 3 else {}
+    K.testMadelung(ev, F, method, nsub, tol=1e-6, **kw)
+    if method == 4 and nsub == 2:
+        K.testMadelung(ev, F, method, nsub, tol=1e-6, force_tol=5e-6, cells=12, grid=160)      # the 13 824-ion lattice the GPU test runs on the brick kernels (coarser mesh: 1.3e-6 of k/r0^2 on the forces)
+
+
 def test_switching_function(ev, F):
     K.testSwitchingFunction(ev, F, 1)
     K.testSwitchingFunction(ev, F, 4, pme=(2.0, 30, 30, 30))
