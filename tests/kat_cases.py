@@ -726,6 +726,8 @@ def rockSalt(F, nsub, method, cells=4, r0=0.25, cutoff=0.9, alpha=4.8, grid=96, 
     ff.setPMEParameters(alpha, grid, grid, grid)
     if method == 5:
         ff.setLJPMEParameters(alpha, grid // 2, grid // 2, grid // 2)
+    if method == 3:
+        ff.ewaldKmax = (24, 24, 24)      # explicit k-vector bounds for the engine's host mirror (context.py calcEwaldParameters)
     for i, s in enumerate(sign):
         ff.addParticle(float(s), 0.2, 0.0)
         if nsub == 2:
