@@ -529,9 +529,15 @@ def main():
         meshes = [(0, grid, "")] + ([(8, dgrid, " [dispersion mesh]")] if method == 5 else [])
         for off, g, tag in meshes:
             Gm = g ** 3; Ghm = g * g * (g // 2 + 1)
+            # charge spreading: either one kernel that also runs the forward z FFT (scanning brick spreader), or the own-atoms spreader's
+            # two kernels (k_spreadOwn leaves per-work-group regions, k_spreadMerge sums them and runs the forward z FFT).  Algorithmic
+            # bytes are the pipeline's: atoms in, half-complex mesh out -- the regions in between are not credited.
             fused = int(stx.n_kernel_timed[off + 2]) == 0
-            add(off + 1, "k_spreadBrick" + (" (+ forward z FFT)" if fused else "") + tag, N * (4 * r + 4) + (nheld * Ghm * 2 * r if fused else nheld * Gm * r))
-            add(off + 2, "k_fftZ forward" + tag, nheld * (Gm * r + Ghm * 2 * r))
+            if fused:
+                add(off + 1, "k_spreadBrick (+ forward z FFT)" + tag, N * (4 * r + 4) + nheld * Ghm * 2 * r)
+            else:
+                add(off + 1, "k_spreadOwn (atoms -> per-work-group regions)" + tag, N * (4 * r + 4))
+                add(off + 2, "k_spreadMerge (regions -> mesh, + forward z FFT)" + tag, nheld * Ghm * 2 * r)
             add(off + 3, "k_fftStrided (y, forward)" + tag, nheld * Ghm * 4 * r)
             add(off + 4, "k_convolveX (x FFT + slice energies + lambda mix + inverse x FFT)" + tag, nheld * Ghm * 4 * r)
             add(off + 5, "k_fftStrided (y, inverse)" + tag, nheld * Ghm * 4 * r)

@@ -57,6 +57,8 @@ struct PinnedRing {
     ~PinnedRing() { for (auto& s : slots) { if (s.ev) (void)hipEventDestroy(s.ev); if (s.p) (void)hipHostFree(s.p); } }
     void copy(void* dst, const void* src, size_t bytes, hipStream_t st) {
         if (bytes == 0) return;
+        static const bool direct = getenv("SNB_NO_PINNED_RING") != nullptr;      // test switch: the copy straight from the caller's array (synchronised)
+        if (direct) { HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); HIPCHECK(hipStreamSynchronize(st)); return; }
         Slot& s = slots[next]; next = (next + 1) % SLOTS;
         if (s.pending) { HIPCHECK(hipEventSynchronize(s.ev)); s.pending = false; }
         if (s.cap < bytes) { if (s.p) (void)hipHostFree(s.p); s.p = nullptr; s.cap = std::max<size_t>(bytes, 4096); HIPCHECK(hipHostMalloc(&s.p, s.cap, hipHostMallocDefault)); }
@@ -173,6 +175,8 @@ template <typename Real> struct PmePlan {
     DevBuf<Real> gridReal;
     DevBuf<typename Vec<Real>::T2> gridCplx, twx, twy, twz;
     DevBuf<Real> modx, mody, modz;
+    // own-atoms spreader (pme.hip k_spreadOwn / k_spreadMerge): geometry and buffers, sized at rebuild time
+    int ownSlabs = 0, ownMargin = 1; DevBuf<unsigned char> ownPartial; DevBuf<int> ownBusy; DevBuf<int2> strays;
     void init(const int g[3], int nGrids, hipStream_t s) {
         d.nx = g[0]; d.ny = g[1]; d.nz = g[2]; d.nzc = g[2] / 2 + 1;
         if (!factorize(d.nx, d.fx, &d.nfx) || !factorize(d.ny, d.fy, &d.nfy) || !factorize(d.nz, d.fz, &d.nfz)) throw HipError{"PME mesh size is not FFT-legal"};
@@ -271,7 +275,7 @@ public:
     DevBuf<double> dDispCoef, sliceE, sliceTotal;      // 64 partitioned copies of the raw [S][2] energies, and their sum (last kernel of an energy step)
     bool energyPending = false, energySelective = false;      // the last energy step's sums are still on the device
     std::vector<double> hostSliceE;   // raw energies of the last energy evaluation (device part + host terms)
-    PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets;
+    PmePlan<Real> pme, dpme; int nGrids = 0; std::vector<int> ownedSubsets; DevBuf<int> dStrayCount;      // [2] stray atoms of the own-atoms spreader (Coulomb mesh, dispersion mesh)
     bool needRebuild = true, paramsDirty = true; int stepsSinceRebuild = 0;
     // direct-space ownership: i-block I belongs to this engine when I % shardPeriod lies in [shardBegin, shardEnd); the default is
     // (shard_rank, shard_rank + 1, shard_count); snb_set_shard_blocks lets the host rebalance direct-space work between ranks
@@ -519,6 +523,7 @@ public:
         gpuBuilt = false;
         if (cfg.host_neighbor_build || !gpuRebuild()) hostRebuild();
         pmeCells.resize(Npad);   // per-slot scratch is sized here: nothing may allocate while a step is being captured into a graph
+        if (isPme()) { dStrayCount.resize(2); planOwnSpread(pme); if (cfg.method == SNB_LJPME) planOwnSpread(dpme); }
         posRef.resize(Npad);
         HIPCHECK(hipMemcpyAsync(posRef.p, posq.p, sizeof(T4) * (size_t)Npad, hipMemcpyDeviceToDevice, stream));
         if (hDispFlags[1]) listOverruns++;      // an atom had moved more than skin/2 before this rebuild came
@@ -1144,16 +1149,59 @@ public:
         // measured on c3: f64 accumulation 1 slab 110 us, 2 slabs 105 us, 4 slabs 145 us; fixed-point (single precision, even nz) 1 slab 61 us, 2 slabs 67 us
         if (plan.d.nz % 2 == 0 && plan.d.nz >= 32 && !(sizeof(Real) == 4)) p.zSlabs = 2;
         if (const char* zs = getenv("SNB_ZSLABS")) { const int k = atoi(zs); if (k >= 1 && plan.d.nz % k == 0) p.zSlabs = k; }
-        if (colCells[0] > 0) {
-            const int ncx = pme.d.nx / colCells[0], ncy = pme.d.ny / colCells[1];
-            static const int gMin = getenv("SNB_BRICK_GROUP") ? atoi(getenv("SNB_BRICK_GROUP")) : 1;
-            auto group = [](int n, int ncols) { if (n % ncols) return 0; const int cpc = n / ncols; for (int g = gMin; g <= 4; g++) if (g * cpc >= 5 && ncols % g == 0) return g; return 0; };
-            const int gx = group(plan.d.nx, ncx), gy = group(plan.d.ny, ncy);
-            const bool packable = plan.d.nx < 1024 && plan.d.ny < 1024 && plan.d.nz < 1024;   // k_pmeCells packs 10 bits per axis
-            if (packable && gx > 0 && gy > 0 && sizeof(double) * (size_t)(gx * plan.d.nx / ncx) * (gy * plan.d.ny / ncy) * plan.d.nz <= 100 * 1024) {
-                p.sortNcx = ncx; p.sortNcy = ncy; p.groupX = gx; p.groupY = gy; p.colRange = colRange.p;
-            }
+        int ncx, ncy, gx, gy;
+        if (brickGeometry(plan, ncx, ncy, gx, gy)) {
+            p.sortNcx = ncx; p.sortNcy = ncy; p.groupX = gx; p.groupY = gy; p.colRange = colRange.p;
+            p.ownSlabs = plan.ownSlabs; p.ownMargin = plan.ownMargin; p.ownPartial = plan.ownPartial.p; p.ownBusy = plan.ownBusy.p;
+            p.strays = plan.strays.p; p.strayCount = dStrayCount.p ? dStrayCount.p + (plan.dispersion ? 1 : 0) : nullptr;
+            if (!p.ownPartial || !p.ownBusy || !p.strays || !p.strayCount) p.ownSlabs = 0;
         }
+    }
+    // brick kernels: do this mesh's cells tile the sort columns (cut for the Coulomb mesh)?  Bricks of `group` columns when one column is
+    // narrower than 5 cells (stencil 4 + 1 cell of drift).
+    bool brickGeometry(const PmePlan<Real>& plan, int& ncx, int& ncy, int& gx, int& gy) const {
+        if (colCells[0] <= 0) return false;
+        ncx = pme.d.nx / colCells[0]; ncy = pme.d.ny / colCells[1];
+        static const int gMin = getenv("SNB_BRICK_GROUP") ? atoi(getenv("SNB_BRICK_GROUP")) : 1;
+        auto group = [](int n, int ncols) { if (n % ncols) return 0; const int cpc = n / ncols; for (int g = gMin; g <= 4; g++) if (g * cpc >= 5 && ncols % g == 0) return g; return 0; };
+        gx = group(plan.d.nx, ncx); gy = group(plan.d.ny, ncy);
+        const bool packable = plan.d.nx < 1024 && plan.d.ny < 1024 && plan.d.nz < 1024;   // k_pmeCells packs 10 bits per axis
+        return packable && gx > 0 && gy > 0 && sizeof(double) * (size_t)(gx * plan.d.nx / ncx) * (gy * plan.d.ny / ncy) * plan.d.nz <= 100 * 1024;
+    }
+    // Geometry and buffers of the own-atoms spreader for one mesh (called from rebuild(): nothing may allocate inside a graph capture).
+    // Margin: the cells an atom can drift across its column's border during a list's life (skin / 2), at least one; slabs: the fewest that
+    // bring a work-group's LDS region under 40 KB (four work-groups per CU), at least two.
+    void planOwnSpread(PmePlan<Real>& plan) {
+        plan.ownSlabs = 0;
+        int ncx, ncy, gx, gy;
+        if (nGrids <= 0 || !brickGeometry(plan, ncx, ncy, gx, gy)) return;
+        const double det = box[0] * box[4] * box[8], sc = 1.0 / det;
+        const double r[9] = {box[4] * box[8] * sc, 0, 0, -box[3] * box[8] * sc, box[0] * box[8] * sc, 0,
+                             (box[3] * box[7] - box[4] * box[6]) * sc, -box[0] * box[7] * sc, box[0] * box[4] * sc};
+        const double perNmX = plan.d.nx * std::sqrt(r[0] * r[0] + r[3] * r[3] + r[6] * r[6]), perNmY = plan.d.ny * std::sqrt(r[1] * r[1] + r[4] * r[4] + r[7] * r[7]);      // mesh cells per nm of displacement
+        int M = std::max(1, (int)std::ceil(0.5 * std::max(cfg.neighbor_padding, 0.0) * std::max(perNmX, perNmY) + 0.01));
+        if (const char* e = getenv("SNB_SPREAD_MARGIN")) M = std::max(0, atoi(e));      // test switch (0: every border crossing becomes a stray)
+        static const bool noFixed = getenv("SNB_NO_FIXED_SPREAD") != nullptr;
+        const bool fixed = sizeof(Real) == 4 && !noFixed;
+        const size_t accBytes = fixed ? 4 : 8;
+        const int cx = gx * (plan.d.nx / ncx), cy = gy * (plan.d.ny / ncy), nz = plan.d.nz;
+        const int RX = cx + 4 + 2 * M, RY = cy + 4 + 2 * M;
+        if (RX > plan.d.nx || RY > plan.d.ny || gx * gy > 16 || nz > 256) return;
+        int best = 0;
+        static const int forced = getenv("SNB_OWN_SLABS") ? atoi(getenv("SNB_OWN_SLABS")) : 0;
+        for (int pass = 0; pass < 2 && !best; pass++)
+            for (int k = 2; k <= 32; k++) {      // (at least two: a single slab's region, nz + 4 planes, would wrap onto itself)
+                if (forced > 0 && k != forced) continue;
+                if (nz % k) continue;
+                const int sz = nz / k;
+                if (sz < 4 || (sz & 1) || (fixed && (sz & 3))) continue;      // (16-byte copies of the regions)
+                if (accBytes * (size_t)RX * RY * (sz + 4) <= (size_t)(pass == 0 ? 40 : 64) * 1024) { best = k; break; }
+            }
+        if (!best) return;
+        const size_t nreg = (size_t)nGrids * (ncx / gx) * (ncy / gy) * best;
+        plan.ownPartial.resize(nreg * RX * RY * (nz / best + 4) * accBytes);
+        plan.ownBusy.resize(nreg); plan.strays.resize(std::max(Npad, 1));
+        plan.ownSlabs = best; plan.ownMargin = M;
     }
 
     void execute(int includeForces, int includeEnergy, int includeDirect, int includeRecip, double* energyOut) override {
@@ -1255,7 +1303,8 @@ public:
     void enqueueStep(bool energy, bool includeDirect, bool includeRecip, EvSet* ev) {
         struct StampScope { StampScope(KernelStamps* k) { g_stamps = k; } ~StampScope() { g_stamps = nullptr; } };
         if (ev) for (int k = 0; k < 16; k++) ev->ks.used[k] = false;
-        StampScope stampScope(ev ? &ev->ks : nullptr);
+        static const bool noStamps = getenv("SNB_NO_KERNEL_STAMPS") != nullptr;      // measurement aid: only the pair-kernel / pipeline timers
+        StampScope stampScope((ev && !noStamps) ? &ev->ks : nullptr);
         if (ev) HIPCHECK(hipEventRecord(ev->e[0], stream));
         // one pass: sorted positions, cleared force arrays, and (PME on the brick path) the packed Coulomb-mesh cell of every atom
         GatherCells<Real> gc;
@@ -1277,6 +1326,7 @@ public:
             gc.fail2 = (Real)(half * half); gc.warn2 = (Real)(0.64 * half * half);      // rebuild request at 80 % of skin/2: the flag is read one step late
         }
         if (energy && Npad > 0) { gc.clearE = sliceE.p; gc.nClearE = S * 2 * SNB_SLICE_E_PARTS; }
+        if (includeRecip && isPme() && dStrayCount.p) { gc.zeroInts = dStrayCount.p; gc.nZeroInts = 2; }
         launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, forceBuf.p, forceArrays(), gc, stream);
         if (energy && Npad <= 0) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2 * SNB_SLICE_E_PARTS, stream));
         const bool ew = cfg.method >= SNB_Ewald;

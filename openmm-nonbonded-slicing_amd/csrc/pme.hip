@@ -33,6 +33,15 @@ struct FastDiv {
     __device__ int div(int x) const { return (int)(((float)x + 0.5f) * inv); }
 };
 
+// LDS stride of a z line in k_spreadOwn's region: a stride that is a multiple of 64 dwords puts every line on the same banks (RZ = 64 for
+// sz = 60: lanes = z-neighbours of one column then collide ~13-way: 47.7 us on c3 against 27.8); a few extra values per line spread them
+template <bool FIXED> __host__ __device__ inline int ownLineStride(int RZ) {
+    const int per = FIXED ? 4 : 2;                                  // values per 16 bytes: lines stay 16-byte aligned for the vector copy
+    int st = (RZ + per - 1) / per * per;
+    while (((st * (FIXED ? 1 : 2)) & 7) != 4) st += per;            // stride = 4 (mod 8) dwords: consecutive lines walk over all 64 banks
+    return st;
+}
+
 template <typename Real> struct Cx { Real x, y; };
 template <typename Real, int R1 = 0, int R2 = 0>
 __device__ inline Cx<Real>* fftLines(Cx<Real>* a, Cx<Real>* b, int n, const int* factors, int nf, int sign, const Cx<Real>* tw, int nb, int BS, int tid, int nthreads);
@@ -381,6 +390,7 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
     }
 }
 
+template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hipStream_t s);      // -1: not applicable, 0: real mesh written, 1: forward z FFT done too
 // Returns true when the spreader also did the forward z FFT (launchPmeForwardFFT must then skip its z pass).
 template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
     if (p.sortNcx > 0 && p.colRange != nullptr) {
@@ -397,6 +407,7 @@ template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStrea
         const size_t lds = brickBytes + (fuse ? std::max(listBytes, fftBytes) : listBytes);
         const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * p.zSlabs;
         if (!p.cellsReady) hipLaunchKernelGGL((k_pmeCells<Real>), dim3((p.natoms + 255) / 256), dim3(256), 0, s, p);
+        if (p.ownSlabs > 0) { const int r = launchSpreadOwn<Real>(p, s); if (r >= 0) return r == 1; }
 #define SNB_SPREAD(FX, FZ) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real, FX, FZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                              SNB_STAMPED_LAUNCH(stampSlot(p, 1), (k_spreadBrick<Real, FX, FZ>), dim3(nblocks), dim3(512), lds, s, p); }
         if constexpr (std::is_same<Real, float>::value) {
@@ -703,6 +714,280 @@ template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bound
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Own-atoms spreader (round 3).  The scanning brick spreader above is VALU-bound (29 M VALU instructions per launch on c3, 85 % busy):
+// every brick scans the atoms of nine columns to find the ones that reach it and every atom is processed by ~1.7 bricks per x-line.
+// Here a work-group = (brick, z slab) handles ONLY the atoms sorted into its own columns whose mesh cell lies in the slab, one thread
+// per atom (weights once, 25 lines, 75 packed LDS atomics), in an LDS region that covers the brick, the stencil's reach (+4) and a drift
+// margin of M cells on either side: no scan, no candidate list, no atom seen twice.  The region goes to global memory (ownPartial) and
+// k_spreadMerge sums, per z line, the regions that cover it -- integer sums in single precision, so the mesh does not depend on any
+// order -- and runs the forward z FFT of the brick's lines.  An atom that has drifted out of its region (further than the margin: the
+// neighbour list is overdue then) is recorded as a stray and added by the merge kernel, one by one.
+// Replaces gridSpreadCharge (platforms/common/src/kernels/pme.cc:24-122) + the sort it relies on + the forward z pass.
+// ---------------------------------------------------------------------------------------------------
+template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_spreadOwn(const PmeParams<Real> p) {
+    extern __shared__ __align__(16) unsigned char s_brick_raw[];
+    constexpr int NT = 512;
+    using Acc = typename std::conditional<FIXED, int, double>::type;
+    const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
+    const int cx = p.groupX * (p.d.nx / ncx), cy = p.groupY * (p.d.ny / ncy);
+    const int nbx = ncx / p.groupX, nby = ncy / p.groupY;
+    const int nSlabs = p.ownSlabs, M = p.ownMargin, sz = nz / nSlabs;
+    const int RX = cx + 4 + 2 * M, RY = cy + 4 + 2 * M, RZ = sz + 4;
+    const int RZP = ownLineStride<FIXED>(RZ);                            // LDS stride of a z line (bank spread); the global copy is dense
+    const int zs = blockIdx.x % nSlabs, brickId = blockIdx.x / nSlabs;
+    const int slot = brickId / (nbx * nby), bcol = brickId - slot * (nbx * nby);
+    const int Bx = bcol / nby, By = bcol - Bx * nby;
+    const int xr0 = Bx * cx - M, yr0 = By * cy - M, z0 = zs * sz;      // region origin (x, y may be negative: compared modulo the mesh)
+    const int nlines = RX * RY;
+    Acc* region = reinterpret_cast<Acc*>(s_brick_raw);
+    __shared__ int s_begin[16], s_pref[17], s_any;
+    const int tid = threadIdx.x;
+    const int nr = p.groupX * p.groupY;                                  // <= 16 (launcher)
+    if (tid < nr) {
+        const int gx = tid / p.groupY, gy = tid - gx * p.groupY;
+        const int2 rg = p.colRange[(size_t)p.gridSubset[slot] * (ncx * ncy) + (Bx * p.groupX + gx) * ncy + By * p.groupY + gy];
+        s_begin[tid] = rg.x; s_pref[tid + 1] = rg.y > rg.x ? rg.y - rg.x : 0;
+    }
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; s_pref[0] = 0; for (int r = 0; r < nr; r++) { acc += s_pref[r + 1]; s_pref[r + 1] = acc; } }
+    __syncthreads();
+    const int total = s_pref[nr];
+    if (total == 0) { if (tid == 0) p.ownBusy[blockIdx.x] = 0; return; }
+    {   // (RZP * sizeof(Acc) is a multiple of 16)
+        int4* z4 = reinterpret_cast<int4*>(region);
+        const int n4 = (int)((sizeof(Acc) * (size_t)nlines * RZP) >> 4);
+        for (int i = tid; i < n4; i += NT) z4[i] = make_int4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const Real fixScale = FIXED ? p.fixDev[0] : Real(1);
+    bool mine = false;
+    for (int v = tid; v < total; v += NT) {
+        int r = 0;
+        while (v >= s_pref[r + 1]) r++;
+        const int a = s_begin[r] + (v - s_pref[r]);
+        const int cell = p.cells[a];                                     // packed mesh cell (position-gather pass / k_pmeCells), -1: no charge on this mesh
+        if (cell < 0) continue;
+        const int rz = ((cell >> 20) & 1023) - z0;
+        if (rz < 0 || rz >= sz) continue;                                // another slab's atom
+        const auto pos = p.posq[a];
+        const Real q = pmeCharge(p, a);
+        int idx[3]; Real fr[3];
+        gridCoord<Real>(p.recip, p.recipLo, pos.x, pos.y, pos.z, p.d.nx, p.d.ny, nz, idx, fr);
+        int rx = idx[0] - xr0; if (rx < 0) rx += p.d.nx; else if (rx >= p.d.nx) rx -= p.d.nx;
+        int ry = idx[1] - yr0; if (ry < 0) ry += p.d.ny; else if (ry >= p.d.ny) ry -= p.d.ny;
+        if (rx + 4 >= RX || ry + 4 >= RY) {                              // drifted out of the region: the merge kernel adds it
+            const int at = atomicAdd(p.strayCount, 1);
+            p.strays[at] = make_int2(a, slot);
+            continue;
+        }
+        mine = true;
+        Real tx[5], ty[5], tz[5], dtmp[5];
+        bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
+        const Real wq = q * fixScale;
+        if constexpr (FIXED) {
+            // 32-bit fixed point, one ds_add_u32 per point: the scanning spreader packs two points per ds_add_u64 (15 instead of 25 LDS
+            // atomics per x-line), which costs ~17 VALU instructions per line for the odd/even selects and the borrow; this kernel is
+            // VALU-bound (one thread per atom, 25 lines), the LDS pipe has room (measured: 8.5 M VALU instructions per launch with pairs)
+#pragma unroll
+            for (int ix = 0; ix < 5; ix++) {
+                const Real wx = wq * tx[ix];
+                Acc* plane = region + (size_t)(rx + ix) * RY * RZP + rz;
+#pragma unroll
+                for (int iy = 0; iy < 5; iy++) {
+                    const Real wxy = wx * ty[iy];
+                    unsigned* line = reinterpret_cast<unsigned*>(plane + (ry + iy) * RZP);
+#pragma unroll
+                    for (int iz = 0; iz < 5; iz++) __hip_atomic_fetch_add(&line[iz], (unsigned)__float2int_rn(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ix = 0; ix < 5; ix++) {
+                const Real wx = wq * tx[ix];
+                Acc* plane = region + (size_t)(rx + ix) * RY * RZP;
+#pragma unroll
+                for (int iy = 0; iy < 5; iy++) {
+                    const Real wxy = wx * ty[iy];
+                    Acc* line = plane + (ry + iy) * RZP + rz;
+#pragma unroll
+                    for (int iz = 0; iz < 5; iz++) __hip_atomic_fetch_add(&line[iz], (double)(wxy * tz[iz]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+    if (mine) s_any = 1;      // (same value from every writer)
+    __syncthreads();
+    const int busy = s_any;
+    if (tid == 0) p.ownBusy[blockIdx.x] = busy;
+    if (!busy) return;
+    Acc* out = reinterpret_cast<Acc*>(p.ownPartial) + (size_t)blockIdx.x * nlines * RZ;
+    // dense copy: a half-wave per line, 16 bytes per lane (RZ * sizeof(Acc) is a multiple of 16: sz even in fixed point)
+    constexpr int PER = 16 / sizeof(Acc);
+    const int q4 = RZ / PER, half = tid >> 5, hl = tid & 31;
+    for (int l = half; l < nlines; l += NT / 32)
+        for (int k = hl; k < q4; k += 32)
+            reinterpret_cast<int4*>(out + (size_t)l * RZ)[k] = reinterpret_cast<const int4*>(region + (size_t)l * RZP)[k];
+}
+
+// One work-group per brick: per z line of the brick, the sum of the regions of k_spreadOwn that cover it (the brick's own slabs, the
+// reach of the bricks below it in x / y, the margin of the bricks above), then -- FUSEZ -- the forward z FFT of the brick's lines, two
+// real lines per complex transform, written as the half-complex mesh; otherwise the real mesh.  One thread sums one 16-byte chunk of a
+// line: at most 3 x 3 bricks and 2 slabs cover it; per y neighbour the 6 (predicated) loads are issued back to back -- the first version
+// walked the candidates one dependent load at a time and took 101 us on c3.
+template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2> __global__ __launch_bounds__(256) void k_spreadMerge(const PmeParams<Real> p, const int chunk) {
+    constexpr int NT = 256;      // (a brick is ~18 complex lines: 512 threads left most of them idle in the FFT passes, and at the ~120 VGPRs of those passes 256-thread groups go four to a CU)
+    using Acc = typename std::conditional<FIXED, int, double>::type;
+    constexpr int CMAX = FIXED ? 4 : 2;                                    // values per 16-byte load
+    const int ncx = p.sortNcx, ncy = p.sortNcy, nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc;
+    const int cx = p.groupX * (nx / ncx), cy = p.groupY * (ny / ncy);
+    const int nbx = ncx / p.groupX, nby = ncy / p.groupY;
+    const int nSlabs = p.ownSlabs, M = p.ownMargin, sz = nz / nSlabs;
+    const int RX = cx + 4 + 2 * M, RY = cy + 4 + 2 * M, RZ = sz + 4;
+    const size_t npts = (size_t)RX * RY * RZ;
+    const int slot = blockIdx.x / (nbx * nby), bcol = blockIdx.x - slot * (nbx * nby);
+    const int Bx = bcol / nby, By = bcol - Bx * nby;
+    const int x0 = Bx * cx, y0 = By * cy;
+    const int nl = cx * cy, nb = (nl + 1) >> 1, BS = nb + 1;
+    const int tid = threadIdx.x;
+    Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);                     // FUSEZ: [nz][BS] (+ B, roots of unity)
+    Cx<Real>* B = A + (size_t)nz * BS;
+    Cx<Real>* tw = B + (size_t)nz * BS;
+    __shared__ int s_busy[9 * 32];                                         // [3][3][nSlabs]: was the region written this step?
+    __shared__ int s_any;
+    const int loX = (4 + M + cx - 1) / cx, hiX = (M + cx - 1) / cx, loY = (4 + M + cy - 1) / cy, hiY = (M + cy - 1) / cy;      // launcher: lo + hi + 1 <= 3
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    if (tid < 9 * nSlabs) {
+        const int j = tid / nSlabs, s = tid - j * nSlabs, jx = j / 3, jy = j - jx * 3;
+        const int dbx = jx - hiX, dby = jy - hiY;
+        int b = 0;
+        if (dbx <= loX && dby <= loY) {
+            int bx2 = (Bx - dbx) % nbx; if (bx2 < 0) bx2 += nbx;
+            int by2 = (By - dby) % nby; if (by2 < 0) by2 += nby;
+            b = p.ownBusy[((slot * nbx + bx2) * nby + by2) * nSlabs + s];
+        }
+        s_busy[tid] = b;
+        if (b) s_any = 1;
+    }
+    if (FUSEZ) for (int k = tid; k < nz; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
+    __syncthreads();
+    const Real inv = FIXED ? p.fixDev[1] : Real(1);
+    const Acc* partial = reinterpret_cast<const Acc*>(p.ownPartial);
+    Real* greal = p.gridReal + (size_t)slot * nx * ny * nz;
+    Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.gridCplx) + (size_t)slot * nx * ny * nzc;
+    const FastDiv dzc(nzc), dcy2(cy);
+    // strays (normally none): atoms whose footprint left the region of their own work-group; every brick looks at every stray
+    const int nStray = *p.strayCount;
+    if (FUSEZ && !s_any && nStray == 0) {      // nothing of this subset anywhere near (uniform): the brick's spectrum is zero
+        for (int it = tid; it < nl * nzc; it += NT) {
+            const int l = dzc.div(it), k = it - l * nzc;
+            const int lx = dcy2.div(l), ly = l - lx * cy;
+            out[((size_t)(x0 + lx) * ny + (y0 + ly)) * nzc + k] = {Real(0), Real(0)};
+        }
+        return;
+    }
+    const int nch = nz / chunk;                                            // chunks per line (launcher: chunk divides sz, hence nz and RZ)
+    const FastDiv dch(nch);
+    for (int it = tid; it < nl * nch; it += NT) {
+        const int l = dch.div(it), k0 = (it - l * nch) * chunk;
+        const int lx = dcy2.div(l), ly = l - lx * cy;
+        // the two slabs whose regions hold plane k0: its own, and the one below when k0 is among that one's four extra planes
+        const int s1 = k0 / sz, zl1 = k0 - s1 * sz;
+        const int s0 = s1 == 0 ? nSlabs - 1 : s1 - 1, zl0 = zl1 + sz;
+        const bool low = zl0 < RZ;
+        Acc sum[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; c++) sum[c] = Acc(0);
+#pragma unroll 1
+        for (int jy = 0; jy < 3; jy++) {      // per y neighbour: the (<= 3 x-neighbours) x (2 slabs) loads go out together
+            const int dby = jy - hiY, ry = ly + dby * cy + M;
+            if (dby > loY || ry < 0 || ry >= RY) continue;
+            int by2 = (By - dby) % nby; if (by2 < 0) by2 += nby;
+            Acc v[6][CMAX];
+#pragma unroll
+            for (int jx = 0; jx < 3; jx++) {
+                const int dbx = jx - hiX, rx = lx + dbx * cx + M;
+                int bx2 = (Bx - dbx) % nbx; if (bx2 < 0) bx2 += nbx;
+                const bool ok = dbx <= loX && rx >= 0 && rx < RX;
+                const size_t reg = (size_t)((slot * nbx + bx2) * nby + by2) * nSlabs;
+                const size_t line = ((size_t)rx * RY + ry) * RZ;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int s = h ? s0 : s1, zl = h ? zl0 : zl1;
+                    const int u = jx * 2 + h;
+#pragma unroll
+                    for (int c = 0; c < CMAX; c++) v[u][c] = Acc(0);
+                    if (ok && (h == 0 || low) && s_busy[(jx * 3 + jy) * nSlabs + s]) {
+                        const Acc* src = partial + (reg + s) * npts + line + zl;
+                        if (chunk == CMAX) {
+                            if constexpr (FIXED) { const int4 t = *reinterpret_cast<const int4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
+                            else { const double2 t = *reinterpret_cast<const double2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
+                        } else v[u][0] = src[0];
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CMAX; c++)
+#pragma unroll
+                for (int u = 0; u < 6; u++) sum[c] += v[u][c];
+        }
+#pragma unroll
+        for (int c = 0; c < CMAX; c++) if (c < chunk) {
+            const Real val = (Real)sum[c] * inv;
+            if (FUSEZ) reinterpret_cast<Real*>(&A[(k0 + c) * BS + (l >> 1)])[l & 1] = val;
+            else greal[((size_t)(x0 + lx) * ny + (y0 + ly)) * nz + k0 + c] = val;
+        }
+    }
+    if (FUSEZ && (nl & 1)) for (int k = tid; k < nz; k += NT) A[k * BS + (nl >> 1)].y = Real(0);      // the odd line out has no partner
+    __syncthreads();
+    for (int s = 0; s < nStray; s++) {
+        const int2 e = p.strays[s];
+        if (e.y != slot) continue;
+        const auto pos = p.posq[e.x];
+        int idx[3]; Real fr[3];
+        gridCoord<Real>(p.recip, p.recipLo, pos.x, pos.y, pos.z, nx, ny, nz, idx, fr);
+        int rx = idx[0] - x0; if (rx > nx / 2) rx -= nx; else if (rx < -(nx / 2)) rx += nx;
+        int ry = idx[1] - y0; if (ry > ny / 2) ry -= ny; else if (ry < -(ny / 2)) ry += ny;
+        if (rx + 4 < 0 || rx >= cx || ry + 4 < 0 || ry >= cy) continue;     // (uniform: every thread looks at the same stray)
+        if (tid < 125) {
+            const int ix = tid / 25, iy = (tid / 5) % 5, iz = tid % 5;
+            const int lx = rx + ix, ly = ry + iy;
+            if (lx >= 0 && lx < cx && ly >= 0 && ly < cy) {
+                Real tx[5], ty[5], tz[5], dtmp[5];
+                bspline5<Real>(fr[0], tx, dtmp); bspline5<Real>(fr[1], ty, dtmp); bspline5<Real>(fr[2], tz, dtmp);
+                Real wxy = pmeCharge(p, e.x) * (FIXED ? p.fixDev[0] : Real(1)), wz = Real(0);
+#pragma unroll
+                for (int k = 0; k < 5; k++) { if (k == ix) wxy *= tx[k]; if (k == iz) wz = tz[k]; }
+#pragma unroll
+                for (int k = 0; k < 5; k++) if (k == iy) wxy *= ty[k];
+                Real w = wxy * wz;
+                if (FIXED) w = (Real)__float2int_rn(w) * inv;      // the value the fixed-point path would have added
+                int z = idx[2] + iz; if (z >= nz) z -= nz;
+                const int l = lx * cy + ly;
+                if (FUSEZ) { Real* t = reinterpret_cast<Real*>(&A[z * BS + (l >> 1)]) + (l & 1); __hip_atomic_fetch_add(t, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                else __hip_atomic_fetch_add(&greal[((size_t)(x0 + lx) * ny + (y0 + ly)) * nz + z], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if constexpr (FUSEZ) {
+        Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, NT);
+        __syncthreads();
+        for (int it = tid; it < nb * nzc; it += NT) {
+            const int c = dzc.div(it), k = it - c * nzc;
+            const Cx<Real> z = R[k * BS + c], m = R[(k == 0 ? 0 : nz - k) * BS + c];
+            const int l0 = 2 * c, lx0 = dcy2.div(l0), ly0 = l0 - lx0 * cy;
+            out[((size_t)(x0 + lx0) * ny + (y0 + ly0)) * nzc + k] = {Real(0.5) * (z.x + m.x), Real(0.5) * (z.y - m.y)};
+            if (l0 + 1 < nl) {
+                const int l1 = l0 + 1, lx1 = dcy2.div(l1), ly1 = l1 - lx1 * cy;
+                out[((size_t)(x0 + lx1) * ny + (y0 + ly1)) * nzc + k] = {Real(0.5) * (z.y + m.y), Real(0.5) * (m.x - z.x)};
+            }
+        }
+    }
+}
+
 // ---- strided axis (y): tiles of NB adjacent lines (adjacent = consecutive complex elements in memory) ----
 // address(a, b, k) = a*strideA + b + k*strideK, b in [0, nbTotal)
 template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void k_fftStrided(const PmeParams<Real> p, int n, size_t strideA, int nbTotal, size_t strideK,
@@ -963,6 +1248,58 @@ template <typename Real> static void launchConvolveX(int r1, int r2, dim3 grid, 
 #undef X
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_convolveX<Real, 0, 0>), grid, dim3(512), lds, s, p, NB, nCols);
+}
+
+
+// own-atoms spreader: k_spreadOwn over (brick, slab) work-groups, then k_spreadMerge per brick (fused with the forward z FFT when its
+// buffers fit LDS).  Geometry (slabs, margin) and the buffers come from the engine (sized at rebuild time).
+template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hipStream_t s) {
+    static const bool off = getenv("SNB_NO_OWN_SPREAD") != nullptr;      // test switch: the scanning brick spreader
+    if (off || p.ownSlabs < 2 || !p.ownPartial || p.d.nz > 256) return -1;      // (one slab's region of nz + 4 planes would wrap onto itself)
+    static const bool noFixed = getenv("SNB_NO_FIXED_SPREAD") != nullptr;
+    const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
+    const int sz = p.d.nz / p.ownSlabs;
+    const bool fixed = std::is_same<Real, float>::value && !noFixed && sz % 4 == 0;      // (16-byte copies of 4-byte values)
+    if (!fixed && (sz & 1)) return -1;
+    const int RX = cx + 4 + 2 * p.ownMargin, RY = cy + 4 + 2 * p.ownMargin, RZ = sz + 4;
+    const size_t ldsOwn = (fixed ? sizeof(int) : sizeof(double)) * (size_t)RX * RY * (fixed ? ownLineStride<true>(RZ) : ownLineStride<false>(RZ));
+    const int M = p.ownMargin;
+    const int reachX = (4 + M + cx - 1) / cx + (M + cx - 1) / cx + 1, reachY = (4 + M + cy - 1) / cy + (M + cy - 1) / cy + 1;      // bricks whose regions cover a line
+    if (ldsOwn > 64 * 1024 || RX > p.d.nx || RY > p.d.ny || p.groupX * p.groupY > 16 || reachX > 3 || reachY > 3 || p.ownSlabs > 32 || sz < 4) return -1;
+    const int cmax = fixed ? 4 : 2, chunk = (sz % cmax == 0) ? cmax : 1;      // values per load of the merge kernel
+    const int nbricks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
+    const int nb = (cx * cy + 1) / 2;
+    const size_t ldsFft = sizeof(Cx<Real>) * ((size_t)2 * p.d.nz * (nb + 1) + p.d.nz);
+    static const bool noFuse = getenv("SNB_NO_FUSED_Z") != nullptr;
+    const bool fuse = !noFuse && ldsFft <= 120 * 1024;
+#define SNB_OWN(FX) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadOwn<Real, FX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsOwn); \
+                      SNB_STAMPED_LAUNCH(stampSlot(p, 1), (k_spreadOwn<Real, FX>), dim3(nbricks * p.ownSlabs), dim3(512), ldsOwn, s, p); }
+#define SNB_MERGE(FX, FZ, A, B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadMerge<Real, FX, FZ, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FZ ? ldsFft : 0)); \
+                                  SNB_STAMPED_LAUNCH(stampSlot(p, 2), (k_spreadMerge<Real, FX, FZ, A, B>), dim3(nbricks), dim3(256), (FZ ? ldsFft : 0), s, p, chunk); }
+    bool done = false;
+    if constexpr (std::is_same<Real, float>::value) {
+        if (fixed) {
+            SNB_OWN(true)
+            if (fuse) {
+#define X(A, B) if (!done && p.d.rz1 == A && p.d.rz2 == B) { SNB_MERGE(true, true, A, B) done = true; }
+                SNB_FFT_PAIRS(X)
+#undef X
+                if (!done) { SNB_MERGE(true, true, 0, 0) done = true; }
+            } else { SNB_MERGE(true, false, 0, 0) done = true; }
+        }
+    }
+    if (!done) {
+        SNB_OWN(false)
+        if (fuse) {
+#define X(A, B) if (!done && p.d.rz1 == A && p.d.rz2 == B) { SNB_MERGE(false, true, A, B) done = true; }
+            SNB_FFT_PAIRS(X)
+#undef X
+            if (!done) { SNB_MERGE(false, true, 0, 0) done = true; }
+        } else { SNB_MERGE(false, false, 0, 0) }
+    }
+#undef SNB_OWN
+#undef SNB_MERGE
+    return fuse ? 1 : 0;
 }
 
 static size_t ldsBudget() { return 96 * 1024; }

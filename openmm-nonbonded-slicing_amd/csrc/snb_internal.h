@@ -141,6 +141,14 @@ template <typename Real> struct PmeParams {
     int groupX, groupY;        // sort columns per brick (brick = group * nx/sortNcx cells, at least 5)
     int zSlabs;                // bricks are also cut into this many slabs along z (nz % zSlabs == 0)
     const int2* colRange;      // [nsubTotal][ncx*ncy] sorted-atom range of every (subset, xy column)
+    // own-atoms spreader (round 3, pme.hip k_spreadOwn / k_spreadMerge): every (brick, z slab) work-group accumulates ONLY the atoms sorted
+    // into its columns, in an LDS region that includes the stencil's reach and a drift margin, and leaves it in ownPartial; the merge kernel
+    // sums the overlapping regions per z line (exact integer sums in single precision) and runs the forward z FFT.  ownSlabs == 0: off.
+    int ownSlabs, ownMargin;   // z slabs per brick; drift margin in mesh cells on either side of the brick (x and y)
+    void* ownPartial;          // [nsub * bricks * ownSlabs][RX * RY * RZ] int (fixed point) or double
+    int* ownBusy;              // [nsub * bricks * ownSlabs] 1 when the region was written this step
+    int2* strays;              // (atom, grid slot) of atoms whose footprint left their work-group's region; merged one by one (normally none)
+    int* strayCount;           // zeroed by the position-gather pass
     // brick interpolation of the step's LAST mesh, unsharded: the atom's thread also writes the step's user-order force,
     // direct-space accumulator + reciprocal force, into the caller's buffer (what k_finishForces does as a launch of its own)
     void* outForces; int outIsDouble, outAccumulate;      // [N][3] in the caller's type, or null
@@ -257,6 +265,7 @@ template <typename Real> struct GatherCells {
     // sqrt(warn2) (time to rebuild), flags[1] |= 1 beyond sqrt(fail2) = skin/2 (the list may already have missed a pair)
     const typename Vec<Real>::T4* posRef; int* flags; Real warn2, fail2;
     double* clearE; int nClearE;      // energy steps: the slice-energy partitions, zeroed by this pass (a memset of their own was a 5 us launch)
+    int* zeroInts; int nZeroInts;     // small per-step counters reset by this pass (the spreader's stray-atom counts)
 };
 
 template <typename Real> void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,

@@ -2,7 +2,7 @@
 # usage: tools/pmc_sq.sh <tag> "<counters>" [bench args...]   (GPU box) one --pmc pass, per-kernel averages
 tag=$1; ctrs=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/$tag -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/$tag.log 2>&1 || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/$tag -- python3 bench.py --no-cpu-baseline --no-double "$@" > gpurun_out/$tag.log 2>&1 || exit 1
 python3 - "$tag" <<'PY'
 import csv, glob, sys, collections
 tag = sys.argv[1]
