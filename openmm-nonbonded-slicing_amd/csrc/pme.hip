@@ -1467,9 +1467,9 @@ template <typename Real> __global__ __launch_bounds__(256) void k_interpolate(co
 // cost ~80 us per held grid at 300k atoms.
 // (occupancy note: ~100 VGPRs => one 1024-thread work-group per CU, 400 bricks = two rounds of ~20 us on c3; forcing 64 VGPRs spills
 // and measures 71 us, 512-thread groups 56 us, z slabs 70 us -- this shape, 52 us, is the best of those)
-template <typename Real> __global__ __launch_bounds__(1024) void k_interpolateBricks(const PmeParams<Real> p, const int zSlabs) {
+template <typename Real, int NT> __global__ __launch_bounds__(NT) void k_interpolateBricks(const PmeParams<Real> p, const int zSlabs) {
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
-    constexpr int NT = 1024, HALO_LO = 1, EXTRA = 6;
+    constexpr int HALO_LO = 1, EXTRA = 6;
     const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
     const int cx = p.groupX * (p.d.nx / ncx), cy = p.groupY * (p.d.ny / ncy);
     const int nby = ncy / p.groupY;
@@ -1684,9 +1684,18 @@ template <typename Real> static bool launchInterpolateBricks(const PmeParams<Rea
         static const bool noBrick = getenv("SNB_NO_INTERP_BRICKS") != nullptr;   // testing aid: force the 32-lanes-per-atom kernel
         if (lds <= 150 * 1024 && !noBrick && p.nsubTotal * p.groupX * p.groupY <= 256) {
             const int nblocks = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * zSlabs;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBricks<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (!p.mix) p.outForces = nullptr;      // (sharded engines visit an atom once per held grid: the separate finish pass stays)
-            SNB_STAMPED_LAUNCH(stampSlot(p, 7), (k_interpolateBricks<Real>), dim3(nblocks), dim3(1024), lds, s, p, zSlabs);
+            // 512-thread work-groups go two to a CU when the brick fits LDS twice (the kernel's ~100 VGPRs allow 16 waves per CU either way):
+            // with more bricks than CUs the second round of 1024-thread groups runs half empty
+            static const int ntEnv = getenv("SNB_INTERP_THREADS") ? atoi(getenv("SNB_INTERP_THREADS")) : 0;
+            const bool narrow = ntEnv ? ntEnv == 512 : (nblocks > 256 && lds <= 76 * 1024);
+            if (narrow) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBricks<Real, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                SNB_STAMPED_LAUNCH(stampSlot(p, 7), (k_interpolateBricks<Real, 512>), dim3(nblocks), dim3(512), lds, s, p, zSlabs);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_interpolateBricks<Real, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                SNB_STAMPED_LAUNCH(stampSlot(p, 7), (k_interpolateBricks<Real, 1024>), dim3(nblocks), dim3(1024), lds, s, p, zSlabs);
+            }
             return p.outForces != nullptr;
         }
     }
@@ -1702,9 +1711,12 @@ template <typename Real> bool launchPmeInterpolate(const PmeParams<Real>& p, hip
         // Wider bricks (2 x 1, 2 x 2 columns) cut the count below the CU count and the halo overhead with it, as long as LDS allows.
         PmeParams<Real> q = p;
         static const int gEnv = getenv("SNB_INTERP_GROUP") ? atoi(getenv("SNB_INTERP_GROUP")) : -1;
+        // (measured on c3, 400 single-column bricks: 1024 threads on 2 x 1-column bricks 35.2 us, 1024 threads on single columns 39.3,
+        // 512 threads on single columns -- two work-groups per CU -- 29.1: when the single-column brick fits LDS twice, do not widen)
+        const size_t single = sizeof(Real) * (size_t)(q.groupX * (q.d.nx / q.sortNcx) + 6) * (q.groupY * (q.d.ny / q.sortNcy) + 6) * (q.d.nz + 4) + 1024;
         for (int step = 0; step < 2; step++) {
             const int nb = (q.sortNcx / q.groupX) * (q.sortNcy / q.groupY);
-            if (gEnv >= 0 ? step >= gEnv : nb <= 256) break;
+            if (gEnv >= 0 ? step >= gEnv : (nb <= 256 || single <= 76 * 1024)) break;
             PmeParams<Real> t = q;
             if (step == 0 && t.sortNcx % (2 * t.groupX) == 0) t.groupX *= 2; else if (t.sortNcy % (2 * t.groupY) == 0) t.groupY *= 2; else break;
             const size_t need = sizeof(Real) * (size_t)(t.groupX * (t.d.nx / t.sortNcx) + 6) * (t.groupY * (t.d.ny / t.sortNcy) + 6) * (t.d.nz + 4) + 1024;
