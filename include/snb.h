@@ -207,7 +207,8 @@ snb_status snb_reset_timers(snb_handle h);
  * samples behind snb_stats' kernel timers); the others replay the captured step graph.  Default 32; a short measured region asks
  * for more samples.  n <= 0: never (no timers). */
 snb_status snb_set_timing_interval(snb_handle h, int32_t n);
-/* Smallest FFT-legal mesh size >= n (radices 2,3,5,7). */
+/* Smallest FFT-legal mesh size >= n: no prime factor above 13, the rule of the reference's GPU platforms
+ * (platforms/common/include/FFT3DFactory.h:31-47); at least 6. */
 int32_t    snb_legal_grid_size(int32_t n);
 int32_t    snb_abi_version(void);
 

@@ -183,9 +183,13 @@ template <typename Real> struct PmePlan {
         splitTwoPass(d.nx, &d.rx1, &d.rx2); splitTwoPass(d.ny, &d.ry1, &d.ry2); splitTwoPass(d.nz, &d.rz1, &d.rz2);
         // measured on MI355X (120^3 = 8 x 15, 4 grids, single precision, Winograd radix-3/5 butterflies): two-pass register FFT vs
         // staged Stockham: inverse z 18.2 vs 23.5 us, y 30.6 vs 32.4, fused x/convolution 68.6 vs 71.0.  SNB_FFT_TWOPASS=0/1 overrides.
-        bool twoPass = sizeof(Real) == 4;
+        // Round 3, double precision (c5, 180^3 = 12 x 15 and 90^3 = 9 x 10): the register passes win on the y and z axes (y 183 -> 150 us,
+        // inverse z 185 -> 134, 90^3: 32 -> 22 and 21 -> 14) and in the fused x kernel of the 90^3 mesh (63 -> 42), but the x kernel of the
+        // 180^3 mesh, which also holds the spectra of all subsets, spills with 15-point transforms in double (351 -> 488): staged there.
+        bool twoPass = true;
         if (const char* e = getenv("SNB_FFT_TWOPASS")) twoPass = atoi(e) != 0;
         if (!twoPass) d.rx1 = d.ry1 = d.rz1 = d.rx2 = d.ry2 = d.rz2 = 0;
+        if (sizeof(Real) == 8 && std::max(d.rx1, d.rx2) > 12 && !getenv("SNB_FFT_TWOPASS")) d.rx1 = d.rx2 = 0;
         gridReal.resize((size_t)nGrids * d.nx * d.ny * d.nz);
         gridCplx.resize((size_t)nGrids * d.nx * d.ny * d.nzc);
         auto tw = [&](int n, DevBuf<typename Vec<Real>::T2>& buf) {

@@ -626,7 +626,9 @@ __device__ inline Cx<Real>* fftLines(Cx<Real>* a, Cx<Real>* b, int n, const int*
             case 3: fftStage<Real, 3>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
             case 4: fftStage<Real, 4>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
             case 5: fftStage<Real, 5>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
-            default: fftStage<Real, 7>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
+            case 7: fftStage<Real, 7>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
+            case 11: fftStage<Real, 11>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
+            default: fftStage<Real, 13>(a, b, n, len, s, sign, tw, nb, BS, tid, nthreads); break;
         }
         Cx<Real>* tmp = a; a = b; b = tmp;
         len /= P; s *= P;
@@ -1749,6 +1751,8 @@ bool factorize(int n, int* factors, int* nf) {
     while (n % 3 == 0) { factors[k++] = 3; n /= 3; }
     while (n % 5 == 0) { factors[k++] = 5; n /= 5; }
     while (n % 7 == 0) { factors[k++] = 7; n /= 7; }
+    while (n % 11 == 0) { factors[k++] = 11; n /= 11; }      // 11 and 13: the reference's GPU FFT is legal up to 13-smooth sizes
+    while (n % 13 == 0) { factors[k++] = 13; n /= 13; }      // (platforms/common/include/FFT3DFactory.h:45-47)
     *nf = k;
     return n == 1 && k <= 16;
 }
@@ -1766,7 +1770,7 @@ int legalGridSize(int n) {
     if (n < 6) n = 6;
     for (;; n++) {
         int f[32], nf, m = n;
-        for (int p : {2, 3, 5, 7}) while (m % p == 0) m /= p;
+        for (int p : {2, 3, 5, 7, 11, 13}) while (m % p == 0) m /= p;
         if (m == 1 && factorize(n, f, &nf)) return n;
     }
 }

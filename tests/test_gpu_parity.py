@@ -144,6 +144,7 @@ CASES = [
     ("ljpme_3000_n4", 3000, 4, 5, 3.2, 1.0, (2.6283, 28, 28, 28), (2.6283, 20, 20, 20), False),
     ("ljpme_brickgroup2_6000_n3", 6000, 3, 5, 4.0, 1.0, (2.6283, 36, 36, 36), (2.6283, 18, 18, 18), False),
     ("pme_smallbox_wrap_600_n2", 600, 2, 4, 2.05, 1.0, (2.6283, 20, 20, 20), None, False),
+    ("pme_mesh_factors_11_13_4096_n2", 4096, 2, 4, 3.5, 1.0, (2.6283, 33, 39, 44), None, False),
 ]
 
 
@@ -537,7 +538,8 @@ def test_fft_against_numpy(snb):
     dp = ctypes.POINTER(ctypes.c_double)
     # sizes of the reference's FFT tests (platforms/cuda/tests/TestCudaCuFFT3D.cpp:36-141) plus the bench grids
     for prec, tol in ((1, 1e-10), (0, 2e-4)):
-        for (nx, ny, nz), batch in [((28, 25, 25), 1), ((25, 28, 25), 2), ((25, 25, 28), 3), ((21, 25, 27), 2), ((28, 25, 30), 1), ((80, 80, 80), 2), ((120, 120, 120), 1)]:
+        for (nx, ny, nz), batch in [((28, 25, 25), 1), ((25, 28, 25), 2), ((25, 25, 28), 3), ((21, 25, 27), 2), ((28, 25, 30), 1), ((80, 80, 80), 2), ((120, 120, 120), 1),
+                                  ((22, 26, 33), 2), ((52, 44, 39), 1), ((143, 26, 22), 1)]:      # factors 11 and 13 (legal on the reference's GPU path: FFT3DFactory.h:45-47)
             a = rng.standard_normal((batch, nx, ny, nz))
             spec = np.zeros((batch, nx, ny, nz // 2 + 1, 2)); rt = np.zeros_like(a)
             st = L.snb_test_fft3d(prec, 0, batch, nx, ny, nz, a.ctypes.data_as(dp), spec.ctypes.data_as(dp), rt.ctypes.data_as(dp))
