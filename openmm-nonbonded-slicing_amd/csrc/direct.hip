@@ -138,12 +138,12 @@ __device__ __forceinline__ void tileSteps(const DirectParams<Real>& p, const typ
             }
             if (MC == MC_LJPME && !ENERGY && std::is_same<Real, double>::value) {
                 // forces only, double: 6 c6 [1 - e^{-x}(1 + x + x^2/2 + x^3/6)] / r^6 = 6 c6 r^2 Gd(r^2), x = (alpha_d r)^2, with
-                // Gd(r^2) = alpha_d^8 e^{-x} sum_k x^k / (k+4)!  an entire function of r^2: a degree-20 polynomial in the same t as the
-                // Ewald factor (~1e-13) instead of a double-precision exp and its pre-factors (engine.hip buildEwaldPoly)
+                // Gd(r^2) = alpha_d^8 e^{-x} sum_k x^k / (k+4)!  an entire function of r^2: a degree-17 polynomial in the same t as the
+                // Ewald factor (~1e-12 of Gd(0)) instead of a double-precision exp and its pre-factors (engine.hip buildEwaldPoly)
                 const Real t = r2 * p.ewScale - Real(1);
-                Real gd = p.dispPoly[20];
+                Real gd = p.dispPoly[SNB_DISP_DEG_F64];
 #pragma unroll
-                for (int k = 19; k >= 0; k--) gd = gd * t + p.dispPoly[k];
+                for (int k = SNB_DISP_DEG_F64 - 1; k >= 0; k--) gd = gd * t + p.dispPoly[k];
                 const Real c6 = c6i * (Real(8) * sj2.x * sj2.x * sj2.x * sj2.y);
                 fLJ += Real(6) * c6 * gd * r2 * lamL;
             } else if (MC == MC_LJPME) {
@@ -177,11 +177,11 @@ __device__ __forceinline__ void tileSteps(const DirectParams<Real>& p, const typ
             // Coulomb
             const Real qq = (ENERGY ? qi : qiS) * xj.w;
             if ((MC == MC_EWALD || MC == MC_LJPME) && !ENERGY && std::is_same<Real, double>::value) {
-                // forces only: [erfc(ar)/r + 2a/sqrt(pi) e^{-(ar)^2}] = 1/r - r^2 Bt(r^2), Bt a degree-20 polynomial (~1e-13): no libm erfc / exp
+                // forces only: [erfc(ar)/r + 2a/sqrt(pi) e^{-(ar)^2}] = 1/r - r^2 Bt(r^2), Bt a degree-16 polynomial (~6e-12 of Bt(0)): no libm erfc / exp
                 const Real t = r2 * p.ewScale - Real(1);
-                Real bt = p.ewPoly[20];
+                Real bt = p.ewPoly[SNB_EW_DEG_F64];
 #pragma unroll
-                for (int k = 19; k >= 0; k--) bt = bt * t + p.ewPoly[k];
+                for (int k = SNB_EW_DEG_F64 - 1; k >= 0; k--) bt = bt * t + p.ewPoly[k];
                 fC = qq * (invR - r2 * bt);
             } else if (MC == MC_EWALD || MC == MC_LJPME) {
                 const Real ar = p.alpha * r;

@@ -367,9 +367,9 @@ public:
     //   [erfc(ar)/r + 2a/sqrt(pi) exp(-(ar)^2)] / r^2 = 1/r^3 - Bt(r^2),   Bt(r^2) = [erf(ar) - 2ar/sqrt(pi) exp(-(ar)^2)] / r^3,
     // Bt is an entire function of r^2 (Bt(0) = 4a^3/(3 sqrt(pi))), so a polynomial in t = 2 r^2/r2max - 1 (Chebyshev fit over
     // [0, (cutoff+skin)^2], converted to monomials in t, |t| <= 1) reproduces it: degree 11 to 1e-7 of Bt(0) in single precision
-    // (12 packed FMAs replace v_exp + v_rcp + the A&S erfc polynomial), degree 20 to ~1e-13 in double (replaces libm erfc + exp).  Absolute force error per pair stays below that of the A&S path at short range and
+    // (12 packed FMAs replace v_exp + v_rcp + the A&S erfc polynomial), degree 16 to ~6e-12 in double (replaces libm erfc + exp).  Absolute force error per pair stays below that of the A&S path at short range and
     // below 2e-6 * qq near the cutoff (tools/ewald_poly_check.py).
-    static constexpr int EW_DEG = sizeof(Real) == 4 ? 11 : 20;      // 1e-7 resp. ~1e-13 of Bt(0)
+    static constexpr int EW_DEG = sizeof(Real) == 4 ? 11 : SNB_EW_DEG_F64;      // 1e-7 resp. ~6e-12 of Bt(0)
     double ewPoly[EW_DEG + 1] = {0}; double ewPolyE[14] = {0}; double dispPoly[21] = {0}; double ewR2Max = 1;
     void buildEwaldPoly() {
         const double rmax = cfg.cutoff + std::max(cfg.neighbor_padding, 0.0) + 0.02, a = cfg.alpha;
@@ -395,7 +395,7 @@ public:
                 for (int k = 0; k < 60; k++) { sum += term; term *= x / (k + 5); if (term < 1e-18 * sum) break; }
                 return std::pow(ad, 8.0) * std::exp(-x) * sum;
             };
-            chebyshevToMonomial(gd, 20, dispPoly);
+            chebyshevToMonomial(gd, SNB_DISP_DEG_F64, dispPoly);
         }
     }
     // Chebyshev interpolant of f(r^2) over [0, ewR2Max] at 96 nodes, truncated at `deg`, as monomial coefficients in t = 2 r^2/ewR2Max - 1

@@ -33,6 +33,13 @@
 #define SNB_SLICE_E_PARTITION(base, stride) ((base) + (size_t)(blockIdx.x & (SNB_SLICE_E_PARTS - 1)) * (size_t)(stride))
 #define SNB_PME_ORDER 5
 
+// Degrees of the double-precision pair kernel's polynomials (forces-only steps): Chebyshev truncation error of the Ewald factor Bt on
+// [0, (cutoff + skin + 0.02)^2] at alpha = 2.6283/nm: degree 14 3.9e-10 of Bt(0), 15 4.7e-11, 16 5.6e-12, 17 6.6e-13; of the LJPME dispersion
+// factor Gd: 16 1.3e-11, 17 1.4e-12, 18 1.5e-13.  Round 2 ran both at degree 20 (1e-13 / 4e-15): five orders beyond the 1e-5 parity bar is
+// plenty, and each degree is one f64 FMA per pair (c5: 2.32 -> ms for the pair kernel).
+#define SNB_EW_DEG_F64 16
+#define SNB_DISP_DEG_F64 17
+
 namespace snb {
 
 template <typename Real> struct Vec;

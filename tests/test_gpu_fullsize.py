@@ -31,7 +31,9 @@ TOL = {"single": 1e-3, "mixed": 1e-3, "double": 1e-5}
 # alone: 1.8e-7 rms of the spectrum, tools/fft_accuracy.py); neither the interpolation kernel nor the fused z pass changes it.  The
 # reference's single-precision platforms run the same arithmetic in float.  Measured: median 7.6e-6, 99.9 % of atoms below 1.3e-4, 9 atoms
 # above 5e-4, ONE above 1e-3.  That case is held to: 99.9 % of atoms within a FIFTH of the tolerance, every atom within 3e-3.
-MAX_TOL = {("c5", "mixed"): 3e-3}
+# (round 3: the own-atoms spreader sums the mesh in exact integers per point, one value per atomic; the worst atom now reads 8.4e-4, so the
+# allowance shrinks from 3e-3 to 1.5e-3 -- kept because 8.4e-4 sits close to the bar and the direct-space float atomics are order-dependent)
+MAX_TOL = {("c5", "mixed"): 1.5e-3}
 CASES = [("c2", "single"), ("c3", "single"), ("c4", "single"), ("c3", "mixed"), ("c3", "double"), ("c5", "double"), ("c5", "mixed")]
 
 
