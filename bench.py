@@ -587,7 +587,8 @@ def main():
         pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "%s_%s_pmc_hbm.json" % (tag, cfg_name))
         if os.path.exists(pmc_file) and world == 1:
             try:
-                rec = json.load(open(pmc_file))["k_direct_forces"]
+                allrec = json.load(open(pmc_file))
+                rec = allrec.get("k_direct_derivatives" if headline_deriv else "k_direct_forces") or allrec["k_direct_forces"]
                 out["roofline"]["traffic_from_profile"] = {"bytes_per_launch": int(rec["traffic_bytes_per_launch"]), "source": "profiles/" + os.path.basename(pmc_file) + ": " + rec["formula"],
                                                            "tiles_in_that_run": rec.get("tiles"), "measured_in_this_run": False}
             except Exception as exc:   # a malformed summary must not hide the measurement

@@ -109,6 +109,8 @@ typedef struct {
      * for the LJPME dispersion mesh (8 unused). */
     double  sum_kernel_ms[16];
     int64_t n_kernel_timed[16];
+    int64_t n_spread_strays;    /* atoms of the LAST execute whose spreading footprint had left their work-group's LDS region (drift beyond the
+                                 * margin since the last re-sort): handled one by one, exactly, by the merge kernel -- normally 0 */
 } snb_stats;
 #define SNB_K_GATHER 0
 #define SNB_K_SPREAD 1

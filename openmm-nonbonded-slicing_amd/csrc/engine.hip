@@ -527,7 +527,7 @@ public:
         gpuBuilt = false;
         if (cfg.host_neighbor_build || !gpuRebuild()) hostRebuild();
         pmeCells.resize(Npad);   // per-slot scratch is sized here: nothing may allocate while a step is being captured into a graph
-        if (isPme()) { dStrayCount.resize(2); planOwnSpread(pme); if (cfg.method == SNB_LJPME) planOwnSpread(dpme); }
+        if (isPme()) { if (!dStrayCount.p) { dStrayCount.resize(2); HIPCHECK(hipMemsetAsync(dStrayCount.p, 0, 2 * sizeof(int), stream)); } planOwnSpread(pme); if (cfg.method == SNB_LJPME) planOwnSpread(dpme); }
         posRef.resize(Npad);
         HIPCHECK(hipMemcpyAsync(posRef.p, posq.p, sizeof(T4) * (size_t)Npad, hipMemcpyDeviceToDevice, stream));
         if (hDispFlags[1]) listOverruns++;      // an atom had moved more than skin/2 before this rebuild came
@@ -1198,7 +1198,7 @@ public:
                 if (forced > 0 && k != forced) continue;
                 if (nz % k) continue;
                 const int sz = nz / k;
-                if (sz < 4 || (sz & 1) || (fixed && (sz & 3))) continue;      // (16-byte copies of the regions)
+                if (sz < 4 || (sz & 1)) continue;      // (8- or 16-byte copies of the regions)
                 if (accBytes * (size_t)RX * RY * (sz + 4) <= (size_t)(pass == 0 ? 40 : 64) * 1024) { best = k; break; }
             }
         if (!best) return;
@@ -1508,6 +1508,8 @@ public:
         stats.n_tiles = shardTiles; stats.n_blocks = numBlocks; stats.n_padded_atoms = Npad; stats.n_exclusion_tiles = numMaskTiles;
         for (int d = 0; d < 3; d++) { stats.grid[d] = isPme() ? pme.d.nx * (d == 0) + pme.d.ny * (d == 1) + pme.d.nz * (d == 2) : 0; stats.dgrid[d] = cfg.method == SNB_LJPME ? dpme.d.nx * (d == 0) + dpme.d.ny * (d == 1) + dpme.d.nz * (d == 2) : 0; }
         for (int k = 0; k < RING; k++) { EvSet& r = ring[(ringPos + k) % RING]; if (r.pending) harvest(r); }
+        stats.n_spread_strays = 0;
+        if (dStrayCount.p) { int h[2] = {0, 0}; HIPCHECK(hipMemcpy(h, dStrayCount.p, sizeof(h), hipMemcpyDeviceToHost)); stats.n_spread_strays = (int64_t)h[0] + h[1]; }
         *o = stats;
     }
     void getPme(double* alpha, int32_t* g, bool dispersion) override {

@@ -826,12 +826,19 @@ template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_sp
     if (tid == 0) p.ownBusy[blockIdx.x] = busy;
     if (!busy) return;
     Acc* out = reinterpret_cast<Acc*>(p.ownPartial) + (size_t)blockIdx.x * nlines * RZ;
-    // dense copy: a half-wave per line, 16 bytes per lane (RZ * sizeof(Acc) is a multiple of 16: sz even in fixed point)
-    constexpr int PER = 16 / sizeof(Acc);
-    const int q4 = RZ / PER, half = tid >> 5, hl = tid & 31;
-    for (int l = half; l < nlines; l += NT / 32)
-        for (int k = hl; k < q4; k += 32)
-            reinterpret_cast<int4*>(out + (size_t)l * RZ)[k] = reinterpret_cast<const int4*>(region + (size_t)l * RZP)[k];
+    // dense copy: a half-wave per line, 16 bytes per lane when a line is a whole number of them, else 8 (RZ is even: launcher)
+    const int half = tid >> 5, hl = tid & 31;
+    if ((RZ * sizeof(Acc)) % 16 == 0) {
+        const int q = (int)(RZ * sizeof(Acc) / 16);
+        for (int l = half; l < nlines; l += NT / 32)
+            for (int k = hl; k < q; k += 32)
+                reinterpret_cast<int4*>(out + (size_t)l * RZ)[k] = reinterpret_cast<const int4*>(region + (size_t)l * RZP)[k];
+    } else {
+        const int q = (int)(RZ * sizeof(Acc) / 8);
+        for (int l = half; l < nlines; l += NT / 32)
+            for (int k = hl; k < q; k += 32)
+                reinterpret_cast<int2*>(out + (size_t)l * RZ)[k] = reinterpret_cast<const int2*>(region + (size_t)l * RZP)[k];
+    }
 }
 
 // One work-group per brick: per z line of the brick, the sum of the regions of k_spreadOwn that cover it (the brick's own slabs, the
@@ -927,7 +934,8 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2> __global__ __la
                         if (chunk == CMAX) {
                             if constexpr (FIXED) { const int4 t = *reinterpret_cast<const int4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
                             else { const double2 t = *reinterpret_cast<const double2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
-                        } else v[u][0] = src[0];
+                        } else if (FIXED && chunk == 2) { const int2 t = *reinterpret_cast<const int2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
+                        else v[u][0] = src[0];
                     }
                 }
             }
@@ -1261,14 +1269,14 @@ template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hi
     static const bool noFixed = getenv("SNB_NO_FIXED_SPREAD") != nullptr;
     const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
     const int sz = p.d.nz / p.ownSlabs;
-    const bool fixed = std::is_same<Real, float>::value && !noFixed && sz % 4 == 0;      // (16-byte copies of 4-byte values)
-    if (!fixed && (sz & 1)) return -1;
+    if (sz & 1) return -1;      // (the regions are copied 8 or 16 bytes at a time)
+    const bool fixed = std::is_same<Real, float>::value && !noFixed;
     const int RX = cx + 4 + 2 * p.ownMargin, RY = cy + 4 + 2 * p.ownMargin, RZ = sz + 4;
     const size_t ldsOwn = (fixed ? sizeof(int) : sizeof(double)) * (size_t)RX * RY * (fixed ? ownLineStride<true>(RZ) : ownLineStride<false>(RZ));
     const int M = p.ownMargin;
     const int reachX = (4 + M + cx - 1) / cx + (M + cx - 1) / cx + 1, reachY = (4 + M + cy - 1) / cy + (M + cy - 1) / cy + 1;      // bricks whose regions cover a line
     if (ldsOwn > 64 * 1024 || RX > p.d.nx || RY > p.d.ny || p.groupX * p.groupY > 16 || reachX > 3 || reachY > 3 || p.ownSlabs > 32 || sz < 4) return -1;
-    const int cmax = fixed ? 4 : 2, chunk = (sz % cmax == 0) ? cmax : 1;      // values per load of the merge kernel
+    const int cmax = fixed ? 4 : 2, chunk = (sz % cmax == 0) ? cmax : ((fixed && sz % 2 == 0) ? 2 : 1);      // values per load of the merge kernel (16, 8 or 4 bytes)
     const int nbricks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
     const int nb = (cx * cy + 1) / 2;
     const size_t ldsFft = sizeof(Cx<Real>) * ((size_t)2 * p.d.nz * (nb + 1) + p.d.nz);

@@ -905,3 +905,62 @@ def test_derivative_only_step_rejects_an_energy_pointer(snb):
     st = eng.L.snb_set_exceptions(eng.h, m - 1, ip(w["exc_pairs"]), dp(w["exc_qq"]), dp(w["exc_sigma"]), dp(w["exc_eps"]), None)
     assert st == eng.capi.SNB_ERR_INVALID_ARGUMENT, st
     eng.close()
+
+
+_DRIFT_SCRIPT = r'''
+import sys, json
+import numpy as np, torch, importlib
+sys.path[:0] = [ROOT, ROOT + "/tests", ROOT + "/oracle"]
+import bench
+snb = importlib.import_module("openmm-nonbonded-slicing_amd")
+method, dgrid, prec = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+n = len(w["q"]); isd = prec == "double"; dt = torch.float64 if isd else torch.float32
+eng = bench.Engine(snb, w, method, 54, dgrid, prec, 0, 0, 1, 0.2, 1 << 30)      # skin 0.2 nm, never re-sorted after the first step
+rng = np.random.default_rng(3)
+out = {}
+pos = w["pos"].copy()
+forces = torch.zeros((n, 3), dtype=dt, device="cuda")
+for step in range(3):
+    if step:
+        # a jitter that keeps the molecules' geometry sane plus a common translation: 0.09 nm of drift in two steps, inside skin / 2,
+        # across mesh-cell and column borders for a third of the atoms
+        pos = pos + rng.uniform(-0.008, 0.008, pos.shape) + np.array([0.04, 0.035, 0.03])
+    pt = torch.tensor(pos, dtype=dt, device="cuda")
+    eng.set_positions_device(pt.data_ptr(), isd); eng.execute(True); eng.forces_to(forces.data_ptr(), isd); eng.sync()
+    w2 = dict(w); w2["pos"] = np.ascontiguousarray(pt.double().cpu().numpy())
+    fo, so, _, _ = bench.oracle_eval(w2, method, 54, dgrid)
+    f = forces.double().cpu().numpy(); se = eng.slice_energies(so.shape[0])
+    st = eng.stats()
+    out[step] = dict(ferr=float(np.max(np.linalg.norm(f - fo, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0))),
+                     eerr=float(np.max(np.abs(se - so) / np.maximum(np.abs(so), 1.0))), strays=int(st.n_spread_strays), rebuilds=int(st.n_rebuilds))
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("env,expect_strays", [({}, False), ({"SNB_SPREAD_MARGIN": "0"}, True), ({"SNB_SPREAD_MARGIN": "0", "SNB_NO_FUSED_Z": "1"}, True),
+                                               ({"SNB_NO_OWN_SPREAD": "1"}, False), ({"SNB_OWN_SLABS": "3"}, False)])
+@pytest.mark.parametrize("method,dgrid,prec", [(4, 0, "single"), (5, 27, "double")])
+def test_spreading_follows_drifting_atoms(env, expect_strays, method, dgrid, prec, snb):
+    """The own-atoms spreader (pme.hip k_spreadOwn / k_spreadMerge) lets a work-group handle only the atoms sorted into its columns, in an
+    LDS region with a drift margin; an atom that has left the region is a 'stray' and is added, exactly, by the merge kernel.  Atoms drift
+    for two steps without a re-sort; with the margin forced to zero (the engine reads its switches once per process: a child process) every
+    border crossing is a stray -- forces and slice energies must match the oracle either way, as they must with the scanning spreader
+    (SNB_NO_OWN_SPREAD), another slab count and the unfused merge."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _DRIFT_SCRIPT, str(method), str(dgrid), prec], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    tol = 1e-5 if prec == "double" else 1e-3
+    for step, rec in res.items():
+        assert rec["ferr"] < tol and rec["eerr"] < tol, (env, step, rec)
+        assert rec["rebuilds"] == 1
+    if expect_strays:
+        assert res["2"]["strays"] > 0, res
+    elif not env:
+        assert res["2"]["strays"] == 0, res

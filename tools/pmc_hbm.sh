@@ -5,7 +5,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_$c -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/${tag}_$c.log 2>&1 || exit 1
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_$c -- python3 bench.py --no-cpu-baseline --no-double "$@" > gpurun_out/${tag}_$c.log 2>&1 || exit 1
 done
 python3 - "$tag" <<'PY'
 import csv, glob, json, sys, collections
