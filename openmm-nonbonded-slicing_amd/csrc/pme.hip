@@ -603,9 +603,15 @@ __device__ __forceinline__ void fftPass2(const Cx<Real>* a, Cx<Real>* bOut, int 
     }
 }
 
+#ifndef SNB_FFT_120
+// the split of a 120-point line, measured on c3 (round 3, A/B through SNB_LIB_PATH): 8 x 15 (rounds 1-2) x kernel 53.2 us, inverse z 16.3,
+// merge + forward z 29.8, y pass 21.3; 10 x 12: 49.7 / 14.8 / 28.2 / 21.6 (the 15-point pass has only nb x 8 tasks for a work-group's 512
+// threads and the most registers); 12 x 10: y pass 28.1; 15 x 8: x kernel 85.4
+#define SNB_FFT_120(X) X(10, 12)
+#endif
 // The kernels are instantiated per (R1, R2) pair (inlining every radix into one runtime switch made them allocate 248 VGPRs);
 // sizes outside this list use the staged Stockham path (R1 = 0).
-#define SNB_FFT_PAIRS(X) X(6, 7) X(6, 9) X(8, 8) X(8, 10) X(9, 10) X(8, 12) X(10, 10) X(9, 12) X(8, 15) X(8, 16) X(12, 12) X(10, 16) X(12, 15) X(12, 16) X(15, 16) X(16, 16)
+#define SNB_FFT_PAIRS(X) X(6, 7) X(6, 9) X(8, 8) X(8, 10) X(9, 10) X(8, 12) X(10, 10) X(9, 12) SNB_FFT_120(X) X(8, 16) X(12, 12) X(10, 16) X(12, 15) X(12, 16) X(15, 16) X(16, 16)
 
 // Runs all stages; returns the buffer holding the result.  Caller must __syncthreads() before reading it.
 template <typename Real, int R1, int R2>
