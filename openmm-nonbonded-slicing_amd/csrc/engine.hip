@@ -1202,6 +1202,8 @@ public:
                 if (accBytes * (size_t)RX * RY * (sz + 4) <= (size_t)(pass == 0 ? 40 : 64) * 1024) { best = k; break; }
             }
         if (!best) return;
+        // few, wide bricks (coarse mesh, 2 x 2 columns per brick): more slabs until a grid has ~400 work-groups (c3l's 60^3 dispersion mesh: 100 bricks)
+        if (forced <= 0) for (int k = best + 1; k <= 16 && (ncx / gx) * (ncy / gy) * best < 400; k++) if (nz % k == 0 && (nz / k) >= 8 && !((nz / k) & 1)) best = k;
         const size_t nreg = (size_t)nGrids * (ncx / gx) * (ncy / gy) * best;
         plan.ownPartial.resize(nreg * RX * RY * (nz / best + 4) * accBytes);
         plan.ownBusy.resize(nreg); plan.strays.resize(std::max(Npad, 1));

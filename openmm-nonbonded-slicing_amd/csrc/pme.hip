@@ -1696,6 +1696,13 @@ template <typename Real> static bool launchInterpolateBricks(const PmeParams<Rea
         // a brick that does not fit LDS in one piece (double precision on a large mesh: 12 x 12 x 184 doubles = 212 KB for the 180^3 mesh of
         // c5) is cut into the fewest z slabs that do, rather than falling back to the 32-lanes-per-atom gather kernel (424 us there)
         if (zsEnv <= 0) for (int k = 2; k <= 8 && ldsFor(zSlabs) > 150 * 1024; k++) if (p.d.nz % k == 0 && p.d.nz / k >= 8) zSlabs = k;
+        // few, wide bricks (a coarse mesh whose bricks span 2 x 2 sort columns: the 60^3 dispersion mesh of c3l has 100 of them, 3000 atoms
+        // each, on 256 CUs: 58.8 us against 26.6 for the 120^3 Coulomb mesh): slabs buy work-groups; every slab rescans the bricks' atoms,
+        // which is why the fine mesh (400 bricks) does not take them
+        if (zsEnv <= 0 && zSlabs == 1) {
+            const int nb1 = (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
+            for (int k = 2; k <= 6 && nb1 * zSlabs < 192; k++) if (p.d.nz % k == 0 && p.d.nz / k >= 10) zSlabs = k;
+        }
         const size_t lds = ldsFor(zSlabs);
         static const bool noBrick = getenv("SNB_NO_INTERP_BRICKS") != nullptr;   // testing aid: force the 32-lanes-per-atom kernel
         if (lds <= 150 * 1024 && !noBrick && p.nsubTotal * p.groupX * p.groupY <= 256) {
