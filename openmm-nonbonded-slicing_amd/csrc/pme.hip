@@ -852,8 +852,8 @@ template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_sp
 // real lines per complex transform, written as the half-complex mesh; otherwise the real mesh.  One thread sums one 16-byte chunk of a
 // line: at most 3 x 3 bricks and 2 slabs cover it; per y neighbour the 6 (predicated) loads are issued back to back -- the first version
 // walked the candidates one dependent load at a time and took 101 us on c3.
-template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2> __global__ __launch_bounds__(256) void k_spreadMerge(const PmeParams<Real> p, const int chunk) {
-    constexpr int NT = 256;      // (a brick is ~18 complex lines: 512 threads left most of them idle in the FFT passes, and at the ~120 VGPRs of those passes 256-thread groups go four to a CU)
+template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_spreadMerge(const PmeParams<Real> p, const int chunk) {
+    // NT = 256      // (a brick is ~18 complex lines: 512 threads left most of them idle in the FFT passes, and at the ~120 VGPRs of those passes 256-thread groups go four to a CU)
     using Acc = typename std::conditional<FIXED, int, double>::type;
     constexpr int CMAX = FIXED ? 4 : 2;                                    // values per 16-byte load
     const int ncx = p.sortNcx, ncy = p.sortNcy, nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc;
@@ -1290,8 +1290,13 @@ template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hi
     const bool fuse = !noFuse && ldsFft <= 120 * 1024;
 #define SNB_OWN(FX) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadOwn<Real, FX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsOwn); \
                       SNB_STAMPED_LAUNCH(stampSlot(p, 1), (k_spreadOwn<Real, FX>), dim3(nbricks * p.ownSlabs), dim3(512), ldsOwn, s, p); }
-#define SNB_MERGE(FX, FZ, A, B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadMerge<Real, FX, FZ, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FZ ? ldsFft : 0)); \
-                                  SNB_STAMPED_LAUNCH(stampSlot(p, 2), (k_spreadMerge<Real, FX, FZ, A, B>), dim3(nbricks), dim3(256), (FZ ? ldsFft : 0), s, p, chunk); }
+    // a long mesh in double precision gives a 256-thread work-group a dozen 16-byte chunks per thread, each three rounds of dependent loads
+    // (c5, 180^3: 309 us): 512 threads there
+    const bool wideMerge = (size_t)cx * cy * (p.d.nz / chunk) > 6 * 256;
+#define SNB_MERGE(FX, FZ, A, B) { if (wideMerge) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadMerge<Real, FX, FZ, A, B, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FZ ? ldsFft : 0)); \
+                                      SNB_STAMPED_LAUNCH(stampSlot(p, 2), (k_spreadMerge<Real, FX, FZ, A, B, 512>), dim3(nbricks), dim3(512), (FZ ? ldsFft : 0), s, p, chunk); } \
+                                  else { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadMerge<Real, FX, FZ, A, B, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FZ ? ldsFft : 0)); \
+                                      SNB_STAMPED_LAUNCH(stampSlot(p, 2), (k_spreadMerge<Real, FX, FZ, A, B, 256>), dim3(nbricks), dim3(256), (FZ ? ldsFft : 0), s, p, chunk); } }
     bool done = false;
     if constexpr (std::is_same<Real, float>::value) {
         if (fixed) {
