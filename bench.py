@@ -147,8 +147,9 @@ CONFIGS = {
     "c3t": (300000, 14.42, 4, 4, 120, 0, "single"),      # c3 in a triclinic cell (shear_workload)
     "c3l": (300000, 14.42, 4, 5, 120, 60, "single"),     # c3 with LJPME (dispersion mesh 60^3)
 }
-# 1-GPU rates of this build on MI355X (bench.py --config <name>, round 2, random-walk coordinates), quoted beside N > 1 results of the same workload
-ONE_GPU_NS_DAY = {"c4": 256.6, "c3": 374.1, "c2": 900.3}
+# 1-GPU rates of this build on MI355X (bench.py --config <name>, round 3, random-walk coordinates, the step each config names: c3 with derivatives,
+# c4 / c2 forces only), quoted beside N > 1 results of the same workload
+ONE_GPU_NS_DAY = {"c4": 268.6, "c3": 365.0, "c2": 912.7}
 ALPHA = 2.6283
 CUTOFF = 1.0
 # configs whose BASELINE.json line names energy-parameter derivatives ("300k-atom solvated protein, 4 subsets with lambda_elec/lambda_vdW derivatives"):
