@@ -18,16 +18,27 @@ template <typename Real> __global__ __launch_bounds__(256) void k_ewaldSums(cons
     const Real kx = m.x * p.recipBox[0], ky = m.y * p.recipBox[1], kz = m.z * p.recipBox[2];
     for (int i = threadIdx.x; i < 2 * p.nsub; i += 256) s_sum[i] = 0.0;
     __syncthreads();
+    // the sorted order is subset-major, so a thread's atoms (stride 256) change subset a handful of times: the sums of the current subset
+    // stay in registers and reach LDS once per change (round 2 issued two ds_add_f64 per atom: 256 threads funnelled into 2 n addresses)
+    int cur = -1; double accC = 0.0, accS = 0.0;
+    auto flush = [&]() {
+        if (cur >= 0) {
+            __hip_atomic_fetch_add(&s_sum[cur], accC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_sum[p.nsub + cur], accS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        accC = 0.0; accS = 0.0;
+    };
     for (int a = threadIdx.x; a < p.natoms; a += 256) {
         const int s = p.atomSubset[a];
         if (s < 0) continue;
+        if (s != cur) { flush(); cur = s; }
         const auto v = p.posq[a];
         const Real ph = kx * v.x + ky * v.y + kz * v.z;
         Real sn, cs;
         sinCos(ph, &sn, &cs);
-        __hip_atomic_fetch_add(&s_sum[s], (double)(v.w * cs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&s_sum[p.nsub + s], (double)(v.w * sn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        accC += (double)(v.w * cs); accS += (double)(v.w * sn);
     }
+    flush();
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * p.nsub; i += 256) p.cosSin[(size_t)kv * 2 * p.nsub + i] = (Real)s_sum[i];
     if (p.wantEnergy && threadIdx.x == 0) {
