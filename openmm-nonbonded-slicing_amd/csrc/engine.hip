@@ -1009,6 +1009,7 @@ public:
         for (int d = 0; d < 3; d++) p.origin[d] = origin[d];
         for (int i = 0; i < 9; i++) tileCell[i] = box[i];
         p.listCutoff = (float)R;
+        { static const bool bw = getenv("SNB_NB_BOX_WALK") != nullptr; p.boxWalk = bw ? 1 : 0; }
         p.jumpDist = (float)(2.0 * std::sqrt(2.0) * std::max(box[0] / ncx, box[4] / ncy));   // neighbours along the sort path of a dense region are closer than this
         p.uSubset = dUSubset.p; p.uCharge = dUCharge.p; p.uSigEps = dUSigEps.p; p.uExclStart = exclStart.p; p.uExclList = exclList.p;
         p.slotOfSubset = dSlotOfSubset.p;

@@ -16,6 +16,7 @@ namespace snb {
 
 // Periodic cell in OpenMM's reduced form: a = (ax, 0, 0), b = (bx, by, 0), c = (cx, cy, cz), |bx| <= ax/2, |cx| <= ax/2, |cy| <= by/2.
 struct Lattice { float ax, bx, by, cx, cy, cz; };
+template <typename P> __device__ inline bool getenvBoxWalk(const P& p) { return p.boxWalk != 0; }      // SNB_NB_BOX_WALK=1: the round-2 candidate walk (test switch)
 template <typename Real> __device__ inline Lattice latticeOf(const NbParams<Real>& p) {
     return Lattice{(float)p.boxm[0], (float)p.boxm[3], (float)p.boxm[4], (float)p.boxm[6], (float)p.boxm[7], (float)p.boxm[8]};
 }
@@ -393,6 +394,7 @@ template <typename Real> __global__ __launch_bounds__(256, 4) void k_nbBuildTile
     const Lattice Lt = latticeOf(p);
     const float X0 = cxx - hx - R, X1 = cxx + hx + R, Y0 = cyy - hy - R, Y1 = cyy + hy + R, Z0 = czz - hz - R, Z1 = czz + hz + R;
     const float feps = 1e-5f;                             // fractional slack for float-vs-double rounding of column / bucket borders
+    const bool rectCell = Lt.bx == 0.f && Lt.cx == 0.f && Lt.cy == 0.f && !getenvBoxWalk(p);
     // The lattice images that can reach the grown box, with their column rectangles and fractional z ranges: geometry only, so it is
     // worked out once per block and reused for every j-subset (typically 1-4 of the 27 images survive).
     int (*imgI)[5] = s_imgI[wid]; float (*imgF)[2] = s_imgF[wid];
@@ -543,11 +545,29 @@ template <typename Real> __global__ __launch_bounds__(256, 4) void k_nbBuildTile
                     if (rg.y > rg.x) {
                         const int serp = ccx * p.ncy + ((ccx & 1) ? (p.ncy - 1 - ccy) : ccy);
                         float fa = fz0, fb = fz1;
+                        if (rectCell) {
+                            // (round 3) the grown BOX reaches a column rectangle at xy distance d only over |z - box| < sqrt(R^2 - d^2): the columns at
+                            // the corners of the rectangle range get a short z interval or none (the box walk tested a third more candidates)
+                            const int kx = code % 3 - 1, ky = (code / 3) % 3 - 1, kz = code / 9 - 1;
+                            const float wx = Lt.ax / p.ncx, wy = Lt.by / p.ncy, slack = 1e-5f * (Lt.ax + Lt.by);
+                            const float xlo = ccx * wx + kx * Lt.ax - slack, xhi = (ccx + 1) * wx + kx * Lt.ax + slack;
+                            const float ylo = ccy * wy + ky * Lt.by - slack, yhi = (ccy + 1) * wy + ky * Lt.by + slack;
+                            float ddx = fmaxf(0.f, fmaxf(xlo - (cxx + hx), (cxx - hx) - xhi)), ddy = fmaxf(0.f, fmaxf(ylo - (cyy + hy), (cyy - hy) - yhi));
+                            const float rz2 = R2 - ddx * ddx - ddy * ddy;
+                            if (rz2 <= 0.f) { fa = 1.f; fb = 0.f; }
+                            else {
+                                const float rz = sqrtf(rz2) * 1.0001f;
+                                const float za = (czz - hz - rz - kz * Lt.cz) / Lt.cz - feps, zb = (czz + hz + rz - kz * Lt.cz) / Lt.cz + feps;
+                                fa = fmaxf(fa, za); fb = fminf(fb, zb);
+                            }
+                        }
+                        if (fb > fa) {
                         if (serp & 1) { const float t = 1.f - fb; fb = 1.f - fa; fa = t; }
                         int blo = ((int)(fa * 1048575.0f) >> 14) - 1, bhi = ((int)(fb * 1048575.0f) >> 14) + 1;   // one bucket of slack for float rounding
                         blo = blo < 0 ? 0 : blo; bhi = bhi > 63 ? 63 : bhi;
                         const int* zi = zIndex + (size_t)col * 65;
                         cStart = zi[blo]; cLen = zi[bhi + 1] - zi[blo];      // an interval of the sorted padded order
+                        }
                     }
                 }
                 const unsigned long long mq = __ballot(cLen > 0);

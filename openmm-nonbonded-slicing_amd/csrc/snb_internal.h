@@ -182,6 +182,7 @@ template <typename Real> struct NbParams {
     double boxm[9];  // periodic cell, rows a, b, c in OpenMM's reduced (lower-triangular) form
     double origin[3];  // subtracted from the user positions before wrapping (the enclosing cell of a non-periodic system; else 0)
     float listCutoff;
+    int boxWalk;     // test switch (SNB_NB_BOX_WALK): candidate runs from the grown box alone, without the per-column z ranges of round 3
     float jumpDist;  // consecutive sorted atoms further apart than this start a new (padded) block segment
     // static, user order
     const int* uSubset; const Real* uCharge; const typename Vec<Real>::T2* uSigEps;
