@@ -607,17 +607,9 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         // rotate-then-subtract leaves lane c holding slot (c+1)&7: one more rotation brings every slot home, then the two
         // partial sums of a slot (lanes c and c+8) are merged
         const int curCode = st.code;
-        if (HALF) {
-            // every lane owns the slot it staged.  The two tiles' slots alternate along the row (even lanes: lower half's tile, odd lanes: upper's);
-            // scattered in that order the atomics are not merged into sectors at all -- the coalescer wants consecutive lanes on consecutive
-            // addresses: 0.40 ms against 0.18 with the scatter switched off -- so the row is un-zipped first (lanes 0-7: one tile's slots 0-7,
-            // lanes 8-15: the other's), four ds_bpermute per trip
-            const int src = ((lane & 48) | (c < 8 ? 2 * c : 2 * (c - 8) + 1)) << 2;
-            pendX = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, rowRor2(fjx))));
-            pendY = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, rowRor2(fjy))));
-            pendZ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, rowRor2(fjz))));
-            const int code2 = __builtin_amdgcn_ds_bpermute(src, curCode);
-            pendIdx = code2 != -1 ? (code2 & SNB_JIDX_MASK) : -1;
+        if (HALF) {      // every lane owns the slot it staged
+            pendX = rowRor2(fjx); pendY = rowRor2(fjy); pendZ = rowRor2(fjz);
+            pendIdx = curCode != -1 ? (curCode & SNB_JIDX_MASK) : -1;
         } else {
             fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
             pendX = fjx + rowRor8(fjx); pendY = fjy + rowRor8(fjy); pendZ = fjz + rowRor8(fjz);
