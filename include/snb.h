@@ -109,8 +109,6 @@ typedef struct {
      * for the LJPME dispersion mesh (8 unused). */
     double  sum_kernel_ms[16];
     int64_t n_kernel_timed[16];
-    int64_t tile_i_atoms;       /* rows of a tile in n_tiles: 32 (block x 32 gathered j-atoms), or 16 -- half tiles: the single-precision pair kernel gives
-                                 * the lower and the upper 16 atoms of a block j-lists of their own; n_tiles then counts half tiles (512 pair slots each) */
     int64_t n_spread_strays;    /* atoms of the LAST execute whose spreading footprint had left their work-group's LDS region (drift beyond the
                                  * margin since the last re-sort): handled one by one, exactly, by the merge kernel -- normally 0 */
 } snb_stats;

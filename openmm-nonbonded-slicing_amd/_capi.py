@@ -43,7 +43,7 @@ class SnbStats(ctypes.Structure):
         ("dgrid", ctypes.c_int32 * 3), ("last_direct_ms", ctypes.c_double), ("last_recip_ms", ctypes.c_double),
         ("last_total_ms", ctypes.c_double), ("last_rebuild_ms", ctypes.c_double), ("sum_direct_ms", ctypes.c_double),
         ("sum_recip_ms", ctypes.c_double), ("sum_total_ms", ctypes.c_double), ("n_timed", ctypes.c_int64), ("n_host_rebuilds", ctypes.c_int64), ("n_list_overruns", ctypes.c_int64),
-        ("sum_kernel_ms", ctypes.c_double * 16), ("n_kernel_timed", ctypes.c_int64 * 16), ("tile_i_atoms", ctypes.c_int64), ("n_spread_strays", ctypes.c_int64),
+        ("sum_kernel_ms", ctypes.c_double * 16), ("n_kernel_timed", ctypes.c_int64 * 16), ("n_spread_strays", ctypes.c_int64),
     ]
 KERNEL_SLOTS = ("gather", "spread", "fft_z_forward", "fft_y_forward", "convolve_x", "fft_y_inverse", "fft_z_inverse", "interpolate")
 

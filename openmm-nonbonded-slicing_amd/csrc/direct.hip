@@ -19,9 +19,6 @@
 #include <cstring>
 #include <type_traits>
 
-#ifndef SNB_EXP_NO_JATOMICS
-#define SNB_EXP_NO_JATOMICS 0      // timing experiment (-DSNB_EXP_NO_JATOMICS=1): the j-force scatter of the packed kernel switched off -- wrong forces
-#endif
 #ifndef SNB_DIRECT_F64_WAVES
 #define SNB_DIRECT_F64_WAVES 2      // waves per SIMD the double-precision pair kernel is compiled for (256 VGPRs: no spills; measured on c5)
 #endif
@@ -217,7 +214,6 @@ __device__ __forceinline__ void tileSteps(const DirectParams<Real>& p, const typ
 // cost the same either way).  8 steps; at step s lane c meets slots (c-2s) [component .x] and (c-2s-1) [component .y];
 // each component's j-force accumulator follows its slot with a two-lane DPP rotation per step.
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ inline float rowRor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true)); }
 __device__ inline float rowRor8(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); }
 
 // ---- the tile kernel ----------------------------------------------------------------------------
@@ -362,7 +358,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
 // energy of the method (Ewald: qq erfc(ar)/r with the A&S erfc) -- from the
 // RAW i-parameters qiRaw / epsiRaw, while the forces keep using the lambda-scaled ones.  This is the kernel of every step of a force
 // that asks for energy-parameter derivatives (the reference accumulates them whether or not the energy is requested, Q4).
-template <int MC, bool MASKED, bool POLY, bool ENERGY, bool SWITCH, bool HALF>
+template <int MC, bool MASKED, bool POLY, bool ENERGY, bool SWITCH>
 __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, const float4* rdPos, const float2* rdSe, const v2f pix, const v2f piy, const v2f piz,
                                                 const v2f sigi, const v2f qiS, const v2f epsiS, const v2f qiRaw, const v2f epsiRaw, const v2f c6iRaw, const float lamL, const unsigned maskA, const unsigned maskB, const int c,
                                                 v2f& fix, v2f& fiy, v2f& fiz, float& fjx, float& fjy, float& fjz, v2f& ecl, v2f& elj) {
@@ -462,10 +458,7 @@ __device__ __forceinline__ void tileStepsPacked(const DirectParams<float>& p, co
         }
         const v2f gx = f * dx, gy = f * dy, gz = f * dz;
         fix = fix + gx; fiy = fiy + gy; fiz = fiz + gz;
-        // (half tiles: even lanes of a row belong to the block's lower 16 atoms and their own j-tile, odd lanes to the upper 16 and theirs; a
-        // rotation by two lanes keeps every accumulator inside its half)
-        if (HALF) { fjx = rowRor2(fjx) - (gx.x + gx.y); fjy = rowRor2(fjy) - (gy.x + gy.y); fjz = rowRor2(fjz) - (gz.x + gz.y); }
-        else { fjx = rowRor1(fjx) - (gx.x + gx.y); fjy = rowRor1(fjy) - (gy.x + gy.y); fjz = rowRor1(fjz) - (gz.x + gz.y); }
+        fjx = rowRor1(fjx) - (gx.x + gx.y); fjy = rowRor1(fjy) - (gy.x + gy.y); fjz = rowRor1(fjz) - (gz.x + gz.y);
     }
 }
 
@@ -474,12 +467,7 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
 
 // The first nListBlocks work-groups of the launch run the O(N) pair lists (exclusion corrections, then 1-4 exceptions: latency-bound
 // work that overlaps the VALU-bound tile work instead of trailing it as a launch of its own); the others loop over tile work items.
-// HALF (round 3): the tile list holds HALF TILES -- the block's lower 16 atoms (sorted order) x 32 j-atoms gathered for THEM, then the upper
-// 16 x theirs, in consecutive list slots (a pair; same j-subset, padded to the same count).  17 % of a block's j-atoms are within the
-// list radius of one half only (tools/sim_split.py), so the two lists together hold 0.83 of the block list's pair slots.  Lane (row r,
-// column c): half h = c & 1, slot index q = c >> 1; it holds i-atoms 16 h + q and 16 h + q + 8 and meets slot 8 r + ((q - s) & 7) of tile
-// t + h.  Every lane scatters the j-force of its own slot (no merge across halves: the halves see different atoms).
-template <int MC, bool POLY, bool ENERGY, bool SWITCH, bool FIXED, bool HALF>
+template <int MC, bool POLY, bool ENERGY, bool SWITCH, bool FIXED>
 __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<float> p, const PairListParams<float> q, const int nExclBlocks, const int nListBlocks) {
     if ((int)blockIdx.x < nListBlocks) {      // (energy steps: the list bodies reduce their slice energies in 2 S doubles of dynamic LDS)
         if ((int)blockIdx.x < nExclBlocks) { PairListParams<float> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<float, ENERGY>(qe, blockIdx.x); }
@@ -488,8 +476,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     }
     const int tileBlock = blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
     double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
-    __shared__ float4 s_pos[4][HALF ? 192 : 64];
-    __shared__ float2 s_se[4][HALF ? 192 : 64];
+    __shared__ float4 s_pos[4][64];
+    __shared__ float2 s_se[4][64];
     __shared__ float4 s_shift[128];      // lattice-image shift of every 7-bit image code (125 in use): + ka a + kb b + kc c (rows of p.box)
     if (threadIdx.x < 128) {
         const int sc = threadIdx.x;
@@ -505,13 +493,10 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     const int I = __builtin_amdgcn_readfirstlane(wi.x);
     const int tBegin = __builtin_amdgcn_readfirstlane(wi.y), tEnd = tBegin + __builtin_amdgcn_readfirstlane(wi.z);
     const int c = lane & 15, row = lane >> 4;
-    const int hh = HALF ? (c & 1) : 0, q8 = HALF ? (c >> 1) : (c & 7);      // my half of the block (half tiles) and my slot index at step 0
-    const int stride = HALF ? 2 : 1;                     // list slots per trip (a pair of half tiles)
-    const int stageJ = 8 * row + q8;                     // j-atom this lane stages (slot q8 of quarter `row` of ITS tile)
-    const int a0 = HALF ? 16 * hh + q8 : c, a1 = HALF ? a0 + 8 : c + 16;      // my two i-atoms
+    const int stageJ = 8 * row + (c & 7);                // j-atom this lane stages (entry c of quarter `row`)
 
-    const float4 pa = p.posq[I * 32 + a0], pb = p.posq[I * 32 + a1];
-    const float2 sa = p.sigeps[I * 32 + a0], sb = p.sigeps[I * 32 + a1];
+    const float4 pa = p.posq[I * 32 + c], pb = p.posq[I * 32 + 16 + c];
+    const float2 sa = p.sigeps[I * 32 + c], sb = p.sigeps[I * 32 + 16 + c];
     const v2f pix = {pa.x, pb.x}, piy = {pa.y, pb.y}, piz = {pa.z, pb.z};
     const v2f qi = {pa.w * p.k4pe, pb.w * p.k4pe}, sigi = {sa.x, sb.x}, epsi = {sa.y, sb.y};
     v2f fix = {0.f, 0.f}, fiy = {0.f, 0.f}, fiz = {0.f, 0.f};
@@ -528,11 +513,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
 
     float4* myPos = s_pos[wid];
     float2* mySe = s_se[wid];
-    // (each octet is stored twice so that the rotated index needs no wrap.  Half tiles: 48 entries per row and 24 per half put the two halves
-    // of a row on complementary LDS bank halves: four passes per 1-KB read, the minimum)
-    const int rdBase = HALF ? 48 * row + 24 * hh + q8 : 16 * row + q8;
-    const float4* rdPos = myPos + rdBase + 8;   // entry for step s is rdPos[-s]
-    const float2* rdSe = mySe + rdBase + 8;
+    const float4* rdPos = myPos + 16 * row + (c & 7) + 8;   // entry for step s is rdPos[-s]
+    const float2* rdSe = mySe + 16 * row + (c & 7) + 8;
 
     // two-tile-deep software pipeline, as in k_direct
     // Software pipeline over the item's tiles with TWO register sets used alternately (the tile loop is unrolled by two).  While tile t
@@ -549,8 +531,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     float pendX = 0.f, pendY = 0.f, pendZ = 0.f; int pendIdx = -1;
     auto flushPending = [&]() { if (pendIdx >= 0) { fAddT<FIXED>(p, p.fx, pendIdx, pendX); fAddT<FIXED>(p, p.fy, pendIdx, pendY); fAddT<FIXED>(p, p.fz, pendIdx, pendZ); } };
     auto requestList = [&](TileRegs& r, int t) {                    // list entry + header of tile t
-        r.jcode = p.tileJ[(t + hh) * 32 + stageJ];
-        const int2 v = *reinterpret_cast<const int2*>(&p.tileInfo[t + hh + vzero]);
+        r.jcode = p.tileJ[t * 32 + stageJ];
+        const int2 v = *reinterpret_cast<const int2*>(&p.tileInfo[t + vzero]);
         r.slice = v.x; r.maskIdx = v.y;
     };
     auto requestAtoms = [&](TileRegs& r) {                          // needs r.jcode / r.slice / r.maskIdx (requested a tile earlier)
@@ -562,7 +544,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         const float4 sh = s_shift[(code >> SNB_JSHIFT_BITS) & 127];      // lattice image of the entry (table filled at kernel start)
         r.shx = sh.x; r.shy = sh.y; r.shz = sh.z;
         const int mi = r.maskIdx < 0 ? 0 : r.maskIdx;              // unconditional loads: a conditionally loaded register is a phi with a copy
-        r.mA = p.masks[mi * 32 + a0]; r.mB = p.masks[mi * 32 + a1];
+        r.mA = p.masks[mi * 32 + c]; r.mB = p.masks[mi * 32 + 16 + c];
         r.lam = *reinterpret_cast<const float2*>(&p.lambdas[2 * (r.slice & 0xFFFF)]);      // (the slice index comes with the tile header, written by the builder)
         if (ENERGY) r.need = p.sliceNeed[r.slice & 0xFFFF];      // energy steps: is this slice's energy wanted?
     };
@@ -572,16 +554,10 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         Staged st;
         __builtin_amdgcn_wave_barrier();
         st.code = R.jcode;
-        {
-            float4 sp; float2 ss;
-            if (st.code != -1) { sp = make_float4(R.pj.x + R.shx, R.pj.y + R.shy, R.pj.z + R.shz, R.pj.w); ss = R.sej; }
-            else { sp = make_float4(3e9f + 1e6f * c, -5e9f, 7e9f, 0.f); ss = make_float2(0.f, 0.f); }      // padding slot: parked far away
-            if (HALF) { myPos[rdBase] = sp; myPos[rdBase + 8] = sp; mySe[rdBase] = ss; mySe[rdBase + 8] = ss; }      // (a lane stages ITS tile's atom, both copies)
-            else { myPos[lane] = sp; mySe[lane] = ss; }
-        }
-        const bool myMask = R.maskIdx >= 0;
-        st.hasMask = HALF ? (__ballot(myMask) != 0ull) : myMask;      // (half tiles: the two tiles of a pair carry their own masks)
-        st.maskA = myMask ? R.mA >> (8 * row) : 0u; st.maskB = myMask ? R.mB >> (8 * row) : 0u;   // my j-quarter's 8 bits
+        if (st.code != -1) { myPos[lane] = make_float4(R.pj.x + R.shx, R.pj.y + R.shy, R.pj.z + R.shz, R.pj.w); mySe[lane] = R.sej; }
+        else { myPos[lane] = make_float4(3e9f + 1e6f * c, -5e9f, 7e9f, 0.f); mySe[lane] = make_float2(0.f, 0.f); }      // padding slot: parked far away
+        st.hasMask = R.maskIdx >= 0;
+        st.maskA = st.hasMask ? R.mA >> (8 * row) : 0u; st.maskB = st.hasMask ? R.mB >> (8 * row) : 0u;   // my j-quarter's 8 bits
         st.lamC = R.lam.x; st.lamL = R.lam.y;
         st.slice = R.slice & 0xFFFF;
         st.needE = ENERGY && __builtin_amdgcn_readfirstlane(R.need) != 0;
@@ -595,37 +571,31 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     // the atomics in flight.
     auto tile = [&](TileRegs& X, TileRegs& Y, const int t, Staged& st) {
         requestAtoms(Y);      // (issues the previous tile's j-force atomics first)
-        requestList(X, t + 2 * stride < tEnd ? t + 2 * stride : tEnd - stride);
+        requestList(X, t + 2 < tEnd ? t + 2 : tEnd - 1);
         // (the sums of a slice nobody asked for are zero: no wave reduction, no atomics -- on derivative steps 95 % of the slice changes)
         if (ENERGY && st.slice != curSlice) { if (curNeeded) flushEnergy(); curSlice = st.slice; curNeeded = st.needE; }
         const v2f qiS = qi * st.lamC, epsiS = epsi * st.lamL;      // lambda folded into the i-side parameters once per tile
         float fjx = 0, fjy = 0, fjz = 0;
-#define SNB_TILE_PACKED(M, E) tileStepsPacked<MC, M, POLY, E, SWITCH, HALF>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, st.lamL, st.maskA, st.maskB, q8, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj)
+#define SNB_TILE_PACKED(M, E) tileStepsPacked<MC, M, POLY, E, SWITCH>(p, rdPos, rdSe, pix, piy, piz, sigi, qiS, epsiS, qi, epsi, c6i, st.lamL, st.maskA, st.maskB, c, fix, fiy, fiz, fjx, fjy, fjz, ecl, elj)
         if (ENERGY && st.needE) { if (st.hasMask) SNB_TILE_PACKED(true, ENERGY); else SNB_TILE_PACKED(false, ENERGY); }
         else { if (st.hasMask) SNB_TILE_PACKED(true, false); else SNB_TILE_PACKED(false, false); }      // forces only (also: energy steps, slice not wanted)
 #undef SNB_TILE_PACKED
         // rotate-then-subtract leaves lane c holding slot (c+1)&7: one more rotation brings every slot home, then the two
         // partial sums of a slot (lanes c and c+8) are merged
+        fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
+        pendX = fjx + rowRor8(fjx); pendY = fjy + rowRor8(fjy); pendZ = fjz + rowRor8(fjz);
         const int curCode = st.code;
-        if (HALF) {      // every lane owns the slot it staged
-            pendX = rowRor2(fjx); pendY = rowRor2(fjy); pendZ = rowRor2(fjz);
-            pendIdx = curCode != -1 ? (curCode & SNB_JIDX_MASK) : -1;
-        } else {
-            fjx = rowRor1(fjx); fjy = rowRor1(fjy); fjz = rowRor1(fjz);
-            pendX = fjx + rowRor8(fjx); pendY = fjy + rowRor8(fjy); pendZ = fjz + rowRor8(fjz);
-            pendIdx = (c < 8 && curCode != -1) ? (curCode & SNB_JIDX_MASK) : -1;      // entry c < 8 of quarter `row` == j-slot 8*row + c == the atom this lane staged
-        }
-        if (SNB_EXP_NO_JATOMICS) pendIdx = -1;
+        pendIdx = (c < 8 && curCode != -1) ? (curCode & SNB_JIDX_MASK) : -1;      // entry c < 8 of quarter `row` == j-slot 8*row + c == the atom this lane staged
         st = stage(Y);
     };
     requestList(A, tBegin);
     B = A;
-    requestList(B, tBegin + stride < tEnd ? tBegin + stride : tBegin);
+    requestList(B, tBegin + 1 < tEnd ? tBegin + 1 : tBegin);
     requestAtoms(A);
     Staged st = stage(A);
-    for (int t = tBegin; t < tEnd; t += 2 * stride) {
+    for (int t = tBegin; t < tEnd; t += 2) {
         tile(A, B, t, st);
-        if (t + stride < tEnd) tile(B, A, t + stride, st);
+        if (t + 1 < tEnd) tile(B, A, t + 1, st);
     }
     flushPending();
     // the four rows hold partial sums for the same i-atoms (different j-quarters)
@@ -634,8 +604,8 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     ux += __shfl_xor(ux, 16, 64); uy += __shfl_xor(uy, 16, 64); uz += __shfl_xor(uz, 16, 64);
     ox += __shfl_xor(ox, 32, 64); oy += __shfl_xor(oy, 32, 64); oz += __shfl_xor(oz, 32, 64);
     ux += __shfl_xor(ux, 32, 64); uy += __shfl_xor(uy, 32, 64); uz += __shfl_xor(uz, 32, 64);
-    if (row == 0) { fAddT<FIXED>(p, p.fx, (I * 32 + a0), ox); fAddT<FIXED>(p, p.fy, (I * 32 + a0), oy); fAddT<FIXED>(p, p.fz, (I * 32 + a0), oz); }
-    if (row == 1) { fAddT<FIXED>(p, p.fx, (I * 32 + a1), ux); fAddT<FIXED>(p, p.fy, (I * 32 + a1), uy); fAddT<FIXED>(p, p.fz, (I * 32 + a1), uz); }
+    if (row == 0) { fAddT<FIXED>(p, p.fx, (I * 32 + c), ox); fAddT<FIXED>(p, p.fy, (I * 32 + c), oy); fAddT<FIXED>(p, p.fz, (I * 32 + c), oz); }
+    if (row == 1) { fAddT<FIXED>(p, p.fx, (I * 32 + 16 + c), ux); fAddT<FIXED>(p, p.fy, (I * 32 + 16 + c), uy); fAddT<FIXED>(p, p.fz, (I * 32 + 16 + c), uz); }
     if (ENERGY) { if (curNeeded) flushEnergy(); curSlice = -1; curNeeded = false; }
     __builtin_amdgcn_wave_barrier();
     }   // work-item loop
@@ -663,10 +633,8 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
             const size_t listLds = (lists && energy) ? sizeof(double) * 2 * q.nSlices : 0;      // the energy list bodies reduce per slice in LDS
             dim3 gridAll(nwg + nListBlocks);
             const bool poly = (MC == MC_EWALD || MC == MC_LJPME) && p.ewUsePoly;
-#define SNB_PACKED(P, E, S) do { if (p.halfTiles) { if (p.fixed) SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S, true, true>), gridAll, listLds, p, q, nExclBlocks, nListBlocks); \
-                                                    else SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S, false, true>), gridAll, listLds, p, q, nExclBlocks, nListBlocks); } \
-                                 else { if (p.fixed) SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S, true, false>), gridAll, listLds, p, q, nExclBlocks, nListBlocks); \
-                                        else SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S, false, false>), gridAll, listLds, p, q, nExclBlocks, nListBlocks); } } while (0)
+#define SNB_PACKED(P, E, S) do { if (p.fixed) SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S, true>), gridAll, listLds, p, q, nExclBlocks, nListBlocks); \
+                                 else SNB_LAUNCH_LDS((k_directPacked<MC, P, E, S, false>), gridAll, listLds, p, q, nExclBlocks, nListBlocks); } while (0)
             if constexpr (MC == MC_NOCUTOFF) { if (energy) SNB_PACKED(false, true, false); else SNB_PACKED(false, false, false); }
             else if (p.useSwitch && MC != MC_LJPME) {      // (no switching function under LJPME, Q2)
                 if (energy) { if (poly) SNB_PACKED(true, true, true); else SNB_PACKED(false, true, true); }

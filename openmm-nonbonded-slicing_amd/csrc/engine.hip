@@ -234,14 +234,6 @@ public:
     DevBuf<unsigned char> ownedPos;
     // sorted state
     int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0, shardTiles = 0; bool wrapMode = false;
-    // Half tiles (round 3): the packed pair kernel's list format -- pairs of (16 i-atoms x 32 j-atoms) tiles, the block's lower and upper half
-    // with j-lists of their own (direct.hip k_directPacked<HALF>, neighbor.hip k_nbBuildTiles<HALF>).  Engines whose steps can reach the
-    // scalar kernel k_direct (double precision, per-pair wrapping, the test switch SNB_SCALAR_ENERGY_KERNEL, switch + NoCutoff) keep 32 x 32 tiles.
-    bool listsHalf = false;
-    bool wantHalfTiles() const {
-        static const bool off = getenv("SNB_NO_HALF_TILES") != nullptr, scalarEnergy = getenv("SNB_SCALAR_ENERGY_KERNEL") != nullptr;
-        return sizeof(Real) == 4 && !off && !scalarEnergy && !(cfg.use_switch && cfg.method == SNB_NoCutoff);
-    }
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
     struct FView { Real* p = nullptr; } fx, fy, fz, fpx, fpy, fpz;   // views of forceBuf (7 Npad values, cleared by the position-gather pass)
@@ -814,17 +806,6 @@ public:
             hBlockTiles[I] = make_int2(firstTile, (int)hTileInfo.size() - firstTile);
             if (emptyBlock) { hBlockTiles[I].y = 0; }
         }
-        // half-tile format from 32 x 32 tiles: every tile twice, in consecutive slots -- the lower half's copy and the upper half's (same j-atoms,
-        // same mask words: a half reads its own 16 rows), i.e. the same pair slots as before; only the GPU builder gives the halves lists of their own
-        listsHalf = wantHalfTiles() && !wrapMode;
-        if (listsHalf) {
-            std::vector<int> j2(hTileJ.size() * 2); std::vector<int4> i2(hTileInfo.size() * 2);
-            for (size_t t = 0; t < hTileInfo.size(); t++) {
-                for (int h = 0; h < 2; h++) { std::copy(hTileJ.begin() + t * 32, hTileJ.begin() + (t + 1) * 32, j2.begin() + (2 * t + h) * 32); i2[2 * t + h] = hTileInfo[t]; }
-            }
-            hTileJ.swap(j2); hTileInfo.swap(i2);
-            for (auto& bt : hBlockTiles) { bt.x *= 2; bt.y *= 2; }
-        }
         numTiles = (int64_t)hTileInfo.size();
         // work items: runs of <= 8 tiles of one i-block (fine grain => several rounds of waves per CU, small tail)
         std::vector<int4> hWork;
@@ -1091,7 +1072,6 @@ public:
             p.shardBegin = shardBegin; p.shardWidth = shardEnd - shardBegin; p.shardPeriod = shardPeriod;
             { static const bool boxOnly = getenv("SNB_BOX_PRUNE") != nullptr; p.exactPrune = boxOnly ? 0 : 1; }
             { static const int it = getenv("SNB_ITEM_TILES") ? std::max(1, std::min(32, atoi(getenv("SNB_ITEM_TILES")))) : 8; p.itemTiles = it; }
-            p.halfLists = wantHalfTiles() ? 1 : 0;
             p.blockCenter = dBlockCenter.p; p.blockHalf = dBlockHalf.p;
             p.sortedToUser = dSortedToUser.p; p.userToSorted = dUserToSorted.p; p.posq = posq.p; p.sigeps = sigeps.p; p.imageOffset = imageOffset.p;
             p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p; p.colRange = colRange.p; p.zIndex = dZIndex.p;
@@ -1123,7 +1103,7 @@ public:
                 fprintf(stderr, "[snb] nb trace: last block start %.1f us after the first\n", lastStart / 100.0);
             }
             if (h[3] == 0) {
-                numTiles = h[0]; numWorkItems = h[1] + h[4]; numMaskTiles = h[2]; wrapMode = false; listsHalf = p.halfLists != 0;
+                numTiles = h[0]; numWorkItems = h[1] + h[4]; numMaskTiles = h[2]; wrapMode = false;
                 if (getenv("SNB_DEBUG_WORK")) {      // consistency of the work list: the items must cover every tile exactly once
                     std::vector<int4> hw(numWorkItems);
                     HIPCHECK(hipMemcpy(hw.data(), workItems.p, sizeof(int4) * numWorkItems, hipMemcpyDeviceToHost));
@@ -1392,7 +1372,6 @@ public:
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.fx = fx.p; p.fy = fy.p; p.fz = fz.p; p.fs = fstride; p.fixed = fixedForces(); p.sliceE = sliceE.p; p.lambdas = dLambdas.p; p.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p;
             const int r = cfg.shard_rank, c = cfg.shard_count;
             (void)r; (void)c;
-            p.halfTiles = listsHalf ? 1 : 0;
             p.workStart = 0; p.workStride = 1; p.numWork = numWorkItems;      // the lists hold only the i-blocks this engine owns (block % shard_count == shard_rank)
             p.nsub = nsub;
             p.cutoff2 = (Real)(cfg.cutoff * cfg.cutoff);
@@ -1533,7 +1512,6 @@ public:
         stats.n_tiles = 0;
         // tiles processed by this shard
         stats.n_list_overruns = listOverruns + (hDispFlags && hDispFlags[1] ? 1 : 0);
-        stats.tile_i_atoms = listsHalf ? 16 : 32;
         stats.n_tiles = shardTiles; stats.n_blocks = numBlocks; stats.n_padded_atoms = Npad; stats.n_exclusion_tiles = numMaskTiles;
         for (int d = 0; d < 3; d++) { stats.grid[d] = isPme() ? pme.d.nx * (d == 0) + pme.d.ny * (d == 1) + pme.d.nz * (d == 2) : 0; stats.dgrid[d] = cfg.method == SNB_LJPME ? dpme.d.nx * (d == 0) + dpme.d.ny * (d == 1) + dpme.d.nz * (d == 2) : 0; }
         for (int k = 0; k < RING; k++) { EvSet& r = ring[(ringPos + k) % RING]; if (r.pending) harvest(r); }

@@ -248,17 +248,9 @@ template <typename Real> __device__ inline int runLowerBound(const NbParams<Real
     return lo;
 }
 
-// HALF (round 3, the packed pair kernel's list format): the block's lower and upper 16 atoms get j-lists of their own -- an atom gathered
-// for the block goes to the list(s) of the half (halves) it is within the list radius of; 17 % reach one half only (tools/sim_split.py) --
-// published as PAIRS of half tiles in consecutive list slots (slot 2k: lower half's tile k, slot 2k + 1: upper half's), the two lists of a
-// j-subset padded to the same tile count so that a pair has one slice.  The gather list is then per-subset scratch.
-constexpr int NB_OUT = NB_CAP;      // entries per half list between publications: a half can be in reach of everything the gather list holds
-static_assert(2 * (NB_OUT / 32) <= 64, "the mask bookkeeping of a publication is one 64-bit word");
-template <typename Real, bool HALF> __global__ __launch_bounds__(256, HALF ? 2 : 4) void k_nbBuildTiles(const NbParams<Real> p) {
+template <typename Real> __global__ __launch_bounds__(256, 4) void k_nbBuildTiles(const NbParams<Real> p) {
     __shared__ int s_list[4][NB_CAP];
-    __shared__ unsigned s_mask[4][HALF ? 2 * (NB_OUT / 32) : NB_MAXT][32];
-    __shared__ int s_out[HALF ? 4 : 1][2][HALF ? NB_OUT : 1];      // half lists
-    __shared__ unsigned char s_cls[HALF ? 4 : 1][HALF ? NB_CAP : 1];      // which half (bit 0 lower, bit 1 upper) a gathered atom is in reach of
+    __shared__ unsigned s_mask[4][NB_MAXT][32];
     __shared__ int s_tileSub[4][NB_MAXT];
     __shared__ int s_query[4][128];      // exclusion partners (sorted index) still to be located in the gathered list
     __shared__ int s_qrow[4][128];       // ... and the i-row each belongs to
@@ -392,13 +384,10 @@ template <typename Real, bool HALF> __global__ __launch_bounds__(256, HALF ? 2 :
     };
 
     const long long tProlog = p.dbgOut ? (long long)wall_clock64() : 0;
-    // diagonal tile (half lists: both halves meet the block's own 32 atoms in their first tile)
-    int count = 32, outCount = 0;                          // entries in the gather list; entries per half list (HALF)
-    if constexpr (HALF) {
-        if (lane < 32) { const int e = (uI >= 0) ? ((I * 32 + lane) | (SNB_JCODE_CENTER << SNB_JSHIFT_BITS)) : -1; s_out[wid][0][lane] = e; s_out[wid][1][lane] = e; }
-        count = 0; outCount = 32;
-    } else if (lane < 32) { list[lane] = (uI >= 0) ? ((I * 32 + lane) | (SNB_JCODE_CENTER << SNB_JSHIFT_BITS)) : -1; }
+    // diagonal tile
+    if (lane < 32) { list[lane] = (uI >= 0) ? ((I * 32 + lane) | (SNB_JCODE_CENTER << SNB_JSHIFT_BITS)) : -1; }
     if (lane == 0) tileSub[0] = p.blockSubset[I];
+    int count = 32;
     bool hasDiag = true;
 
     // the block's box grown by the list radius: a j-atom is wanted if one of its periodic images lies inside
@@ -444,7 +433,7 @@ template <typename Real, bool HALF> __global__ __launch_bounds__(256, HALF ? 2 :
         const auto q0 = p.posq[I * 32 + 2 * lane], q1 = p.posq[I * 32 + 2 * lane + 1];
         ipos[lane] = make_float4((float)q0.x, (float)q1.x, (float)q0.y, (float)q1.y); iposZ[lane] = make_float2((float)q0.z, (float)q1.z);
     }
-    int filtered = HALF ? 0 : 32;                         // list[0 .. filtered) has been through the exact test (the diagonal tile needs none)
+    int filtered = 32;                                    // list[0 .. filtered) has been through the exact test (the diagonal tile needs none)
     auto exactFilter = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -461,167 +450,23 @@ template <typename Real, bool HALF> __global__ __launch_bounds__(256, HALF ? 2 :
                 px = (float)q.x + kx * Lt.ax + ky * Lt.bx + kz * Lt.cx; py = (float)q.y + ky * Lt.by + kz * Lt.cy; pz = (float)q.z + kz * Lt.cz;
             }
             typedef float v2f __attribute__((ext_vector_type(2)));
-            float best = 3e38f, bestLo = 3e38f;          // nearest atom of the block; of its lower 16 atoms (entries 0..7)
+            float best = 3e38f;
 #pragma unroll 8
             for (int a = 0; a < 16; a++) {                // two i-atoms per pass (packed fp32), LDS broadcast reads
                 const float4 xy = ipos[a]; const float2 zz = iposZ[a];
                 const v2f ddx = v2f{xy.x, xy.y} - px, ddy = v2f{xy.z, xy.w} - py, ddz = v2f{zz.x, zz.y} - pz;
                 const v2f d2 = ddx * ddx + ddy * ddy + ddz * ddz;
                 best = fminf(best, fminf(d2.x, d2.y));
-                if (HALF && a == 7) { bestLo = best; best = 3e38f; }
             }
-            int cls = 3;
-            if (HALF) { cls = (bestLo < R2 ? 1 : 0) | (best < R2 ? 2 : 0); best = fminf(best, bestLo); }
             keep = keep && best < R2;
             __builtin_amdgcn_wave_barrier();             // every lane has read its entry before the slots below it are rewritten
             const unsigned long long m = __ballot(keep);
-            if (keep) { const int o = out + lanePrefix(m); list[o] = e; if (HALF) s_cls[HALF ? wid : 0][o] = (unsigned char)cls; }
+            if (keep) { const int o = out + lanePrefix(m); list[o] = e; }
             out += __popcll(m);
         }
         count = out; filtered = out;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-    };
-
-    // ---- half lists: masks + publication of the pairs gathered so far (the counterpart of flush() above) ----
-    auto flushHalf = [&](int nPer, bool diag) {               // nPer entries (a multiple of 32) in each half list
-        if constexpr (HALF) {
-        int* out0 = s_out[wid][0]; int* out1 = s_out[wid][1];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int nP = nPer >> 5, nT = 2 * nP;                // pairs, half tiles (list slots): slot 2k + h
-        for (int k = lane; k < nT * 32; k += 64) mask[k >> 5][k & 31] = 0u;
-        __builtin_amdgcn_wave_barrier();
-        // the block's own atoms as j-atoms: keep j > i only (rows of the other half are never read)
-        if (diag && half == 0) { unsigned m = 0; for (int j = 0; j <= il; j++) m |= 1u << j; mask[il >> 4][il] = m; }
-        __builtin_amdgcn_wave_barrier();
-        for (int k = 0; k < nP; k++) {                         // padded j slots are masked for every row, padded i rows entirely; lanes 0-31: lower half's tile, 32-63: upper's
-            const int e = (half ? out1 : out0)[k * 32 + il];
-            const unsigned long long bal = __ballot(e == -1);
-            const unsigned jPad = half ? (unsigned)(bal >> 32) : (unsigned)bal;
-            const unsigned row = (uI < 0) ? 0xFFFFFFFFu : jPad;
-            if (row) atomicOr(&mask[2 * k + half][il], row);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // exclusions: a partner inside the block hits the diagonal tile of the row's half; the others are looked up in that half's list
-        int mine0[NB_OUT / 64], mine1[NB_OUT / 64];
-#pragma unroll
-        for (int r = 0; r < NB_OUT / 64; r++) {
-            const int k2 = lane + 64 * r;
-            const bool in = k2 < nPer && !(diag && k2 < 32);
-            const int e0 = in ? out0[k2] : -1, e1 = in ? out1[k2] : -1;
-            mine0[r] = (e0 == -1) ? -1 : (e0 & SNB_JIDX_MASK); mine1[r] = (e1 == -1) ? -1 : (e1 & SNB_JIDX_MASK);
-        }
-        auto resolve = [&](int nq) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int qi = 0; qi < nq; qi++) {
-                const int target = query[qi], row = qrow[qi], hr = row >> 4;
-#pragma unroll
-                for (int r = 0; r < NB_OUT / 64; r++)
-                    if ((hr ? mine1[r] : mine0[r]) == target) { const int k2 = lane + 64 * r; atomicOr(&mask[2 * (k2 >> 5) + hr][row], 1u << (k2 & 31)); }
-            }
-            __builtin_amdgcn_wave_barrier();
-        };
-        int nq = 0;
-        const int e0 = uI >= 0 ? p.uExclStart[uI] : 0, e1 = uI >= 0 ? p.uExclStart[uI + 1] : 0;
-        int maxLen = e1 - e0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(maxLen, o, 64); maxLen = maxLen > other ? maxLen : other; }
-        for (int k = 0; k < maxLen; k++) {
-            bool want = false; int sp = -1;
-            if (half == 0 && e0 + k < e1) {
-                sp = p.userToSorted[p.uExclList[e0 + k]];
-                const int J = sp >> 5;
-                if (J == I) { if (diag) atomicOr(&mask[il >> 4][il], 1u << (sp & 31)); }
-                else want = ownsPair(I, J);
-            }
-            const unsigned long long m = __ballot(want);
-            const int nNew = __popcll(m);
-            if (nq + nNew > 128) { resolve(nq); nq = 0; }
-            if (want) { const int o = nq + lanePrefix(m); query[o] = sp; qrow[o] = il; }
-            nq += nNew;
-        }
-        resolve(nq);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // publish: nT list slots; work items of CH slots (CH even: whole pairs)
-        int first = 0, w0 = 0, wp = 0;
-        const int CH = (p.itemTiles & ~1) < 2 ? 2 : (p.itemTiles & ~1);
-        const int nFull = nT / CH, nPart = (nT % CH) ? 1 : 0;
-        const int part = I & (NB_PARTS - 1);
-        int* cnt = p.counters + 32 * (1 + part);
-        const int tileRegion = p.tileCapacity / NB_PARTS, workRegion = p.workCapacity / NB_PARTS;
-        if (lane == 0) { first = atomicAdd(&cnt[0], nT); w0 = atomicAdd(&cnt[1], nFull); wp = nPart ? atomicAdd(&cnt[4], 1) : 0; }
-        first = __builtin_amdgcn_readfirstlane(first); w0 = __builtin_amdgcn_readfirstlane(w0); wp = __builtin_amdgcn_readfirstlane(wp);
-        if (first + nT > tileRegion || w0 + nFull > workRegion || wp + nPart > workRegion) { failed = true; return; }   // the host grows the regions and retries
-        first += part * tileRegion; w0 += part * workRegion; wp += part * workRegion;
-        for (int k = lane; k < nT * 32; k += 64) { const int t = k >> 5; p.tileJ[(size_t)first * 32 + k] = ((t & 1) ? out1 : out0)[(t >> 1) * 32 + (k & 31)]; }
-        unsigned long long anyBits = 0ull;      // bit t = list slot t has a non-zero mask (nT <= 40)
-        for (int t2 = 0; t2 < nT; t2 += 2) {
-            const int t = t2 + half;
-            const unsigned row = mask[t][il];
-            const unsigned long long bal = __ballot(row != 0u);
-            if ((unsigned)bal) anyBits |= 1ull << t2;
-            if ((unsigned)(bal >> 32)) anyBits |= 1ull << (t2 + 1);
-        }
-        const int nMasked = __popcll(anyBits);
-        int mi0 = 0;
-        if (nMasked > 0) {
-            if (lane == 0) mi0 = atomicAdd(&cnt[2], nMasked);
-            mi0 = __builtin_amdgcn_readfirstlane(mi0);
-            if (mi0 + nMasked > p.maskCapacity / NB_PARTS) { failed = true; return; }
-            mi0 += part * (p.maskCapacity / NB_PARTS);
-        }
-        for (int t2 = 0; t2 < nT; t2 += 2) {
-            const int t = t2 + half;
-            if ((anyBits >> t) & 1ull) p.masks[(size_t)(mi0 + __popcll(anyBits & ((1ull << t) - 1ull))) * 32 + il] = mask[t][il];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int subIb = p.blockSubset[I];
-        for (int t = lane; t < nT; t += 64) p.tileInfo[first + t] = make_int4(nbSliceOf(subIb, tileSub[t >> 1]), ((anyBits >> t) & 1ull) ? mi0 + __popcll(anyBits & ((1ull << t) - 1ull)) : -1, tileSub[t >> 1], 0);
-        for (int k = lane; k < nFull; k += 64) p.workItemsStage[w0 + k] = make_int4(I, first + CH * k, CH, subIb);
-        if (nPart && lane == 0) p.workItemsPartial[wp] = make_int4(I, first + CH * nFull, nT % CH, subIb);
-        __builtin_amdgcn_wave_barrier();
-        }
-    };
-    // the gathered (and exactly filtered) atoms of j-subset `sub` move from the gather list to the half lists, by the classes the exact filter left
-    auto closeSegmentHalf = [&](int sub) {
-        if constexpr (HALF) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        int n0 = 0, n1 = 0;
-        for (int b0 = 0; b0 < count; b0 += 64) {
-            const int k = b0 + lane;
-            const int c2 = k < count ? (exact ? (int)s_cls[wid][k] : 3) : 0;
-            n0 += __popcll(__ballot((c2 & 1) != 0)); n1 += __popcll(__ballot((c2 & 2) != 0));
-        }
-        const int nt = ((n0 > n1 ? n0 : n1) + 31) >> 5;
-        if (nt > 0) {
-            if (outCount + 32 * nt > NB_OUT) { flushHalf(outCount, hasDiag); hasDiag = false; outCount = 0; }
-            if (!failed) {
-                int* out0 = s_out[wid][0] + outCount; int* out1 = s_out[wid][1] + outCount;
-                int w0 = 0, w1 = 0;
-                for (int b0 = 0; b0 < count; b0 += 64) {
-                    const int k = b0 + lane;
-                    const int e = k < count ? list[k] : 0;
-                    const int c2 = k < count ? (exact ? (int)s_cls[wid][k] : 3) : 0;
-                    const unsigned long long m0 = __ballot((c2 & 1) != 0), m1 = __ballot((c2 & 2) != 0);
-                    if (c2 & 1) out0[w0 + lanePrefix(m0)] = e;
-                    if (c2 & 2) out1[w1 + lanePrefix(m1)] = e;
-                    w0 += __popcll(m0); w1 += __popcll(m1);
-                }
-                for (int k = n0 + lane; k < 32 * nt; k += 64) out0[k] = -1;
-                for (int k = n1 + lane; k < 32 * nt; k += 64) out1[k] = -1;
-                for (int t = (outCount >> 5) + lane; t < (outCount >> 5) + nt; t += 64) tileSub[t] = sub;
-                outCount += 32 * nt;
-            }
-        }
-        count = 0; filtered = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        }
     };
 
     for (int s = 0; s < p.nSubsets && !failed; s++) {
@@ -671,11 +516,8 @@ template <typename Real, bool HALF> __global__ __launch_bounds__(256, HALF ? 2 :
                 }
                 const unsigned long long m = __ballot(ok);
                 const int nNew = __popcll(m);
-                // (half lists: a subset's gathered atoms must fit ONE half list beside the diagonal tile -- a half can be in reach of all of them)
-                constexpr int GCAP = HALF ? NB_OUT - 32 : NB_CAP;
-                if (count + nNew > GCAP - 32 && exact) exactFilter();      // make room first
-                if (HALF && count + nNew > GCAP - 32) closeSegmentHalf(s);      // (the gather list is per-subset scratch: empty it into the half lists)
-                else if (count + nNew > GCAP - 32) {
+                if (count + nNew > NB_CAP - 32 && exact) exactFilter();      // make room first
+                if (count + nNew > NB_CAP - 32) {
                     // list full: close the current segment, publish this chunk and start a fresh list
                     const int padded = (count + 31) & ~31;
                     for (int k = count + lane; k < padded; k += 64) list[k] = -1;
@@ -737,18 +579,14 @@ template <typename Real, bool HALF> __global__ __launch_bounds__(256, HALF ? 2 :
         }
         if (nCmb > 0 && !failed) runCandidates();
         if (exact && !failed) exactFilter();
-        if constexpr (HALF) { if (!failed) closeSegmentHalf(s); }
-        else {
         // close the subset segment: pad to a whole tile, record the tiles' subset
         const int padded = (count + 31) & ~31;
         for (int k = count + lane; k < padded; k += 64) list[k] = -1;
         for (int t = (segStart >> 5) + lane; t < (padded >> 5); t += 64) tileSub[t] = s;
         count = padded; filtered = padded;
-        }
     }
     const long long tGather = p.dbgOut ? (long long)wall_clock64() : 0;
-    if constexpr (HALF) { if (!failed && outCount > 0) flushHalf(outCount, hasDiag); }
-    else if (!failed && count > 0) flush(count, hasDiag);
+    if (!failed && count > 0) flush(count, hasDiag);
     if (failed && lane == 0) atomicAdd(&p.counters[3], 1);
     if (p.dbgOut && lane == 0) { p.dbgOut[2 * I] = tStart; p.dbgOut[2 * I + 1] = (long long)wall_clock64(); p.dbgOut[2 * p.nBlocks + 2 * I] = tProlog; p.dbgOut[2 * p.nBlocks + 2 * I + 1] = tGather; }
 }
@@ -839,8 +677,7 @@ template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipSt
         const int nOwned = (p.nBlocks / p.shardPeriod) * p.shardWidth + std::min(std::max(p.nBlocks % p.shardPeriod - p.shardBegin, 0), p.shardWidth);
         if (nOwned > 0) {
             NbParams<Real> pb = p; pb.nOwned = nOwned;
-            if (pb.halfLists) hipLaunchKernelGGL((k_nbBuildTiles<Real, true>), dim3((nOwned + 3) / 4), block, 0, s, pb);
-            else hipLaunchKernelGGL((k_nbBuildTiles<Real, false>), dim3((nOwned + 3) / 4), block, 0, s, pb);
+            hipLaunchKernelGGL((k_nbBuildTiles<Real>), dim3((nOwned + 3) / 4), block, 0, s, pb);
         }
         hipLaunchKernelGGL((k_nbCompactWork<Real>), dim3(2 * NB_PARTS), block, 0, s, p);
     }

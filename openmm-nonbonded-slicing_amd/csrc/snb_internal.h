@@ -62,7 +62,6 @@ template <typename Real> struct DirectParams {
     double* sliceE;           // [S*2] raw energies
     const Real* lambdas;      // [S*2]
     const int* sliceNeed;     // [S] energy steps: non-zero = this slice's raw energies are wanted (derivative-only steps ask for a few slices)
-    int halfTiles;            // the list holds pairs of half tiles (16 i-atoms x 32 j-atoms each; direct.hip k_directPacked<HALF>)
     int numWork, workStart, workStride;   // sharding: items workStart, workStart+workStride, ...
     int nsub;
     Real cutoff2, krf, crf, alpha, alphaD, k4pe;          // k4pe = ONE_4PI_EPS0
@@ -183,7 +182,6 @@ template <typename Real> struct NbParams {
     double boxm[9];  // periodic cell, rows a, b, c in OpenMM's reduced (lower-triangular) form
     double origin[3];  // subtracted from the user positions before wrapping (the enclosing cell of a non-periodic system; else 0)
     float listCutoff;
-    int halfLists;   // publish pairs of half tiles (16 i-atoms x 32 j-atoms each) for the packed pair kernel instead of 32 x 32 tiles
     int boxWalk;     // test switch (SNB_NB_BOX_WALK): candidate runs from the grown box alone, without the per-column z ranges of round 3
     float jumpDist;  // consecutive sorted atoms further apart than this start a new (padded) block segment
     // static, user order

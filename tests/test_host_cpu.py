@@ -25,7 +25,7 @@ def test_struct_layout_matches_header(snb):
     capi = snb.capi
     # sizes follow from the field lists in include/snb.h (natural alignment)
     assert ctypes.sizeof(capi.SnbConfig) == 8 * 4 + 4 * 8 + 6 * 4 + 8 + 3 * 4 + 4 + 8 + 3 * 4 + 2 * 4 + 4 + 8
-    assert ctypes.sizeof(capi.SnbStats) == 7 * 8 + 6 * 4 + 4 * 8 + 3 * 8 + 8 + 8 + 8 + 16 * 8 + 16 * 8 + 8 + 8
+    assert ctypes.sizeof(capi.SnbStats) == 7 * 8 + 6 * 4 + 4 * 8 + 3 * 8 + 8 + 8 + 8 + 16 * 8 + 16 * 8 + 8
 
 
 def test_struct_layout_matches_c_compiler(snb, tmp_path):
