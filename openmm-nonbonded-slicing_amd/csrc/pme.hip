@@ -875,8 +875,8 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
     const int loX = (4 + M + cx - 1) / cx, hiX = (M + cx - 1) / cx, loY = (4 + M + cy - 1) / cy, hiY = (M + cy - 1) / cy;      // launcher: lo + hi + 1 <= 3
     if (tid == 0) s_any = 0;
     __syncthreads();
-    if (tid < 9 * nSlabs) {
-        const int j = tid / nSlabs, s = tid - j * nSlabs, jx = j / 3, jy = j - jx * 3;
+    for (int i = tid; i < 9 * nSlabs; i += NT) {      // (9 x 32 flags at most: more than a 256-thread work-group)
+        const int j = i / nSlabs, s = i - j * nSlabs, jx = j / 3, jy = j - jx * 3;
         const int dbx = jx - hiX, dby = jy - hiY;
         int b = 0;
         if (dbx <= loX && dby <= loY) {
@@ -884,7 +884,7 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
             int by2 = (By - dby) % nby; if (by2 < 0) by2 += nby;
             b = p.ownBusy[((slot * nbx + bx2) * nby + by2) * nSlabs + s];
         }
-        s_busy[tid] = b;
+        s_busy[i] = b;
         if (b) s_any = 1;
     }
     if (FUSEZ) for (int k = tid; k < nz; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
