@@ -1146,6 +1146,7 @@ public:
         for (int i = 0; i < 9; i++) { p.recip[i] = (Real)r[i]; p.recipLo[i] = (Real)(r[i] - (double)p.recip[i]); }
         p.alpha = (Real)plan.alpha; p.volume = (Real)det; p.dispersion = plan.dispersion ? 1 : 0;
         p.lambdas = dLambdas.p; p.sliceNeed = energySelective ? dSliceNeedSel.p : dSliceNeedAll.p; p.gridSubset = gridSubset.p; p.nsubTotal = nsub; p.mix = cfg.shard_count == 1 ? 1 : 0;
+        { static const bool m16 = getenv("SNB_MIX_16X16") != nullptr; p.mix16 = m16 ? 1 : 0; }
         p.sliceE = sliceE.p; p.fpx = fpx.p; p.fpy = fpy.p; p.fpz = fpz.p; p.wantEnergy = wantEnergy ? 1 : 0;
         // brick kernels: the sort columns were cut for the Coulomb mesh; any mesh whose cells tile those columns can use them,
         // with bricks of `group` columns when one column is narrower than 5 cells (stencil 4 + 1 cell of drift)

@@ -1165,7 +1165,51 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
     // convolution with the lambda mix:  O_I = eterm * sum_J lambda[slice(I,J)][term] * S_J   (mix=0: O_I = eterm * S_I)
     bool mixedOnMatrixCores = false;
     if constexpr (std::is_same<Real, float>::value) {
-        if (p.mix && nsub <= 16) {
+        static_assert(sizeof(Cx<Real>) == 8 || !std::is_same<Real, float>::value, "");
+        if (p.mix && nsub <= 4 && !p.mix16) {
+            // Up to four subsets (round 3): v_mfma_f32_4x4x1_16b_f32 -- 16 blocks of a 4 x 1 by 1 x 4 product.  Lane l holds A[block l/4][row l%4]
+            // and B[block l/4][col l%4] and receives D[block l/4][row r][col l%4] in register r (tools/ubench_mfma4x4.hip).  With A = one column
+            // J of the lambda matrix (rows = output subsets I) and B = the spectra of subset J at the lanes' own 64 points (re / im are points),
+            // four accumulating instructions leave every lane with the four mixed values of ITS point: one LDS read per J, one LDS write per I,
+            // no shuffling.  The 16 x 16 x 4 form below spends ~60 VALU instructions per 16 points on operand indexing and uses 4 of its 16
+            // output rows: 7200 wave-instructions per work-group, 46 % of this kernel's VALU work on c3; this form needs ~750.
+            mixedOnMatrixCores = true;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const int term = p.dispersion ? 1 : 0;
+            const int lane = tid & 63, wave = tid >> 6, nWaves = NT / 64;
+            float aReg[4];
+#pragma unroll
+            for (int J = 0; J < 4; J++) {
+                const int I = lane & 3;
+                float v = 0.f;
+                if (I < nsub && J < nsub) {
+                    const int gi = p.gridSubset[I], gj = p.gridSubset[J];
+                    v = p.lambdas[2 * (gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi) + term];
+                }
+                aReg[J] = v;
+            }
+            const int nPts = nx * NB * 2;
+            const float* Sf = reinterpret_cast<const float*>(S);
+            float* Of = reinterpret_cast<float*>(O);
+            const FastDiv d2NB(2 * NB);
+            for (int p0 = 64 * wave; p0 < nPts; p0 += 64 * nWaves) {
+                const int pt = p0 + lane;
+                const bool valid = pt < nPts;
+                const int k = d2NB.div(valid ? pt : 0), rem = (valid ? pt : 0) - k * 2 * NB;
+                const int base = 2 * k * BS + rem;                       // float index of (k, subset 0, col, re/im); subset J: + 2 NB J
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int J = 0; J < 4; J++) {
+                    const float b = (valid && J < nsub) ? Sf[base + 2 * NB * J] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(aReg[J], b, acc, 0, 0, 0);
+                }
+                if (valid) {
+                    const float e = (float)et[k * NB + (rem >> 1)];
+#pragma unroll
+                    for (int I = 0; I < 4; I++) if (I < nsub) Of[base + 2 * NB * I] = acc[I] * e;
+                }
+            }
+        } else if (p.mix && nsub <= 16) {
             // The mix is a dense [n x n] x [n x points] contraction: it runs on the matrix cores.  v_mfma_f32_16x16x4_f32:
             // A[i][k] (lane: i = l&15, k = l>>4) = lambda matrix (rows = output subset, K = input subset, 4 per instruction),
             // B[k][j] (lane: k = l>>4, j = l&15) = 16 spectral values (re/im are separate "points"), D rows (l>>4)*4+r, column l&15.

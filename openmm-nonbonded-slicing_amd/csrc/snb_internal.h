@@ -141,6 +141,7 @@ template <typename Real> struct PmeParams {
     const int* gridSubset;    // [nsub] subset id of each held grid
     int nsubTotal;
     int mix;                  // 1: lambda-mix the potentials in k-space (unsharded); 0: plain convolution (sharded)
+    int mix16;                // test switch (SNB_MIX_16X16): the 16 x 16 x 4 matrix-core form of the mix also for <= 4 subsets
     double* sliceE;
     Real* fpx; Real* fpy; Real* fpz;   // reciprocal force accumulators (plain stores when unsharded)
     int wantEnergy;
