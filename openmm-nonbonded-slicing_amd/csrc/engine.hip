@@ -173,7 +173,7 @@ template <typename Real> struct PmePlan {
     double alpha = 0;
     bool dispersion = false;
     DevBuf<Real> gridReal;
-    DevBuf<typename Vec<Real>::T2> gridCplx, twx, twy, twz;
+    DevBuf<typename Vec<Real>::T2> gridCplx, gridCplxB, twx, twy, twz;      // (gridCplxB: second complex mesh of the plane path, single precision)
     DevBuf<Real> modx, mody, modz;
     // own-atoms spreader (pme.hip k_spreadOwn / k_spreadMerge): geometry and buffers, sized at rebuild time
     int ownSlabs = 0, ownMargin = 1; DevBuf<unsigned char> ownPartial; DevBuf<int> ownBusy; DevBuf<int2> strays;
@@ -192,6 +192,7 @@ template <typename Real> struct PmePlan {
         if (sizeof(Real) == 8 && std::max(d.rx1, d.rx2) > 12 && !getenv("SNB_FFT_TWOPASS")) d.rx1 = d.rx2 = 0;
         gridReal.resize((size_t)nGrids * d.nx * d.ny * d.nz);
         gridCplx.resize((size_t)nGrids * d.nx * d.ny * d.nzc);
+        if (sizeof(Real) == 4 && d.nx == d.ny && d.nx <= 144) gridCplxB.resize((size_t)nGrids * d.nx * d.ny * d.nzc);
         auto tw = [&](int n, DevBuf<typename Vec<Real>::T2>& buf) {
             std::vector<typename Vec<Real>::T2> h(n);
             for (int k = 0; k < n; k++) { double a = -2.0 * SNB_PI * k / n; h[k].x = (Real)std::cos(a); h[k].y = (Real)std::sin(a); }
@@ -1138,7 +1139,7 @@ public:
         { static const bool tr = getenv("SNB_PME_TRACE") != nullptr; if (tr) { if (!dPmeTrace.p) { dPmeTrace.resize(8); HIPCHECK(hipMemset(dPmeTrace.p, 0, 64)); } p.trace = dPmeTrace.p; } }
         p.cellsReady = (!plan.dispersion && cellsFromGather) ? 1 : 0;
         p.fixDev = dFixScale.p ? dFixScale.p + (plan.dispersion ? 2 : 0) : nullptr;      // (k_fixScale keeps it in step with the parameters)
-        p.gridReal = plan.gridReal.p; p.gridCplx = plan.gridCplx.p; p.twx = plan.twx.p; p.twy = plan.twy.p; p.twz = plan.twz.p;
+        p.gridReal = plan.gridReal.p; p.gridCplx = plan.gridCplx.p; p.planeB = plan.gridCplxB.p; p.twx = plan.twx.p; p.twy = plan.twy.p; p.twz = plan.twz.p;
         p.modx = plan.modx.p; p.mody = plan.mody.p; p.modz = plan.modz.p;
         const double det = box[0] * box[4] * box[8], sc = 1.0 / det;
         const double r[9] = {box[4] * box[8] * sc, 0, 0, -box[3] * box[8] * sc, box[0] * box[8] * sc, 0,
@@ -1487,10 +1488,13 @@ public:
     void resetTimers() override { for (auto& r : ring) if (r.pending) harvest(r); stats.sum_direct_ms = stats.sum_recip_ms = stats.sum_total_ms = 0; stats.n_timed = 0; for (int k = 0; k < 16; k++) { stats.sum_kernel_ms[k] = 0; stats.n_kernel_timed[k] = 0; } execCount = 0; stampCounter = 0; }
 
     bool runPme(PmeParams<Real>& pp, hipStream_t st) {      // true: its interpolation kernel delivered the user-order forces (pp.outForces)
-        const bool zDone = launchPmeSpread<Real>(pp, st);
-        launchPmeForwardFFT<Real>(pp, st, zDone);
-        launchPmeConvolution<Real>(pp, st);
-        launchPmeInverseFFT<Real>(pp, st);
+        const int zDone = launchPmeSpread<Real>(pp, st);
+        if (zDone == 2) launchPmePlanePath<Real>(pp, st);      // per-plane x / y transforms + convolution in LDS, then mix + inverse z
+        else {
+            launchPmeForwardFFT<Real>(pp, st, zDone == 1);
+            launchPmeConvolution<Real>(pp, st);
+            launchPmeInverseFFT<Real>(pp, st);
+        }
         return launchPmeInterpolate<Real>(pp, st);
     }
 

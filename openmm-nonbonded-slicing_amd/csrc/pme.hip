@@ -390,9 +390,10 @@ template <typename Real, bool FIXED, bool FUSEZ> __global__ __launch_bounds__(51
     }
 }
 
-template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hipStream_t s);      // -1: not applicable, 0: real mesh written, 1: forward z FFT done too
-// Returns true when the spreader also did the forward z FFT (launchPmeForwardFFT must then skip its z pass).
-template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
+template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hipStream_t s);      // -1: not applicable, 0: real mesh written, 1: forward z FFT done too, 2: ... and written plane-major
+// Returns 1 when the spreader also did the forward z FFT (launchPmeForwardFFT must then skip its z pass), 2 when it left the spectrum
+// plane-major for the plane path (launchPmePlanePath replaces forward FFT, convolution and inverse FFT), else 0.
+template <typename Real> int launchPmeSpread(const PmeParams<Real>& p, hipStream_t s) {
     if (p.sortNcx > 0 && p.colRange != nullptr) {
         const int cx = p.groupX * (p.d.nx / p.sortNcx), cy = p.groupY * (p.d.ny / p.sortNcy);
         static const bool noFixed = getenv("SNB_NO_FIXED_SPREAD") != nullptr;      // test switch: f64 LDS accumulation in single precision too
@@ -407,21 +408,21 @@ template <typename Real> bool launchPmeSpread(const PmeParams<Real>& p, hipStrea
         const size_t lds = brickBytes + (fuse ? std::max(listBytes, fftBytes) : listBytes);
         const int nblocks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * p.zSlabs;
         if (!p.cellsReady) hipLaunchKernelGGL((k_pmeCells<Real>), dim3((p.natoms + 255) / 256), dim3(256), 0, s, p);
-        if (p.ownSlabs > 0) { const int r = launchSpreadOwn<Real>(p, s); if (r >= 0) return r == 1; }
+        if (p.ownSlabs > 0) { const int r = launchSpreadOwn<Real>(p, s); if (r >= 0) return r; }
 #define SNB_SPREAD(FX, FZ) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadBrick<Real, FX, FZ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                              SNB_STAMPED_LAUNCH(stampSlot(p, 1), (k_spreadBrick<Real, FX, FZ>), dim3(nblocks), dim3(512), lds, s, p); }
         if constexpr (std::is_same<Real, float>::value) {
-            if (fixed) { if (fuse) SNB_SPREAD(true, true) else SNB_SPREAD(true, false) return fuse; }
+            if (fixed) { if (fuse) SNB_SPREAD(true, true) else SNB_SPREAD(true, false) return fuse ? 1 : 0; }
         }
         if (fuse) SNB_SPREAD(false, true) else SNB_SPREAD(false, false)
 #undef SNB_SPREAD
-        return fuse;
+        return fuse ? 1 : 0;
     }
     // fallback (triclinic boxes, meshes without a usable column divisor): global float atomics
     hipMemsetAsync(p.gridReal, 0, sizeof(Real) * (size_t)p.nsub * p.d.nx * p.d.ny * p.d.nz, s);
-    if (p.natoms <= 0) return false;
+    if (p.natoms <= 0) return 0;
     SNB_STAMPED_LAUNCH(stampSlot(p, 1), (k_spread<Real>), dim3((p.natoms + 7) / 8), dim3(256), 0, s, p);
-    return false;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -852,7 +853,7 @@ template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_sp
 // real lines per complex transform, written as the half-complex mesh; otherwise the real mesh.  One thread sums one 16-byte chunk of a
 // line: at most 3 x 3 bricks and 2 slabs cover it; per y neighbour the 6 (predicated) loads are issued back to back -- the first version
 // walked the candidates one dependent load at a time and took 101 us on c3.
-template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_spreadMerge(const PmeParams<Real> p, const int chunk) {
+template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_spreadMerge(const PmeParams<Real> p, const int chunk, const int plane) {
     // NT = 256      // (a brick is ~18 complex lines: 512 threads left most of them idle in the FFT passes, and at the ~120 VGPRs of those passes 256-thread groups go four to a CU)
     using Acc = typename std::conditional<FIXED, int, double>::type;
     constexpr int CMAX = FIXED ? 4 : 2;                                    // values per 16-byte load
@@ -897,6 +898,15 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
     // strays (normally none): atoms whose footprint left the region of their own work-group; every brick looks at every stray
     const int nStray = *p.strayCount;
     if (FUSEZ && !s_any && nStray == 0) {      // nothing of this subset anywhere near (uniform): the brick's spectrum is zero
+        if (plane) {      // plane-major spectrum [slot][kz][x][y] (the plane path, k_planeXY)
+            const FastDiv dnl(nl);
+            for (int it = tid; it < nl * nzc; it += NT) {
+                const int k = dnl.div(it), l = it - k * nl;
+                const int lx = dcy2.div(l), ly = l - lx * cy;
+                out[((size_t)k * nx + (x0 + lx)) * ny + (y0 + ly)] = {Real(0), Real(0)};
+            }
+            return;
+        }
         for (int it = tid; it < nl * nzc; it += NT) {
             const int l = dzc.div(it), k = it - l * nzc;
             const int lx = dcy2.div(l), ly = l - lx * cy;
@@ -993,6 +1003,19 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
     if constexpr (FUSEZ) {
         Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, NT);
         __syncthreads();
+        if (plane) {      // plane-major [slot][kz][x][y]: consecutive lanes = consecutive line pairs of one kz (runs of cy elements per x row)
+            const FastDiv dnb(nb);
+            for (int it = tid; it < nb * nzc; it += NT) {
+                const int k = dnb.div(it), c = it - k * nb;
+                const Cx<Real> z = R[k * BS + c], m = R[(k == 0 ? 0 : nz - k) * BS + c];
+                const int l0 = 2 * c, lx0 = dcy2.div(l0), ly0 = l0 - lx0 * cy;
+                out[((size_t)k * nx + (x0 + lx0)) * ny + (y0 + ly0)] = {Real(0.5) * (z.x + m.x), Real(0.5) * (z.y - m.y)};
+                if (l0 + 1 < nl) {
+                    const int l1 = l0 + 1, lx1 = dcy2.div(l1), ly1 = l1 - lx1 * cy;
+                    out[((size_t)k * nx + (x0 + lx1)) * ny + (y0 + ly1)] = {Real(0.5) * (z.y + m.y), Real(0.5) * (m.x - z.x)};
+                }
+            }
+        } else
         for (int it = tid; it < nb * nzc; it += NT) {
             const int c = dzc.div(it), k = it - c * nzc;
             const Cx<Real> z = R[k * BS + c], m = R[(k == 0 ? 0 : nz - k) * BS + c];
@@ -1284,6 +1307,247 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Plane path (round 3).  The y pass, the fused x kernel and the inverse y pass above are three trips of the complex meshes through HBM and
+// ~80 us of latency-bound work-groups on c3 (21 + 38..44 + 21).  A (subset, kz) plane of a mesh up to ~128^2 is 115 KB in single
+// precision: it fits the 160 KB of LDS of one CU, and a 120^3 mesh with 4 subsets has 244 such planes -- one round of 256 CUs.  So, when
+// the merge kernel has written the half-complex spectrum plane-major ([slot][kz][x][y]), ONE kernel does, per plane and entirely in LDS:
+// forward FFT_y, forward FFT_x, multiplication by the reciprocal-space kernel, inverse FFT_x, inverse FFT_y, and (energy steps) the
+// slice energies.  The transforms are the two-pass register FFT run IN PLACE: the forward passes leave frequency k1 + R1 k2 at position
+// k1 R2 + k2, the kernel value is looked up at that permuted index, and the inverse passes run in the opposite order and undo the
+// permutation -- no reordering pass, no second LDS buffer.  The lambda mix moves behind it: it is linear, so mixing the convolved
+// potentials psi_J of the subsets in (x, y, kz) space gives the same phi_I = sum_J lambda_IJ psi_J as mixing in k-space; the inverse z
+// kernel below (k_fftZInvMix) does it on the matrix cores while it loads its lines.  Slice energies need no k-space either: by
+// Parseval over the plane, sum_{kx,ky} S_I conj(eterm S_J) = sum_{x,y} Q~_I conj(psi~_J), with Q~ the plane as the merge kernel left it
+// (kept in the first buffer: the convolved planes go to a second one) and psi~ the plane this work-group has just produced.
+// Replaces, on this path, reciprocalConvolution + gridEvaluateEnergy (platforms/common/src/kernels/pme.cc:138-274) and four of the six
+// 1D FFT passes of the vendor FFT the reference calls.
+// ---------------------------------------------------------------------------------------------------
+template <typename Real, int R, int SIGN, int TWMODE, bool STRIDED, typename PRE>
+__device__ __forceinline__ void planePass(Cx<Real>* P, const int lines, const int lineStride, const int elemStride, const int other, const Cx<Real>* tw,
+                                          const int tid, const int NT, PRE pre) {
+    // One R-point transform per task, in place.  STRIDED: task j = n2, element k at position k * other + j (pass over n1 / k1);
+    // else task j = k1, element k at position j * R + k (pass over n2 / k2).  TWMODE 1: W_n^{j k} after the transform (forward),
+    // 2: conj W_n^{j k} before it (inverse).  Lanes run along `lines`.
+    const int tasks = lines * other;
+    const FastDiv dl(lines);
+    for (int t = tid; t < tasks; t += NT) {
+        const int j = dl.div(t), line = t - j * lines;
+        Cx<Real>* base = P + line * lineStride;
+        Cx<Real> v[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int pos = STRIDED ? (k * other + j) : (j * R + k);
+            v[k] = base[pos * elemStride];
+            const Real sc = pre(line, pos);
+            v[k].x *= sc; v[k].y *= sc;
+        }
+        if (TWMODE == 2 && j > 0) {
+#pragma unroll
+            for (int k = 1; k < R; k++) { Cx<Real> w = tw[j * k]; w.y = -w.y; v[k] = cmul(v[k], w); }
+        }
+        fftReg<Real, R>(v, SIGN);
+        if (TWMODE == 1 && j > 0) {
+#pragma unroll
+            for (int k = 1; k < R; k++) v[k] = cmul(v[k], tw[j * k]);
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int pos = STRIDED ? (k * other + j) : (j * R + k);
+            base[pos * elemStride] = v[k];
+        }
+    }
+}
+struct PlaneNoScale { template <typename... A> __device__ float operator()(A...) const { return 1.0f; } };
+
+#ifndef SNB_PLANE_EXP
+#define SNB_PLANE_EXP 0
+#endif
+template <int R1, int R2> __global__ __launch_bounds__(1024) void k_planeXY(const PmeParams<float> p) {
+    using Real = float;
+    constexpr int NT = 1024;
+    const int nx = p.d.nx, ny = p.d.ny, nzc = p.d.nzc;      // launcher: nx == ny == R1 * R2
+    const int PY = ny | 1;                                  // odd pitch: lanes along x (stride PY) and lanes along y (stride 1) are both conflict-free
+    const int slot = blockIdx.x / nzc, kz = blockIdx.x - slot * nzc;
+    Cx<Real>* P = reinterpret_cast<Cx<Real>*>(s_dyn);                  // [nx][PY]
+    Cx<Real>* tw = P + (size_t)nx * PY;                                // [nx] roots of unity (nx == ny)
+    __shared__ double s_red[NT / 64];
+    const int tid = threadIdx.x;
+    const size_t planeElems = (size_t)nx * ny;
+    const Cx<Real>* in = reinterpret_cast<const Cx<Real>*>(p.gridCplx) + ((size_t)slot * nzc + kz) * planeElems;
+    Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.planeB) + ((size_t)slot * nzc + kz) * planeElems;
+    for (int k = tid; k < nx; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twx)[k];
+    const FastDiv dny(ny);
+    const int nPairs = (int)(planeElems >> 1);                         // ny is even (launcher): 16-byte loads never straddle a row
+    batchedCopy<8, float4>(tid, nPairs, NT,
+        [&](int e) {
+#if SNB_PLANE_EXP & 1
+            return make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+            return reinterpret_cast<const float4*>(in)[e]; },
+        [&](int e, const float4& v) { const int x = dny.div(2 * e), y = 2 * e - x * ny; P[x * PY + y] = {v.x, v.y}; P[x * PY + y + 1] = {v.z, v.w}; });
+    __syncthreads();
+    // forward y (lines = x rows, elements along y), forward x (lines = y columns, elements along x, stride PY)
+    planePass<Real, R1, -1, 1, true>(P, nx, PY, 1, R2, tw, tid, NT, PlaneNoScale());
+    __syncthreads();
+    planePass<Real, R2, -1, 0, false>(P, nx, PY, 1, R1, tw, tid, NT, PlaneNoScale());
+    __syncthreads();
+    planePass<Real, R1, -1, 1, true>(P, ny, 1, PY, R2, tw, tid, NT, PlaneNoScale());
+    __syncthreads();
+    planePass<Real, R2, -1, 0, false>(P, ny, 1, PY, R1, tw, tid, NT, PlaneNoScale());
+    __syncthreads();
+    // position q of an axis now holds frequency (q / R2) + R1 * (q % R2); the kernel value is applied while the first inverse pass loads
+    const FastDiv dr2(R2);
+    planePass<Real, R2, +1, 0, false>(P, ny, 1, PY, R1, tw, tid, NT,
+        [&](int line, int pos) {
+#if SNB_PLANE_EXP & 4
+            return 1.0f;
+#endif
+            const int a = dr2.div(line), b = dr2.div(pos); return recipTerm<Real>(p, b + R1 * (pos - b * R2), a + R1 * (line - a * R2), kz); });
+    __syncthreads();
+    planePass<Real, R1, +1, 2, true>(P, ny, 1, PY, R2, tw, tid, NT, PlaneNoScale());
+    __syncthreads();
+    planePass<Real, R2, +1, 0, false>(P, nx, PY, 1, R1, tw, tid, NT, PlaneNoScale());
+    __syncthreads();
+    planePass<Real, R1, +1, 2, true>(P, nx, PY, 1, R2, tw, tid, NT, PlaneNoScale());
+    __syncthreads();
+    batchedCopy<8, float4>(tid, nPairs, NT,
+        [&](int e) { const int x = dny.div(2 * e), y = 2 * e - x * ny; const Cx<Real> a = P[x * PY + y], b = P[x * PY + y + 1]; return make_float4(a.x, a.y, b.x, b.y); },
+        [&](int e, const float4& v) {
+#if SNB_PLANE_EXP & 2
+            return;
+#endif
+            reinterpret_cast<float4*>(out)[e] = v; });
+    // per-slice energies (ReferencePME.cpp:487-491): E_IJ = sum_k eterm Re(S_I conj S_J) over the full mesh (1/2 on the diagonal), here as
+    // sum over the plane of Re(Q~_I conj psi~_J), Hermitian weight 2 for interior kz; this work-group holds psi~_J, J = its slot, and takes the
+    // pairs I >= J
+    if (p.wantEnergy && p.mix && !(SNB_PLANE_EXP & 8)) {
+        const int term = p.dispersion ? 1 : 0;
+        const int gj = p.gridSubset[slot];
+        const double w = (kz == 0 || 2 * kz == p.d.nz) ? 1.0 : 2.0;
+        for (int I = slot; I < p.nsub; I++) {
+            const int gi = p.gridSubset[I];
+            const int slice = gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi;
+            if (!p.sliceNeed[slice]) continue;      // (uniform)
+            const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const Cx<Real>*>(p.gridCplx) + ((size_t)I * nzc + kz) * planeElems);
+            double acc = 0;
+            for (int e0 = tid; e0 < nPairs; e0 += 4 * NT) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int e = e0 + u * NT; if (e < nPairs) v[u] = q[e]; }
+                float part = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u * NT;
+                    if (e < nPairs) {
+                        const int x = dny.div(2 * e), y = 2 * e - x * ny;
+                        const Cx<Real> a = P[x * PY + y], b = P[x * PY + y + 1];
+                        part += (v[u].x * a.x + v[u].y * a.y) + (v[u].z * b.x + v[u].w * b.y);
+                    }
+                }
+                acc += (double)part;
+            }
+            acc *= (I == slot) ? 0.5 * w : w;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            __syncthreads();
+            if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0; for (int k = 0; k < NT / 64; k++) tot += s_red[k];
+                atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, p.nsubTotal * (p.nsubTotal + 1))[2 * slice + term], tot);
+            }
+        }
+    }
+}
+
+// ---- inverse z pass of the plane path: lambda mix (matrix cores) + half-complex -> real -------------------------------------------
+// One work-group takes NBY consecutive y at one x, all held subsets: per (kz, y) point it loads the convolved potentials psi~_J of the
+// subsets from the plane-major buffer, mixes them (phi_I = sum_J lambda[slice(I,J)] psi~_J; v_mfma_f32_4x4x1_16b_f32 with A = a column of
+// the lambda matrix and B = the lanes' own values, as in k_convolveX: every lane ends up with the mixed values of ITS point, real and
+// imaginary part as two accumulation chains; up to 8 subsets, two groups of four output rows), packs subsets 2m and 2m+1 as the real and
+// imaginary line of one complex transform (Z = A + iB with A, B Hermitian) and runs the inverse z FFT into the real mesh [slot][x][y][z]
+// the interpolation reads.  mix == 0 (sharded engines): no mix, the subsets' own potentials.
+template <int R1, int R2> __global__ __launch_bounds__(256) void k_fftZInvMix(const PmeParams<float> p, const int NBY) {
+    using Real = float;
+    constexpr int NT = 256;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc, nsub = p.nsub;
+    const int NP = (nsub + 1) >> 1;                                      // complex transforms per y: subsets (2m, 2m+1)
+    const int tilesY = (ny + NBY - 1) / NBY;
+    const int x = blockIdx.x / tilesY, y0 = (blockIdx.x - x * tilesY) * NBY;
+    const int nby = (ny - y0) < NBY ? (ny - y0) : NBY;
+    const int nb = nby * NP, BS = NBY * NP + 1;
+    Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
+    Cx<Real>* B = A + (size_t)nz * BS;
+    Cx<Real>* tw = B + (size_t)nz * BS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < nz; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
+    const int term = p.dispersion ? 1 : 0;
+    float aReg[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int J = 0; J < 8; J++) {
+            const int I = 4 * g + (lane & 3);
+            float v = 0.f;
+            if (I < nsub && J < nsub) {
+                if (p.mix) {
+                    const int gi = p.gridSubset[I], gj = p.gridSubset[J];
+                    v = p.lambdas[2 * (gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi) + term];
+                } else v = (I == J) ? 1.f : 0.f;
+            }
+            aReg[g][J] = v;
+        }
+    const size_t planeElems = (size_t)nx * ny, subStride = (size_t)nzc * planeElems;
+    const Cx<Real>* src = reinterpret_cast<const Cx<Real>*>(p.planeB) + (size_t)x * ny + y0;
+    const int nPts = nzc * nby;
+    const FastDiv dnby(nby);
+    const int nG = (nsub + 3) >> 2;
+    for (int p0 = 64 * wave; p0 < nPts; p0 += NT) {      // (uniform trip count per wave: the matrix-core instructions run with every lane)
+        const int pt = p0 + lane;
+        const bool valid = pt < nPts;
+        const int kz = dnby.div(valid ? pt : 0), yy = (valid ? pt : 0) - kz * nby;
+        const Cx<Real>* s0 = src + (size_t)kz * planeElems + yy;
+        Cx<Real> v[8];
+#pragma unroll
+        for (int J = 0; J < 8; J++) { v[J] = {0.f, 0.f}; if (valid && J < nsub) v[J] = s0[J * subStride]; }
+        f32x4 re[2], im[2];
+#pragma unroll
+        for (int g = 0; g < 2; g++) { re[g] = {0.f, 0.f, 0.f, 0.f}; im[g] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int g = 0; g < 2; g++) if (g < nG) {
+#pragma unroll
+            for (int J = 0; J < 8; J++) if (J < nsub) {
+                re[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(aReg[g][J], v[J].x, re[g], 0, 0, 0);
+                im[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(aReg[g][J], v[J].y, im[g], 0, 0, 0);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) if (m < NP) {
+                const int g = m >> 1, r = (2 * m) & 3;
+                const Cx<Real> a = {re[g][r], im[g][r]};
+                Cx<Real> b = {0.f, 0.f};
+                if (2 * m + 1 < nsub) b = {re[g][r + 1], im[g][r + 1]};
+                const int c = yy * NP + m;
+                A[kz * BS + c] = {a.x - b.y, a.y + b.x};                                          // A_k + i B_k
+                if (kz > 0 && nz - kz >= nzc) A[(nz - kz) * BS + c] = {a.x + b.y, b.x - a.y};    // conj(A_k) + i conj(B_k)
+            }
+        }
+    }
+    Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, +1, tw, nb, BS, tid, NT);
+    __syncthreads();
+    const FastDiv dz(nz), dnp(NP);
+    for (int it = tid; it < nb * nz; it += NT) {
+        const int c = dz.div(it), k = it - c * nz;
+        const int yy = dnp.div(c), m = c - yy * NP;
+        const Cx<Real> z = R[k * BS + c];
+        p.gridReal[(((size_t)(2 * m) * nx + x) * ny + (y0 + yy)) * nz + k] = z.x;
+        if (2 * m + 1 < nsub) p.gridReal[(((size_t)(2 * m + 1) * nx + x) * ny + (y0 + yy)) * nz + k] = z.y;
+    }
+}
+
 // ---- launch dispatch over the instantiated (R1, R2) pairs ------------------------------------------
 // threads per work-group of the y FFT pass: 512 over the same LDS tile (two rounds of register sub-transforms become one and twice the
 // waves hide the tile's load latency: 24.4 -> 22.4 us per pass on c3; SNB_FFT_THREADS=256 restores the narrower groups).  The z pass
@@ -1313,6 +1577,54 @@ template <typename Real> static void launchConvolveX(int r1, int r2, dim3 grid, 
 }
 
 
+// Plane path (k_planeXY + k_fftZInvMix): single precision, a square mesh plane that fits LDS with its row padding, an instantiated
+// two-pass split, at most 8 held subsets, and the own-atoms spreader's merge kernel in front (it writes the plane-major spectrum).
+#define SNB_PLANE_PAIRS(X) X(6, 7) X(6, 9) X(8, 8) X(8, 10) X(9, 10) X(8, 12) X(10, 10) X(9, 12) X(10, 12) X(8, 16)
+template <typename Real> static size_t planeLds(const PmeParams<Real>& p) { return sizeof(Cx<Real>) * ((size_t)p.d.nx * (p.d.ny | 1) + p.d.nx); }
+template <typename Real> static bool planePathOK(const PmeParams<Real>& p) {
+    static const bool off = getenv("SNB_NO_PLANE_FFT") != nullptr;      // test switch: the three-kernel y / x / y pipeline
+    if (off || !std::is_same<Real, float>::value || !p.planeB) return false;
+    if (p.d.nx != p.d.ny || (p.d.ny & 1) || p.d.rx1 <= 0 || p.d.rx1 != p.d.ry1 || p.d.rx2 != p.d.ry2 || p.d.rx1 * p.d.rx2 != p.d.nx) return false;
+    if (p.nsub > 8 || planeLds(p) > 156 * 1024) return false;
+    bool inst = false;
+#define X(A, B) if (p.d.rx1 == A && p.d.rx2 == B) inst = true;
+    SNB_PLANE_PAIRS(X)
+#undef X
+    return inst;
+}
+static void launchPlaneXY(const PmeParams<float>& p, hipStream_t s) {
+    const size_t lds = planeLds(p);
+    const dim3 grid((unsigned)(p.nsub * p.d.nzc));
+#define X(A, B) if (p.d.rx1 == A && p.d.rx2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_planeXY<A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_planeXY<A, B>), grid, dim3(1024), lds, s, p); return; }
+    SNB_PLANE_PAIRS(X)
+#undef X
+}
+static void launchFftZInvMix(const PmeParams<float>& p, hipStream_t s) {
+    static const int nbyEnv = getenv("SNB_ZMIX_NBY") ? atoi(getenv("SNB_ZMIX_NBY")) : 8;
+    const int NP = (p.nsub + 1) / 2;
+    int NBY = std::max(1, std::min(nbyEnv, p.d.ny));
+    while (NBY > 1 && sizeof(Cx<float>) * ((size_t)2 * p.d.nz * (NBY * NP + 1) + p.d.nz) > 64 * 1024) NBY >>= 1;
+    const size_t lds = sizeof(Cx<float>) * ((size_t)2 * p.d.nz * (NBY * NP + 1) + p.d.nz);
+    const dim3 grid((unsigned)(p.d.nx * ((p.d.ny + NBY - 1) / NBY)));
+#define X(A, B) if (p.d.rz1 == A && p.d.rz2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZInvMix<A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        SNB_STAMPED_LAUNCH(stampSlot(p, 6), (k_fftZInvMix<A, B>), grid, dim3(256), lds, s, p, NBY); return; }
+    SNB_FFT_PAIRS(X)
+#undef X
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZInvMix<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SNB_STAMPED_LAUNCH(stampSlot(p, 6), (k_fftZInvMix<0, 0>), grid, dim3(256), lds, s, p, NBY);
+}
+// The middle of the pipeline on the plane path (after a spreader that returned 2): convolution + x / y transforms per plane, then mix + inverse z.
+template <typename Real> void launchPmePlanePath(const PmeParams<Real>& p, hipStream_t s) {
+    if constexpr (std::is_same<Real, float>::value) {
+        static const int dbg = getenv("SNB_PLANE_DEBUG") ? atoi(getenv("SNB_PLANE_DEBUG")) : 0;      // diagnosis: 1 = skip the z kernel, 2 = skip the plane kernel, 3 = skip both
+        if (!(dbg & 2)) launchPlaneXY(p, s);
+        if (!(dbg & 1)) launchFftZInvMix(p, s);
+    }
+}
+template void launchPmePlanePath<float>(const PmeParams<float>&, hipStream_t);
+template void launchPmePlanePath<double>(const PmeParams<double>&, hipStream_t);
+
 // own-atoms spreader: k_spreadOwn over (brick, slab) work-groups, then k_spreadMerge per brick (fused with the forward z FFT when its
 // buffers fit LDS).  Geometry (slabs, margin) and the buffers come from the engine (sized at rebuild time).
 template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hipStream_t s) {
@@ -1334,15 +1646,16 @@ template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hi
     const size_t ldsFft = sizeof(Cx<Real>) * ((size_t)2 * p.d.nz * (nb + 1) + p.d.nz);
     static const bool noFuse = getenv("SNB_NO_FUSED_Z") != nullptr;
     const bool fuse = !noFuse && ldsFft <= 120 * 1024;
+    const int plane = (fuse && planePathOK<Real>(p)) ? 1 : 0;      // plane-major spectrum for k_planeXY
 #define SNB_OWN(FX) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadOwn<Real, FX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsOwn); \
                       SNB_STAMPED_LAUNCH(stampSlot(p, 1), (k_spreadOwn<Real, FX>), dim3(nbricks * p.ownSlabs), dim3(512), ldsOwn, s, p); }
     // a long mesh in double precision gives a 256-thread work-group a dozen 16-byte chunks per thread, each three rounds of dependent loads
     // (c5, 180^3: 309 us): 512 threads there
     const bool wideMerge = (size_t)cx * cy * (p.d.nz / chunk) > 6 * 256;
 #define SNB_MERGE(FX, FZ, A, B) { if (wideMerge) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadMerge<Real, FX, FZ, A, B, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FZ ? ldsFft : 0)); \
-                                      SNB_STAMPED_LAUNCH(stampSlot(p, 2), (k_spreadMerge<Real, FX, FZ, A, B, 512>), dim3(nbricks), dim3(512), (FZ ? ldsFft : 0), s, p, chunk); } \
+                                      SNB_STAMPED_LAUNCH(stampSlot(p, 2), (k_spreadMerge<Real, FX, FZ, A, B, 512>), dim3(nbricks), dim3(512), (FZ ? ldsFft : 0), s, p, chunk, plane); } \
                                   else { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadMerge<Real, FX, FZ, A, B, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FZ ? ldsFft : 0)); \
-                                      SNB_STAMPED_LAUNCH(stampSlot(p, 2), (k_spreadMerge<Real, FX, FZ, A, B, 256>), dim3(nbricks), dim3(256), (FZ ? ldsFft : 0), s, p, chunk); } }
+                                      SNB_STAMPED_LAUNCH(stampSlot(p, 2), (k_spreadMerge<Real, FX, FZ, A, B, 256>), dim3(nbricks), dim3(256), (FZ ? ldsFft : 0), s, p, chunk, plane); } }
     bool done = false;
     if constexpr (std::is_same<Real, float>::value) {
         if (fixed) {
@@ -1366,7 +1679,7 @@ template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hi
     }
 #undef SNB_OWN
 #undef SNB_MERGE
-    return fuse ? 1 : 0;
+    return plane ? 2 : (fuse ? 1 : 0);
 }
 
 static size_t ldsBudget() { return 96 * 1024; }
@@ -1804,8 +2117,8 @@ template <typename Real> bool launchPmeInterpolate(const PmeParams<Real>& p, hip
     return false;
 }
 
-template bool launchPmeSpread<float>(const PmeParams<float>&, hipStream_t);
-template bool launchPmeSpread<double>(const PmeParams<double>&, hipStream_t);
+template int launchPmeSpread<float>(const PmeParams<float>&, hipStream_t);
+template int launchPmeSpread<double>(const PmeParams<double>&, hipStream_t);
 template void launchPmeForwardFFT<float>(const PmeParams<float>&, hipStream_t, bool);
 template void launchPmeForwardFFT<double>(const PmeParams<double>&, hipStream_t, bool);
 template void launchPmeConvolution<float>(const PmeParams<float>&, hipStream_t);
