@@ -175,6 +175,7 @@ template <typename Real> struct PmePlan {
     DevBuf<Real> gridReal;
     DevBuf<typename Vec<Real>::T2> gridCplx, gridCplxB, twx, twy, twz;      // (gridCplxB: second complex mesh of the plane path, single precision)
     DevBuf<Real> modx, mody, modz;
+    DevBuf<Real> planeEterm; bool planeEtermReady = false;      // plane path: kernel-value table, refilled at every rebuild (box, alpha)
     // own-atoms spreader (pme.hip k_spreadOwn / k_spreadMerge): geometry and buffers, sized at rebuild time
     int ownSlabs = 0, ownMargin = 1; DevBuf<unsigned char> ownPartial; DevBuf<int> ownBusy; DevBuf<int2> strays;
     void init(const int g[3], int nGrids, hipStream_t s) {
@@ -192,7 +193,7 @@ template <typename Real> struct PmePlan {
         if (sizeof(Real) == 8 && std::max(d.rx1, d.rx2) > 12 && !getenv("SNB_FFT_TWOPASS")) d.rx1 = d.rx2 = 0;
         gridReal.resize((size_t)nGrids * d.nx * d.ny * d.nz);
         gridCplx.resize((size_t)nGrids * d.nx * d.ny * d.nzc);
-        if (sizeof(Real) == 4 && d.nx == d.ny && d.nx <= 144) gridCplxB.resize((size_t)nGrids * d.nx * d.ny * d.nzc);
+        if (sizeof(Real) == 4 && d.nx == d.ny && d.nx <= 144) { gridCplxB.resize((size_t)nGrids * d.nx * d.ny * d.nzc); planeEterm.resize((size_t)d.nx * d.ny * d.nzc); planeEtermReady = false; }
         auto tw = [&](int n, DevBuf<typename Vec<Real>::T2>& buf) {
             std::vector<typename Vec<Real>::T2> h(n);
             for (int k = 0; k < n; k++) { double a = -2.0 * SNB_PI * k / n; h[k].x = (Real)std::cos(a); h[k].y = (Real)std::sin(a); }
@@ -528,7 +529,7 @@ public:
         gpuBuilt = false;
         if (cfg.host_neighbor_build || !gpuRebuild()) hostRebuild();
         pmeCells.resize(Npad);   // per-slot scratch is sized here: nothing may allocate while a step is being captured into a graph
-        if (isPme()) { if (!dStrayCount.p) { dStrayCount.resize(2); HIPCHECK(hipMemsetAsync(dStrayCount.p, 0, 2 * sizeof(int), stream)); } planOwnSpread(pme); if (cfg.method == SNB_LJPME) planOwnSpread(dpme); }
+        if (isPme()) { if (!dStrayCount.p) { dStrayCount.resize(2); HIPCHECK(hipMemsetAsync(dStrayCount.p, 0, 2 * sizeof(int), stream)); } planOwnSpread(pme); if (cfg.method == SNB_LJPME) planOwnSpread(dpme); planPlaneTable(pme); if (cfg.method == SNB_LJPME) planPlaneTable(dpme); }
         posRef.resize(Npad);
         HIPCHECK(hipMemcpyAsync(posRef.p, posq.p, sizeof(T4) * (size_t)Npad, hipMemcpyDeviceToDevice, stream));
         if (hDispFlags[1]) listOverruns++;      // an atom had moved more than skin/2 before this rebuild came
@@ -1139,7 +1140,7 @@ public:
         { static const bool tr = getenv("SNB_PME_TRACE") != nullptr; if (tr) { if (!dPmeTrace.p) { dPmeTrace.resize(8); HIPCHECK(hipMemset(dPmeTrace.p, 0, 64)); } p.trace = dPmeTrace.p; } }
         p.cellsReady = (!plan.dispersion && cellsFromGather) ? 1 : 0;
         p.fixDev = dFixScale.p ? dFixScale.p + (plan.dispersion ? 2 : 0) : nullptr;      // (k_fixScale keeps it in step with the parameters)
-        p.gridReal = plan.gridReal.p; p.gridCplx = plan.gridCplx.p; p.planeB = plan.gridCplxB.p; p.twx = plan.twx.p; p.twy = plan.twy.p; p.twz = plan.twz.p;
+        p.gridReal = plan.gridReal.p; p.gridCplx = plan.gridCplx.p; p.planeB = plan.gridCplxB.p; p.planeEterm = plan.planeEtermReady ? plan.planeEterm.p : nullptr; p.twx = plan.twx.p; p.twy = plan.twy.p; p.twz = plan.twz.p;
         p.modx = plan.modx.p; p.mody = plan.mody.p; p.modz = plan.modz.p;
         const double det = box[0] * box[4] * box[8], sc = 1.0 / det;
         const double r[9] = {box[4] * box[8] * sc, 0, 0, -box[3] * box[8] * sc, box[0] * box[8] * sc, 0,
@@ -1178,6 +1179,15 @@ public:
     // Geometry and buffers of the own-atoms spreader for one mesh (called from rebuild(): nothing may allocate inside a graph capture).
     // Margin: the cells an atom can drift across its column's border during a list's life (skin / 2), at least one; slabs: the fewest that
     // bring a work-group's LDS region under 40 KB (four work-groups per CU), at least two.
+    // Plane path (pme.hip k_planeXY): its table of reciprocal-space kernel values follows the box and alpha, both fixed between rebuilds.
+    void planPlaneTable(PmePlan<Real>& plan) {
+        plan.planeEtermReady = false;
+        if (!plan.planeEterm.p || !plan.gridCplxB.p || nGrids <= 0) return;
+        PmeParams<Real> pp; std::memset(&pp, 0, sizeof(pp));
+        fillPme(pp, plan, false);
+        launchPlaneEterm<Real>(pp, plan.planeEterm.p, stream);
+        plan.planeEtermReady = true;
+    }
     void planOwnSpread(PmePlan<Real>& plan) {
         plan.ownSlabs = 0;
         int ncx, ncy, gx, gy;

@@ -1360,12 +1360,18 @@ __device__ __forceinline__ void planePass(Cx<Real>* P, const int lines, const in
 }
 struct PlaneNoScale { template <typename... A> __device__ float operator()(A...) const { return 1.0f; } };
 
-#ifndef SNB_PLANE_EXP
-#define SNB_PLANE_EXP 0
-#endif
-template <int R1, int R2> __global__ __launch_bounds__(1024) void k_planeXY(const PmeParams<float> p) {
+// The reciprocal-space kernel value of every plane position, in the permuted order the in-place forward passes leave (position q of an
+// axis holds frequency q / R2 + R1 (q % R2)): [kz][px][py], filled at rebuild time (the box and alpha are fixed between rebuilds).
+template <typename Real> __global__ __launch_bounds__(256) void k_planeEterm(const PmeParams<Real> p, Real* table, const int R1, const int R2) {
+    const int nx = p.d.nx, ny = p.d.ny;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)p.d.nzc * nx * ny) return;
+    const int py = (int)(i % ny), px = (int)((i / ny) % nx), kz = (int)(i / ((size_t)nx * ny));
+    table[i] = recipTerm<Real>(p, px / R2 + R1 * (px % R2), py / R2 + R1 * (py % R2), kz);
+}
+
+template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeXY(const PmeParams<float> p) {
     using Real = float;
-    constexpr int NT = 1024;
     const int nx = p.d.nx, ny = p.d.ny, nzc = p.d.nzc;      // launcher: nx == ny == R1 * R2
     const int PY = ny | 1;                                  // odd pitch: lanes along x (stride PY) and lanes along y (stride 1) are both conflict-free
     const int slot = blockIdx.x / nzc, kz = blockIdx.x - slot * nzc;
@@ -1380,11 +1386,7 @@ template <int R1, int R2> __global__ __launch_bounds__(1024) void k_planeXY(cons
     const FastDiv dny(ny);
     const int nPairs = (int)(planeElems >> 1);                         // ny is even (launcher): 16-byte loads never straddle a row
     batchedCopy<8, float4>(tid, nPairs, NT,
-        [&](int e) {
-#if SNB_PLANE_EXP & 1
-            return make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-            return reinterpret_cast<const float4*>(in)[e]; },
+        [&](int e) { return reinterpret_cast<const float4*>(in)[e]; },
         [&](int e, const float4& v) { const int x = dny.div(2 * e), y = 2 * e - x * ny; P[x * PY + y] = {v.x, v.y}; P[x * PY + y + 1] = {v.z, v.w}; });
     __syncthreads();
     // forward y (lines = x rows, elements along y), forward x (lines = y columns, elements along x, stride PY)
@@ -1396,14 +1398,11 @@ template <int R1, int R2> __global__ __launch_bounds__(1024) void k_planeXY(cons
     __syncthreads();
     planePass<Real, R2, -1, 0, false>(P, ny, 1, PY, R1, tw, tid, NT, PlaneNoScale());
     __syncthreads();
-    // position q of an axis now holds frequency (q / R2) + R1 * (q % R2); the kernel value is applied while the first inverse pass loads
-    const FastDiv dr2(R2);
+    // position q of an axis now holds frequency (q / R2) + R1 * (q % R2); the kernel value (tabulated in that order) is applied while the
+    // first inverse pass loads
+    const Real* et = p.planeEterm + (size_t)kz * planeElems;
     planePass<Real, R2, +1, 0, false>(P, ny, 1, PY, R1, tw, tid, NT,
-        [&](int line, int pos) {
-#if SNB_PLANE_EXP & 4
-            return 1.0f;
-#endif
-            const int a = dr2.div(line), b = dr2.div(pos); return recipTerm<Real>(p, b + R1 * (pos - b * R2), a + R1 * (line - a * R2), kz); });
+        [&](int line, int pos) { return et[pos * ny + line]; });
     __syncthreads();
     planePass<Real, R1, +1, 2, true>(P, ny, 1, PY, R2, tw, tid, NT, PlaneNoScale());
     __syncthreads();
@@ -1413,15 +1412,11 @@ template <int R1, int R2> __global__ __launch_bounds__(1024) void k_planeXY(cons
     __syncthreads();
     batchedCopy<8, float4>(tid, nPairs, NT,
         [&](int e) { const int x = dny.div(2 * e), y = 2 * e - x * ny; const Cx<Real> a = P[x * PY + y], b = P[x * PY + y + 1]; return make_float4(a.x, a.y, b.x, b.y); },
-        [&](int e, const float4& v) {
-#if SNB_PLANE_EXP & 2
-            return;
-#endif
-            reinterpret_cast<float4*>(out)[e] = v; });
+        [&](int e, const float4& v) { reinterpret_cast<float4*>(out)[e] = v; });
     // per-slice energies (ReferencePME.cpp:487-491): E_IJ = sum_k eterm Re(S_I conj S_J) over the full mesh (1/2 on the diagonal), here as
     // sum over the plane of Re(Q~_I conj psi~_J), Hermitian weight 2 for interior kz; this work-group holds psi~_J, J = its slot, and takes the
     // pairs I >= J
-    if (p.wantEnergy && p.mix && !(SNB_PLANE_EXP & 8)) {
+    if (p.wantEnergy && p.mix) {
         const int term = p.dispersion ? 1 : 0;
         const int gj = p.gridSubset[slot];
         const double w = (kz == 0 || 2 * kz == p.d.nz) ? 1.0 : 2.0;
@@ -1583,7 +1578,7 @@ template <typename Real> static void launchConvolveX(int r1, int r2, dim3 grid, 
 template <typename Real> static size_t planeLds(const PmeParams<Real>& p) { return sizeof(Cx<Real>) * ((size_t)p.d.nx * (p.d.ny | 1) + p.d.nx); }
 template <typename Real> static bool planePathOK(const PmeParams<Real>& p) {
     static const bool off = getenv("SNB_NO_PLANE_FFT") != nullptr;      // test switch: the three-kernel y / x / y pipeline
-    if (off || !std::is_same<Real, float>::value || !p.planeB) return false;
+    if (off || !std::is_same<Real, float>::value || !p.planeB || !p.planeEterm) return false;
     if (p.d.nx != p.d.ny || (p.d.ny & 1) || p.d.rx1 <= 0 || p.d.rx1 != p.d.ry1 || p.d.rx2 != p.d.ry2 || p.d.rx1 * p.d.rx2 != p.d.nx) return false;
     if (p.nsub > 8 || planeLds(p) > 156 * 1024) return false;
     bool inst = false;
@@ -1595,8 +1590,13 @@ template <typename Real> static bool planePathOK(const PmeParams<Real>& p) {
 static void launchPlaneXY(const PmeParams<float>& p, hipStream_t s) {
     const size_t lds = planeLds(p);
     const dim3 grid((unsigned)(p.nsub * p.d.nzc));
-#define X(A, B) if (p.d.rx1 == A && p.d.rx2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_planeXY<A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_planeXY<A, B>), grid, dim3(1024), lds, s, p); return; }
+    static const int nt = getenv("SNB_PLANE_NT") ? atoi(getenv("SNB_PLANE_NT")) : 1024;      // threads per plane: 1024 or 768
+#define X(A, B) if (p.d.rx1 == A && p.d.rx2 == B) { \
+        if (nt == 768) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_planeXY<A, B, 768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                         SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_planeXY<A, B, 768>), grid, dim3(768), lds, s, p); } \
+        else { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_planeXY<A, B, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+               SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_planeXY<A, B, 1024>), grid, dim3(1024), lds, s, p); } \
+        return; }
     SNB_PLANE_PAIRS(X)
 #undef X
 }
@@ -1614,6 +1614,15 @@ static void launchFftZInvMix(const PmeParams<float>& p, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZInvMix<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SNB_STAMPED_LAUNCH(stampSlot(p, 6), (k_fftZInvMix<0, 0>), grid, dim3(256), lds, s, p, NBY);
 }
+// Rebuild time: the kernel-value table of the plane path (no-op when the mesh does not qualify).
+template <typename Real> void launchPlaneEterm(const PmeParams<Real>& p, Real* table, hipStream_t s) {
+    PmeParams<Real> q = p; q.planeEterm = table;
+    if (!table || !planePathOK<Real>(q)) return;
+    const size_t n = (size_t)p.d.nzc * p.d.nx * p.d.ny;
+    hipLaunchKernelGGL((k_planeEterm<Real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, table, p.d.rx1, p.d.rx2);
+}
+template void launchPlaneEterm<float>(const PmeParams<float>&, float*, hipStream_t);
+template void launchPlaneEterm<double>(const PmeParams<double>&, double*, hipStream_t);
 // The middle of the pipeline on the plane path (after a spreader that returned 2): convolution + x / y transforms per plane, then mix + inverse z.
 template <typename Real> void launchPmePlanePath(const PmeParams<Real>& p, hipStream_t s) {
     if constexpr (std::is_same<Real, float>::value) {

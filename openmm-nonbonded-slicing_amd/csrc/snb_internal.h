@@ -130,6 +130,7 @@ template <typename Real> struct PmeParams {
     int* cells;               // [Npad] scratch: packed mesh cell per atom (k_pmeCells), brick spreader only
     Real* gridReal;           // [nsub][nx][ny][nz]
     typename Vec<Real>::T2* gridCplx;   // [nsub][nx][ny][nzc]  (plane path: [nsub][nzc][nx][ny], the z-transformed charges)
+    const Real* planeEterm;             // plane path: reciprocal-space kernel values [nzc][nx][ny] in the permuted order of the in-place transforms (filled at rebuild time)
     typename Vec<Real>::T2* planeB;     // plane path (pme.hip k_planeXY): [nsub][nzc][nx][ny] convolved potentials before the lambda mix; null: path off
     const typename Vec<Real>::T2* twx; const typename Vec<Real>::T2* twy; const typename Vec<Real>::T2* twz;   // roots of unity exp(-2 pi i k/n)
     const Real* modx; const Real* mody; const Real* modz;       // B-spline moduli
@@ -222,6 +223,7 @@ template <typename Real> bool launchDirect(const DirectParams<Real>& p, int meth
                                           hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, bool* timed = nullptr);   // true: lists ran inside the launch
 template <typename Real> void launchPairLists(const PairListParams<Real>& p, bool energy, hipStream_t s);
 template <typename Real> int launchPmeSpread(const PmeParams<Real>& p, hipStream_t s);   // 1: forward z FFT already done; 2: ... and the spectrum is plane-major (plane path)
+template <typename Real> void launchPlaneEterm(const PmeParams<Real>& p, Real* table, hipStream_t s);   // rebuild time: fills the plane path's kernel-value table
 template <typename Real> void launchPmePlanePath(const PmeParams<Real>& p, hipStream_t s);   // after a spreader that returned 2: k_planeXY + k_fftZInvMix instead of forward FFT, convolution, inverse FFT
 template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s, bool zDone);
 template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hipStream_t s);   // fused x-FFT, energy, convolution, inverse x-FFT
