@@ -964,3 +964,66 @@ def test_spreading_follows_drifting_atoms(env, expect_strays, method, dgrid, pre
         assert res["2"]["strays"] > 0, res
     elif not env:
         assert res["2"]["strays"] == 0, res
+
+
+_PLANE_SCRIPT = r'''
+import sys, json
+import numpy as np, torch, importlib
+sys.path[:0] = [ROOT, ROOT + "/tests", ROOT + "/oracle"]
+import bench
+snb = importlib.import_module("openmm-nonbonded-slicing_amd")
+method, grid, dgrid, nsub = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+w = bench.build_workload(24000, 6.2145, nsub, np.random.default_rng(bench.SEED))
+n = len(w["q"])
+eng = bench.Engine(snb, w, method, grid, dgrid, "single", 0, 0, 1, 0.1, 1 << 30)
+eng.set_timing_interval(1)                       # every step eager with per-kernel stamps: the stamp slots tell which pipeline ran
+pt = torch.tensor(w["pos"], dtype=torch.float32, device="cuda")
+forces = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+eng.set_positions_device(pt.data_ptr(), False)
+eng.execute(True); eng.forces_to(forces.data_ptr(), False); eng.sync()
+fe = forces.double().cpu().numpy(); se = eng.slice_energies(nsub * (nsub + 1) // 2)
+for _ in range(6):
+    eng.execute(False)                           # forces-only steps
+eng.forces_to(forces.data_ptr(), False); eng.sync()
+ff = forces.double().cpu().numpy()
+w2 = dict(w); w2["pos"] = np.ascontiguousarray(pt.double().cpu().numpy())
+fo, so, _, _ = bench.oracle_eval(w2, method, grid, dgrid)
+st = eng.stats()
+rel = lambda f: float(np.max(np.linalg.norm(f - fo, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0)))
+print("RESULT " + json.dumps(dict(ferr_energy_step=rel(fe), ferr_forces_step=rel(ff), eerr=float(np.max(np.abs(se - so) / np.maximum(np.abs(so), 1.0))),
+                                  timed=[int(x) for x in st.n_kernel_timed], host_rebuilds=int(st.n_host_rebuilds))))
+'''
+
+
+@pytest.mark.parametrize("method,grid,dgrid,nsub", [(4, 54, 0, 4), (4, 42, 0, 3), (4, 64, 0, 2), (4, 54, 0, 1), (4, 54, 0, 5), (4, 48, 0, 8), (5, 54, 54, 4)],
+                         ids=["pme54_n4", "pme42_n3", "pme64_n2", "pme54_n1", "pme54_n5", "pme48x_n8", "ljpme54_54_n4"])
+def test_plane_path_and_three_pass_pipeline_agree_with_the_oracle(method, grid, dgrid, nsub, snb):
+    """Round 3: on square single-precision meshes whose (subset, kz) plane fits LDS the reciprocal pipeline runs k_planeXY (FFT_y, FFT_x,
+    kernel value, inverse FFT_x / FFT_y of one plane in LDS, slice energies by Parseval over the plane) and k_fftZInvMix (lambda mix on the
+    matrix cores + inverse z FFT) instead of the y pass, k_convolveX and the inverse y / z passes.  Both pipelines (SNB_NO_PLANE_FFT=1
+    selects the old one; switches are read once per process: child processes) must meet the oracle on forces and slice energies, for an
+    odd number of subsets (one line of a pair empty), for more than four (two groups of matrix-core output rows), for one subset, for the
+    dispersion mesh of LJPME, and the stamp slots must show which pipeline ran (slots 3 / 5 are the y passes).  A 48^3 mesh (6 x 8 is not an
+    instantiated split) stays on the old pipeline either way."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for tag, env in (("plane", {}), ("three_pass", {"SNB_NO_PLANE_FFT": "1"})):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _PLANE_SCRIPT, str(method), str(grid), str(dgrid), str(nsub)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+        got[tag] = res
+        assert res["host_rebuilds"] == 0
+        assert res["ferr_energy_step"] < 1e-3 and res["ferr_forces_step"] < 1e-3 and res["eerr"] < 1e-3, (tag, res)
+    plane_expected = grid in (42, 54, 64)
+    t = got["plane"]["timed"]
+    assert t[4] > 0 and t[6] > 0, t
+    assert (t[3] == 0 and t[5] == 0) == plane_expected, ("y-pass stamps", t)
+    if method == 5 and plane_expected:
+        assert (t[8 + 3] == 0 and t[8 + 5] == 0) == (dgrid in (42, 54, 64)), ("dispersion mesh", t)
+    t = got["three_pass"]["timed"]
+    assert t[3] > 0 and t[5] > 0, t
