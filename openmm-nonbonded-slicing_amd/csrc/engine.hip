@@ -193,7 +193,8 @@ template <typename Real> struct PmePlan {
         if (sizeof(Real) == 8 && std::max(d.rx1, d.rx2) > 12 && !getenv("SNB_FFT_TWOPASS")) d.rx1 = d.rx2 = 0;
         gridReal.resize((size_t)nGrids * d.nx * d.ny * d.nz);
         gridCplx.resize((size_t)nGrids * d.nx * d.ny * d.nzc);
-        if (sizeof(Real) == 4 && d.nx == d.ny && d.nx <= 144) { gridCplxB.resize((size_t)nGrids * d.nx * d.ny * d.nzc); planeEterm.resize((size_t)d.nx * d.ny * d.nzc); planeEtermReady = false; }
+        if (sizeof(Real) == 4 && d.nx == d.ny && d.nx <= 144) { gridCplxB.resize((size_t)nGrids * d.nx * (d.ny + 8) * d.nzc);      // (y padded to whole tiles of the inverse z kernel)
+             planeEterm.resize((size_t)d.nx * d.ny * d.nzc); planeEtermReady = false; }
         auto tw = [&](int n, DevBuf<typename Vec<Real>::T2>& buf) {
             std::vector<typename Vec<Real>::T2> h(n);
             for (int k = 0; k < n; k++) { double a = -2.0 * SNB_PI * k / n; h[k].x = (Real)std::cos(a); h[k].y = (Real)std::sin(a); }

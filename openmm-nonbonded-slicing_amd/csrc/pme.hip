@@ -1370,7 +1370,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_planeEterm(con
     table[i] = recipTerm<Real>(p, px / R2 + R1 * (px % R2), py / R2 + R1 * (py % R2), kz);
 }
 
-template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeXY(const PmeParams<float> p) {
+template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeXY(const PmeParams<float> p, const int NBY) {
     using Real = float;
     const int nx = p.d.nx, ny = p.d.ny, nzc = p.d.nzc;      // launcher: nx == ny == R1 * R2
     const int PY = ny | 1;                                  // odd pitch: lanes along x (stride PY) and lanes along y (stride 1) are both conflict-free
@@ -1381,7 +1381,11 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeX
     const int tid = threadIdx.x;
     const size_t planeElems = (size_t)nx * ny;
     const Cx<Real>* in = reinterpret_cast<const Cx<Real>*>(p.gridCplx) + ((size_t)slot * nzc + kz) * planeElems;
-    Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.planeB) + ((size_t)slot * nzc + kz) * planeElems;
+    // convolved plane: written in the order the inverse z kernel reads, [x][y tile][slot][kz][NBY] (its lines of one work-group are contiguous)
+    Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.planeB) + ((size_t)slot * nzc + kz) * NBY;
+    const int tilesY = (ny + NBY - 1) / NBY;
+    const size_t tileStride = (size_t)p.nsub * nzc * NBY;
+    const FastDiv dNBY(NBY);
     for (int k = tid; k < nx; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twx)[k];
     const FastDiv dny(ny);
     const int nPairs = (int)(planeElems >> 1);                         // ny is even (launcher): 16-byte loads never straddle a row
@@ -1412,7 +1416,7 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeX
     __syncthreads();
     batchedCopy<8, float4>(tid, nPairs, NT,
         [&](int e) { const int x = dny.div(2 * e), y = 2 * e - x * ny; const Cx<Real> a = P[x * PY + y], b = P[x * PY + y + 1]; return make_float4(a.x, a.y, b.x, b.y); },
-        [&](int e, const float4& v) { reinterpret_cast<float4*>(out)[e] = v; });
+        [&](int e, const float4& v) { const int x = dny.div(2 * e), y = 2 * e - x * ny, t = dNBY.div(y); *reinterpret_cast<float4*>(out + ((size_t)x * tilesY + t) * tileStride + (y - t * NBY)) = v; });
     // per-slice energies (ReferencePME.cpp:487-491): E_IJ = sum_k eterm Re(S_I conj S_J) over the full mesh (1/2 on the diagonal), here as
     // sum over the plane of Re(Q~_I conj psi~_J), Hermitian weight 2 for interior kz; this work-group holds psi~_J, J = its slot, and takes the
     // pairs I >= J
@@ -1463,9 +1467,8 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeX
 // imaginary part as two accumulation chains; up to 8 subsets, two groups of four output rows), packs subsets 2m and 2m+1 as the real and
 // imaginary line of one complex transform (Z = A + iB with A, B Hermitian) and runs the inverse z FFT into the real mesh [slot][x][y][z]
 // the interpolation reads.  mix == 0 (sharded engines): no mix, the subsets' own potentials.
-template <int R1, int R2> __global__ __launch_bounds__(256) void k_fftZInvMix(const PmeParams<float> p, const int NBY) {
+template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_fftZInvMix(const PmeParams<float> p, const int NBY) {
     using Real = float;
-    constexpr int NT = 256;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc, nsub = p.nsub;
     const int NP = (nsub + 1) >> 1;                                      // complex transforms per y: subsets (2m, 2m+1)
@@ -1494,16 +1497,16 @@ template <int R1, int R2> __global__ __launch_bounds__(256) void k_fftZInvMix(co
             }
             aReg[g][J] = v;
         }
-    const size_t planeElems = (size_t)nx * ny, subStride = (size_t)nzc * planeElems;
-    const Cx<Real>* src = reinterpret_cast<const Cx<Real>*>(p.planeB) + (size_t)x * ny + y0;
-    const int nPts = nzc * nby;
-    const FastDiv dnby(nby);
+    const size_t subStride = (size_t)nzc * NBY;                          // [x][y tile][slot][kz][NBY]: this work-group's lines are one contiguous block
+    const Cx<Real>* src = reinterpret_cast<const Cx<Real>*>(p.planeB) + (size_t)blockIdx.x * nsub * subStride;
+    const int nPts = nzc * NBY;
+    const FastDiv dNBY(NBY);
     const int nG = (nsub + 3) >> 2;
     for (int p0 = 64 * wave; p0 < nPts; p0 += NT) {      // (uniform trip count per wave: the matrix-core instructions run with every lane)
         const int pt = p0 + lane;
-        const bool valid = pt < nPts;
-        const int kz = dnby.div(valid ? pt : 0), yy = (valid ? pt : 0) - kz * nby;
-        const Cx<Real>* s0 = src + (size_t)kz * planeElems + yy;
+        const int kz = dNBY.div(pt < nPts ? pt : 0), yy = (pt < nPts ? pt : 0) - kz * NBY;
+        const bool valid = pt < nPts && yy < nby;
+        const Cx<Real>* s0 = src + (valid ? pt : 0);
         Cx<Real> v[8];
 #pragma unroll
         for (int J = 0; J < 8; J++) { v[J] = {0.f, 0.f}; if (valid && J < nsub) v[J] = s0[J * subStride]; }
@@ -1587,32 +1590,42 @@ template <typename Real> static bool planePathOK(const PmeParams<Real>& p) {
 #undef X
     return inst;
 }
+// y lines per work-group of the inverse z kernel = tile of the convolved planes' layout (c4, 8 subsets: plane + z kernel 45.5 + 55.0 us with 8, 61.2 + 42.4 with 4: 32-byte runs in the plane kernel's store)
+static int planeTileY(const PmeParams<float>& p) {
+    static const int env = getenv("SNB_ZMIX_NBY") ? atoi(getenv("SNB_ZMIX_NBY")) : 0;
+    return (env == 2 || env == 4 || env == 8) ? env : 8;
+}
 static void launchPlaneXY(const PmeParams<float>& p, hipStream_t s) {
     const size_t lds = planeLds(p);
+    const int NBY = planeTileY(p);
     const dim3 grid((unsigned)(p.nsub * p.d.nzc));
     static const int nt = getenv("SNB_PLANE_NT") ? atoi(getenv("SNB_PLANE_NT")) : 1024;      // threads per plane: 1024 or 768
 #define X(A, B) if (p.d.rx1 == A && p.d.rx2 == B) { \
         if (nt == 768) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_planeXY<A, B, 768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                         SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_planeXY<A, B, 768>), grid, dim3(768), lds, s, p); } \
+                         SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_planeXY<A, B, 768>), grid, dim3(768), lds, s, p, NBY); } \
         else { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_planeXY<A, B, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-               SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_planeXY<A, B, 1024>), grid, dim3(1024), lds, s, p); } \
+               SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_planeXY<A, B, 1024>), grid, dim3(1024), lds, s, p, NBY); } \
         return; }
     SNB_PLANE_PAIRS(X)
 #undef X
 }
 static void launchFftZInvMix(const PmeParams<float>& p, hipStream_t s) {
-    static const int nbyEnv = getenv("SNB_ZMIX_NBY") ? atoi(getenv("SNB_ZMIX_NBY")) : 8;
     const int NP = (p.nsub + 1) / 2;
-    int NBY = std::max(1, std::min(nbyEnv, p.d.ny));
-    while (NBY > 1 && sizeof(Cx<float>) * ((size_t)2 * p.d.nz * (NBY * NP + 1) + p.d.nz) > 64 * 1024) NBY >>= 1;
+    const int NBY = planeTileY(p);
     const size_t lds = sizeof(Cx<float>) * ((size_t)2 * p.d.nz * (NBY * NP + 1) + p.d.nz);
     const dim3 grid((unsigned)(p.d.nx * ((p.d.ny + NBY - 1) / NBY)));
-#define X(A, B) if (p.d.rz1 == A && p.d.rz2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZInvMix<A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        SNB_STAMPED_LAUNCH(stampSlot(p, 6), (k_fftZInvMix<A, B>), grid, dim3(256), lds, s, p, NBY); return; }
+    static const int ntEnv = getenv("SNB_ZMIX_NT") ? atoi(getenv("SNB_ZMIX_NT")) : 0;
+    const bool wide = ntEnv ? ntEnv == 512 : NBY * NP >= 24;      // 24+ complex transforms per work-group (5-8 subsets): 512 threads
+#define X(A, B) if (p.d.rz1 == A && p.d.rz2 == B) { \
+        if (wide) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZInvMix<A, B, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                    SNB_STAMPED_LAUNCH(stampSlot(p, 6), (k_fftZInvMix<A, B, 512>), grid, dim3(512), lds, s, p, NBY); } \
+        else { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZInvMix<A, B, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+               SNB_STAMPED_LAUNCH(stampSlot(p, 6), (k_fftZInvMix<A, B, 256>), grid, dim3(256), lds, s, p, NBY); } \
+        return; }
     SNB_FFT_PAIRS(X)
 #undef X
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZInvMix<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    SNB_STAMPED_LAUNCH(stampSlot(p, 6), (k_fftZInvMix<0, 0>), grid, dim3(256), lds, s, p, NBY);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fftZInvMix<0, 0, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SNB_STAMPED_LAUNCH(stampSlot(p, 6), (k_fftZInvMix<0, 0, 256>), grid, dim3(256), lds, s, p, NBY);
 }
 // Rebuild time: the kernel-value table of the plane path (no-op when the mesh does not qualify).
 template <typename Real> void launchPlaneEterm(const PmeParams<Real>& p, Real* table, hipStream_t s) {
