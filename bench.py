@@ -539,10 +539,18 @@ def main():
             else:
                 add(off + 1, "k_spreadOwn (atoms -> per-work-group regions)" + tag, N * (4 * r + 4))
                 add(off + 2, "k_spreadMerge (regions -> mesh, + forward z FFT)" + tag, nheld * Ghm * 2 * r)
-            add(off + 3, "k_fftStrided (y, forward)" + tag, nheld * Ghm * 4 * r)
-            add(off + 4, "k_convolveX (x FFT + slice energies + lambda mix + inverse x FFT)" + tag, nheld * Ghm * 4 * r)
-            add(off + 5, "k_fftStrided (y, inverse)" + tag, nheld * Ghm * 4 * r)
-            add(off + 6, "k_fftZ inverse" + tag, nheld * (Gm * r + Ghm * 2 * r))
+            # plane path (square single-precision meshes whose (subset, kz) plane fits LDS): no y passes were stamped -- k_planeXY does
+            # FFT_y, FFT_x, the convolution and both inverses of a plane in LDS (one read and one write of the complex meshes, + the kernel
+            # table), k_fftZInvMix mixes on the matrix cores and runs the inverse z FFT
+            plane = int(stx.n_kernel_timed[off + 3]) == 0 and int(stx.n_kernel_timed[off + 5]) == 0 and int(stx.n_kernel_timed[off + 4]) > 0
+            if plane:
+                add(off + 4, "k_planeXY (FFT_y + FFT_x + convolution + slice energies + inverse FFT_x + FFT_y, one (subset, kz) plane in LDS)" + tag, nheld * Ghm * 4 * r + Ghm * r)
+                add(off + 6, "k_fftZInvMix (lambda mix on the matrix cores + inverse z FFT)" + tag, nheld * (Gm * r + Ghm * 2 * r))
+            else:
+                add(off + 3, "k_fftStrided (y, forward)" + tag, nheld * Ghm * 4 * r)
+                add(off + 4, "k_convolveX (x FFT + slice energies + lambda mix + inverse x FFT)" + tag, nheld * Ghm * 4 * r)
+                add(off + 5, "k_fftStrided (y, inverse)" + tag, nheld * Ghm * 4 * r)
+                add(off + 6, "k_fftZ inverse" + tag, nheld * (Gm * r + Ghm * 2 * r))
             add(off + 7, "k_interpolateBricks (+ user-order force write)" + tag, N * (4 * r + 3 * r + 4 + 3 * r + 3 * r) + nheld * Gm * r)
         return rows
 

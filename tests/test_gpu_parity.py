@@ -1019,6 +1019,8 @@ def test_plane_path_and_three_pass_pipeline_agree_with_the_oracle(method, grid, 
         got[tag] = res
         assert res["host_rebuilds"] == 0
         assert res["ferr_energy_step"] < 1e-3 and res["ferr_forces_step"] < 1e-3 and res["eerr"] < 1e-3, (tag, res)
+    if any(k in os.environ for k in ("SNB_NO_FUSED_Z", "SNB_NO_OWN_SPREAD", "SNB_FFT_TWOPASS", "SNB_NO_PLANE_FFT")):
+        return      # (tools/switch_matrix.sh: these switches take the plane path's front end away -- parity above is all there is to check)
     plane_expected = grid in (42, 54, 64)
     t = got["plane"]["timed"]
     assert t[4] > 0 and t[6] > 0, t
