@@ -12,6 +12,6 @@ for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0][:60]
     a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, v in acc.items():
-    if any(x in k for x in ("k_direct", "k_spread", "k_interp", "k_conv", "k_fft", "k_nbBuild")):
+    if any(x in k for x in ("k_direct", "k_spread", "k_interp", "k_conv", "k_fft", "k_plane", "k_nbBuild")):
         print(k, {c: round(a[0] / a[1]) for c, a in v.items()})
 PY
