@@ -182,6 +182,8 @@ BIG_CASES = [
     ("pme_oddgrid45_13824_n3", 13824, 3, 4, 6.0, (2.6283, 45, 45, 45), None),                       # odd nz: f64 LDS accumulation, odd-length z pairs
     ("ljpme_grids48_24_13824_n3", 13824, 3, 5, 6.0, (2.6283, 48, 48, 48), (2.6283, 24, 24, 24)),    # dispersion mesh: bricks of column groups
     ("pme_grid54_13824_n4", 13824, 4, 4, 6.0, (2.6283, 54, 54, 54), None),                          # 54 = 6 x 9 two-pass FFT split
+    ("pme_grid54x54x50_13824_n3", 13824, 3, 4, 6.0, (2.6283, 54, 54, 50), None),                    # plane path (square 54 x 54 planes) with a z length that has no two-pass split: staged inverse z FFT behind the mix
+    ("pme_grid54x60x54_13824_n2", 13824, 2, 4, 6.0, (2.6283, 54, 60, 54), None),                    # non-square planes: the three-pass pipeline
 ]
 
 
@@ -398,7 +400,7 @@ def test_triclinic_cell_on_the_gpu_builder(method, snb, F, oev, prec):
     columns, lattice-vector tile images, sheared candidate search.  Energies, forces and derivatives against the oracle; then two
     forces-only steps (packed kernel, graph replay) after small moves."""
     n, L = 13824, 6.0
-    pme = (2.6283, 48, 48, 48) if method >= 4 else None
+    pme = ((2.6283, 54, 54, 54) if method == 4 else (2.6283, 48, 48, 48)) if method >= 4 else None      # (54: the plane path's kernel table in a triclinic cell; 48: the three-pass pipeline)
     ljpme = (2.6283, 24, 24, 24) if method == 5 else None
     force, pos, _ = systems.random_box(F, n, 3, method, L, 1.0, pme=pme, ljpme=ljpme)
     pos = (pos / L) @ TRICLINIC                           # the jittered lattice, sheared with the cell
