@@ -915,20 +915,16 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
         return;
     }
     const int nch = nz / chunk;                                            // chunks per line (launcher: chunk divides sz, hence nz and RZ)
-    const FastDiv dch(nch);
-    for (int it = tid; it < nl * nch; it += NT) {
-        const int l = dch.div(it), k0 = (it - l * nch) * chunk;
+    // A thread stays on ONE line per pass (NT / nl threads share a line and stride over its chunks), so which regions cover the line -- the
+    // 3 x 3 neighbour bricks' offsets and their busy slabs, ~20 instructions per candidate -- is worked out once per line, in registers,
+    // instead of once per 16-byte chunk (7 k of the work-group's 11 k wave-instructions; a table in LDS instead of registers was slower:
+    // 33.3 us against 28.3, one more LDS round trip per candidate).
+    const int TPL = (NT / nl) > 0 ? (NT / nl) : 1, LPP = NT / TPL;        // threads per line, lines per pass
+    const FastDiv dtpl(TPL);
+    const int lineOfThread = dtpl.div(tid), sub = tid - lineOfThread * TPL;
+    for (int l = lineOfThread; l < nl; l += LPP) {
         const int lx = dcy2.div(l), ly = l - lx * cy;
-        // the two slabs whose regions hold plane k0: its own, and the one below when k0 is among that one's four extra planes
-        const int s1 = k0 / sz, zl1 = k0 - s1 * sz;
-        const int s0 = s1 == 0 ? nSlabs - 1 : s1 - 1, zl0 = zl1 + sz;
-        const bool low = zl0 < RZ;
-        Acc sum[CMAX];
-#pragma unroll
-        for (int c = 0; c < CMAX; c++) sum[c] = Acc(0);
-        // all (<= 3 x 3 bricks) x (2 slabs) candidate loads of the chunk go out together: a thread has ~4 chunks, and with one round of
-        // dependent loads per y neighbour the merge was 12 latencies long (28.5 us on c3)
-        Acc v[18][CMAX];
+        long long off[9]; unsigned bmask[9];
 #pragma unroll
         for (int jy = 0; jy < 3; jy++) {
             const int dby = jy - hiY, ry = ly + dby * cy + M;
@@ -939,22 +935,39 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
                 const int dbx = jx - hiX, rx = lx + dbx * cx + M;
                 int bx2 = (Bx - dbx) % nbx; if (bx2 < 0) bx2 += nbx;
                 const bool ok = oky && dbx <= loX && rx >= 0 && rx < RX;
-                const size_t reg = (size_t)((slot * nbx + bx2) * nby + by2) * nSlabs;
-                const size_t line = ((size_t)rx * RY + ry) * RZ;
+                unsigned m = 0;
+                if (ok) for (int sl = 0; sl < nSlabs; sl++) if (s_busy[(jx * 3 + jy) * nSlabs + sl]) m |= 1u << sl;      // (launcher: at most 32 slabs)
+                bmask[jy * 3 + jx] = m;
+                off[jy * 3 + jx] = (long long)((size_t)((slot * nbx + bx2) * nby + by2) * nSlabs * npts + ((size_t)rx * RY + ry) * RZ);
+            }
+        }
+        for (int ch = sub; ch < nch; ch += TPL) {
+        const int k0 = ch * chunk;
+        // the two slabs whose regions hold plane k0: its own, and the one below when k0 is among that one's four extra planes
+        const int s1 = k0 / sz, zl1 = k0 - s1 * sz;
+        const int s0 = s1 == 0 ? nSlabs - 1 : s1 - 1, zl0 = zl1 + sz;
+        const bool low = zl0 < RZ;
+        Acc sum[CMAX];
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int s = h ? s0 : s1, zl = h ? zl0 : zl1;
-                    const int u = (jy * 3 + jx) * 2 + h;
+        for (int c = 0; c < CMAX; c++) sum[c] = Acc(0);
+        // all (<= 3 x 3 bricks) x (2 slabs) candidate loads of the chunk go out together: a thread has ~3 chunks, and with one round of
+        // dependent loads per y neighbour the merge was 12 latencies long (28.5 us on c3)
+        Acc v[18][CMAX];
 #pragma unroll
-                    for (int c = 0; c < CMAX; c++) v[u][c] = Acc(0);
-                    if (ok && (h == 0 || low) && s_busy[(jx * 3 + jy) * nSlabs + s]) {
-                        const Acc* src = partial + (reg + s) * npts + line + zl;
-                        if (chunk == CMAX) {
-                            if constexpr (FIXED) { const int4 t = *reinterpret_cast<const int4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
-                            else { const double2 t = *reinterpret_cast<const double2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
-                        } else if (FIXED && chunk == 2) { const int2 t = *reinterpret_cast<const int2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
-                        else v[u][0] = src[0];
-                    }
+        for (int j = 0; j < 9; j++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int sl = h ? s0 : s1, zl = h ? zl0 : zl1;
+                const int u = j * 2 + h;
+#pragma unroll
+                for (int c = 0; c < CMAX; c++) v[u][c] = Acc(0);
+                if (((bmask[j] >> sl) & 1u) && (h == 0 || low)) {
+                    const Acc* src = partial + off[j] + (size_t)sl * npts + zl;
+                    if (chunk == CMAX) {
+                        if constexpr (FIXED) { const int4 t = *reinterpret_cast<const int4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
+                        else { const double2 t = *reinterpret_cast<const double2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
+                    } else if (FIXED && chunk == 2) { const int2 t = *reinterpret_cast<const int2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
+                    else v[u][0] = src[0];
                 }
             }
         }
@@ -967,6 +980,7 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
             const Real val = (Real)sum[c] * inv;
             if (FUSEZ) reinterpret_cast<Real*>(&A[(k0 + c) * BS + (l >> 1)])[l & 1] = val;
             else greal[((size_t)(x0 + lx) * ny + (y0 + ly)) * nz + k0 + c] = val;
+        }
         }
     }
     if (FUSEZ && (nl & 1)) for (int k = tid; k < nz; k += NT) A[k * BS + (nl >> 1)].y = Real(0);      // the odd line out has no partner
@@ -1673,7 +1687,8 @@ template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hi
                       SNB_STAMPED_LAUNCH(stampSlot(p, 1), (k_spreadOwn<Real, FX>), dim3(nbricks * p.ownSlabs), dim3(512), ldsOwn, s, p); }
     // a long mesh in double precision gives a 256-thread work-group a dozen 16-byte chunks per thread, each three rounds of dependent loads
     // (c5, 180^3: 309 us): 512 threads there
-    const bool wideMerge = (size_t)cx * cy * (p.d.nz / chunk) > 6 * 256;
+    static const int mergeNt = getenv("SNB_MERGE_NT") ? atoi(getenv("SNB_MERGE_NT")) : 0;      // test switch: 256 / 512 threads per brick
+    const bool wideMerge = mergeNt ? mergeNt == 512 : (size_t)cx * cy * (p.d.nz / chunk) > 6 * 256;
 #define SNB_MERGE(FX, FZ, A, B) { if (wideMerge) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadMerge<Real, FX, FZ, A, B, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FZ ? ldsFft : 0)); \
                                       SNB_STAMPED_LAUNCH(stampSlot(p, 2), (k_spreadMerge<Real, FX, FZ, A, B, 512>), dim3(nbricks), dim3(512), (FZ ? ldsFft : 0), s, p, chunk, plane); } \
                                   else { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spreadMerge<Real, FX, FZ, A, B, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FZ ? ldsFft : 0)); \
