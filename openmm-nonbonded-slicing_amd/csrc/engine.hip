@@ -354,7 +354,8 @@ public:
         (void)hipStreamSynchronize(stream);
         if (dPmeTrace.p) {
             long long g[8] = {0}; (void)hipMemcpy(g, dPmeTrace.p, 64, hipMemcpyDeviceToHost);
-            if (g[7] > 0) fprintf(stderr, "[snb] spreading bricks (busy ones): mean scan %.2f us, entries %.2f us, z FFT + store %.2f us per work-group (%lld work-groups)\n", g[4] / 100.0 / g[7], g[5] / 100.0 / g[7], g[6] / 100.0 / g[7], g[7]);
+            if (g[7] > 0 && g[3] > 0) fprintf(stderr, "[snb] merge kernel prologue (busy flags, roots of unity, barrier): %.2f us per busy work-group\n", g[3] / 100.0 / g[7]);
+            if (g[7] > 0) fprintf(stderr, "[snb] spreading (busy work-groups; scanning spreader: scan / entries / z FFT + store; merge kernel: sums / strays + z FFT / store): %.2f us, %.2f us, %.2f us per work-group (%lld work-groups)\n", g[4] / 100.0 / g[7], g[5] / 100.0 / g[7], g[6] / 100.0 / g[7], g[7]);
         }
         if (dPmeTrace.p) { long long h[4] = {0, 0, 0, 0}; (void)hipMemcpy(h, dPmeTrace.p, 32, hipMemcpyDeviceToHost); if (h[2] > 0) fprintf(stderr, "[snb] interpolation bricks: mean load %.2f us, mean compute %.2f us per work-group (%lld work-groups)\n", h[0] / 100.0 / h[2], h[1] / 100.0 / h[2], h[2]); }
         dropGraph();

@@ -868,35 +868,47 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
     const int x0 = Bx * cx, y0 = By * cy;
     const int nl = cx * cy, nb = (nl + 1) >> 1, BS = nb + 1;
     const int tid = threadIdx.x;
+    const bool trace = p.trace != nullptr;      // SNB_PME_TRACE: wall-clock split of the busy work-groups (sum phase / strays + z FFT / store), 100 MHz ticks
+    long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (trace) tr0 = wall_clock64();
     Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);                     // FUSEZ: [nz][BS] (+ B, roots of unity)
     Cx<Real>* B = A + (size_t)nz * BS;
     Cx<Real>* tw = B + (size_t)nz * BS;
-    __shared__ int s_busy[9 * 32];                                         // [3][3][nSlabs]: was the region written this step?
+    // per neighbour brick j = jy * 3 + jx (uniform for the work-group): which of its slabs' regions were written this step (bit per slab)
+    // and where its regions start -- worked out by nine threads, once (per line and candidate this was two integer modulos and a
+    // flag loop: 5 of the busy work-groups' 25 us, SNB_PME_TRACE)
+    __shared__ unsigned s_bmask[9];
+    __shared__ int s_roff[9];                                              // (launcher: every element offset of ownPartial below 2^31)
     __shared__ int s_any;
     const int loX = (4 + M + cx - 1) / cx, hiX = (M + cx - 1) / cx, loY = (4 + M + cy - 1) / cy, hiY = (M + cy - 1) / cy;      // launcher: lo + hi + 1 <= 3
     if (tid == 0) s_any = 0;
     __syncthreads();
-    for (int i = tid; i < 9 * nSlabs; i += NT) {      // (9 x 32 flags at most: more than a 256-thread work-group)
-        const int j = i / nSlabs, s = i - j * nSlabs, jx = j / 3, jy = j - jx * 3;
+    if (tid < 9) {
+        const int jy = tid / 3, jx = tid - jy * 3;
         const int dbx = jx - hiX, dby = jy - hiY;
-        int b = 0;
+        unsigned m = 0; int ro = 0;
         if (dbx <= loX && dby <= loY) {
             int bx2 = (Bx - dbx) % nbx; if (bx2 < 0) bx2 += nbx;
             int by2 = (By - dby) % nby; if (by2 < 0) by2 += nby;
-            b = p.ownBusy[((slot * nbx + bx2) * nby + by2) * nSlabs + s];
+            const int reg = ((slot * nbx + bx2) * nby + by2) * nSlabs;
+            for (int sl = 0; sl < nSlabs; sl++) if (p.ownBusy[reg + sl]) m |= 1u << sl;      // (launcher: at most 32 slabs)
+            ro = (int)((size_t)reg * npts) + (((jx - hiX) * cx + M) * RY + ((jy - hiY) * cy + M)) * RZ;      // + the line (lx, ly) of THIS brick: (lx * RY + ly) * RZ
         }
-        s_busy[i] = b;
-        if (b) s_any = 1;
+        s_bmask[tid] = m; s_roff[tid] = ro;
+        if (m) s_any = 1;
     }
     if (FUSEZ) for (int k = tid; k < nz; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
-    __syncthreads();
+    // (both requested BEFORE the barrier: behind it they were a dependent memory round trip of their own ahead of the sums -- the busy
+    // work-groups spend 17 of their 25 us in dependent load rounds, SNB_PME_TRACE)
+    const int nStray = *p.strayCount;      // strays (normally none): atoms whose footprint left the region of their own work-group; every brick looks at every stray
     const Real inv = FIXED ? p.fixDev[1] : Real(1);
+    __syncthreads();
+    long long trA = 0;
+    if (trace) trA = wall_clock64();
     const Acc* partial = reinterpret_cast<const Acc*>(p.ownPartial);
     Real* greal = p.gridReal + (size_t)slot * nx * ny * nz;
     Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.gridCplx) + (size_t)slot * nx * ny * nzc;
     const FastDiv dzc(nzc), dcy2(cy);
-    // strays (normally none): atoms whose footprint left the region of their own work-group; every brick looks at every stray
-    const int nStray = *p.strayCount;
     if (FUSEZ && !s_any && nStray == 0) {      // nothing of this subset anywhere near (uniform): the brick's spectrum is zero
         if (plane) {      // plane-major spectrum [slot][kz][x][y] (the plane path, k_planeXY)
             const FastDiv dnl(nl);
@@ -924,23 +936,23 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
     const int lineOfThread = dtpl.div(tid), sub = tid - lineOfThread * TPL;
     for (int l = lineOfThread; l < nl; l += LPP) {
         const int lx = dcy2.div(l), ly = l - lx * cy;
-        long long off[9]; unsigned bmask[9];
+        // the neighbour tables are uniform: they travel in scalar registers; a thread keeps the offset of its line and one bit per
+        // neighbour (does that brick's region reach this line?) -- 18 vector registers fewer than offsets and masks per candidate, which is
+        // what keeps four work-groups on a CU (at 152 registers the 1728 empty bricks of c3's solute meshes queue behind three)
+        const int lineOff = (lx * RY + ly) * RZ;
+        unsigned okBits = 0;
 #pragma unroll
         for (int jy = 0; jy < 3; jy++) {
-            const int dby = jy - hiY, ry = ly + dby * cy + M;
-            const bool oky = dby <= loY && ry >= 0 && ry < RY;
-            int by2 = (By - dby) % nby; if (by2 < 0) by2 += nby;
+            const int ry = ly + (jy - hiY) * cy + M;
 #pragma unroll
             for (int jx = 0; jx < 3; jx++) {
-                const int dbx = jx - hiX, rx = lx + dbx * cx + M;
-                int bx2 = (Bx - dbx) % nbx; if (bx2 < 0) bx2 += nbx;
-                const bool ok = oky && dbx <= loX && rx >= 0 && rx < RX;
-                unsigned m = 0;
-                if (ok) for (int sl = 0; sl < nSlabs; sl++) if (s_busy[(jx * 3 + jy) * nSlabs + sl]) m |= 1u << sl;      // (launcher: at most 32 slabs)
-                bmask[jy * 3 + jx] = m;
-                off[jy * 3 + jx] = (long long)((size_t)((slot * nbx + bx2) * nby + by2) * nSlabs * npts + ((size_t)rx * RY + ry) * RZ);
+                const int rx = lx + (jx - hiX) * cx + M;
+                if (rx >= 0 && rx < RX && ry >= 0 && ry < RY) okBits |= 1u << (jy * 3 + jx);      // (bricks out of reach carry an empty mask)
             }
         }
+        int cadd[9]; unsigned bmask[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) { cadd[j] = __builtin_amdgcn_readfirstlane(s_roff[j]); bmask[j] = (unsigned)__builtin_amdgcn_readfirstlane((int)s_bmask[j]); }
         for (int ch = sub; ch < nch; ch += TPL) {
         const int k0 = ch * chunk;
         // the two slabs whose regions hold plane k0: its own, and the one below when k0 is among that one's four extra planes
@@ -953,24 +965,33 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
         // all (<= 3 x 3 bricks) x (2 slabs) candidate loads of the chunk go out together: a thread has ~3 chunks, and with one round of
         // dependent loads per y neighbour the merge was 12 latencies long (28.5 us on c3)
         Acc v[18][CMAX];
+        // per candidate: one bit test, one 64-bit add, one load (the slab offsets are per chunk, the load width is chosen once per chunk:
+        // with ~2 waves per SIMD a wave's own instruction stream is latency, not throughput -- SNB_PME_TRACE: 5 us per chunk before this)
+        const int sOff[2] = {(int)(s1 * (int)npts + zl1), (int)(s0 * (int)npts + zl0)};
+        const unsigned sBit[2] = {1u << s1, low ? (1u << s0) : 0u};
+        auto loadAll = [&](auto width) {
+            constexpr int W = decltype(width)::value;      // values per load: CMAX (16 bytes), 2 (fixed point, 8 bytes) or 1
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
+            for (int j = 0; j < 9; j++) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int sl = h ? s0 : s1, zl = h ? zl0 : zl1;
-                const int u = j * 2 + h;
+                for (int h = 0; h < 2; h++) {
+                    const int u = j * 2 + h;
 #pragma unroll
-                for (int c = 0; c < CMAX; c++) v[u][c] = Acc(0);
-                if (((bmask[j] >> sl) & 1u) && (h == 0 || low)) {
-                    const Acc* src = partial + off[j] + (size_t)sl * npts + zl;
-                    if (chunk == CMAX) {
-                        if constexpr (FIXED) { const int4 t = *reinterpret_cast<const int4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
-                        else { const double2 t = *reinterpret_cast<const double2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
-                    } else if (FIXED && chunk == 2) { const int2 t = *reinterpret_cast<const int2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
-                    else v[u][0] = src[0];
+                    for (int c = 0; c < CMAX; c++) v[u][c] = Acc(0);
+                    if (((okBits >> j) & 1u) && (bmask[j] & sBit[h])) {
+                        const Acc* src = partial + (lineOff + cadd[j] + sOff[h]);
+                        if constexpr (W == CMAX) {
+                            if constexpr (FIXED) { const int4 t = *reinterpret_cast<const int4*>(src); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
+                            else { const double2 t = *reinterpret_cast<const double2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
+                        } else if constexpr (FIXED && W == 2) { const int2 t = *reinterpret_cast<const int2*>(src); v[u][0] = t.x; v[u][1] = t.y; }
+                        else v[u][0] = src[0];
+                    }
                 }
             }
-        }
+        };
+        if (chunk == CMAX) loadAll(std::integral_constant<int, CMAX>());
+        else if (FIXED && chunk == 2) loadAll(std::integral_constant<int, 2>());
+        else loadAll(std::integral_constant<int, 1>());
 #pragma unroll
         for (int c = 0; c < CMAX; c++)
 #pragma unroll
@@ -985,6 +1006,7 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
     }
     if (FUSEZ && (nl & 1)) for (int k = tid; k < nz; k += NT) A[k * BS + (nl >> 1)].y = Real(0);      // the odd line out has no partner
     __syncthreads();
+    if (trace) tr1 = wall_clock64();
     for (int s = 0; s < nStray; s++) {
         const int2 e = p.strays[s];
         if (e.y != slot) continue;
@@ -1017,6 +1039,7 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
     if constexpr (FUSEZ) {
         Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, NT);
         __syncthreads();
+        if (trace) tr2 = wall_clock64();
         if (plane) {      // plane-major [slot][kz][x][y]: consecutive lanes = consecutive line pairs of one kz (runs of cy elements per x row)
             const FastDiv dnb(nb);
             for (int it = tid; it < nb * nzc; it += NT) {
@@ -1039,6 +1062,12 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
                 const int l1 = l0 + 1, lx1 = dcy2.div(l1), ly1 = l1 - lx1 * cy;
                 out[((size_t)(x0 + lx1) * ny + (y0 + ly1)) * nzc + k] = {Real(0.5) * (z.y + m.y), Real(0.5) * (m.x - z.x)};
             }
+        }
+        if (trace && tid == 0) {
+            const long long t3 = wall_clock64();
+            atomicAdd((unsigned long long*)&p.trace[3], (unsigned long long)(trA - tr0));      // (of which: the prologue up to its barrier)
+            atomicAdd((unsigned long long*)&p.trace[4], (unsigned long long)(tr1 - tr0)); atomicAdd((unsigned long long*)&p.trace[5], (unsigned long long)(tr2 - tr1));
+            atomicAdd((unsigned long long*)&p.trace[6], (unsigned long long)(t3 - tr2)); atomicAdd((unsigned long long*)&p.trace[7], 1ull);
         }
     }
 }
@@ -1676,6 +1705,7 @@ template <typename Real> static int launchSpreadOwn(const PmeParams<Real>& p, hi
     const int M = p.ownMargin;
     const int reachX = (4 + M + cx - 1) / cx + (M + cx - 1) / cx + 1, reachY = (4 + M + cy - 1) / cy + (M + cy - 1) / cy + 1;      // bricks whose regions cover a line
     if (ldsOwn > 64 * 1024 || RX > p.d.nx || RY > p.d.ny || p.groupX * p.groupY > 16 || reachX > 3 || reachY > 3 || p.ownSlabs > 32 || sz < 4) return -1;
+    if ((size_t)p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY) * p.ownSlabs * RX * RY * RZ >= ((size_t)1 << 31)) return -1;      // (the merge kernel keeps 32-bit element offsets into ownPartial)
     const int cmax = fixed ? 4 : 2, chunk = (sz % cmax == 0) ? cmax : ((fixed && sz % 2 == 0) ? 2 : 1);      // values per load of the merge kernel (16, 8 or 4 bytes)
     const int nbricks = p.nsub * (p.sortNcx / p.groupX) * (p.sortNcy / p.groupY);
     const int nb = (cx * cy + 1) / 2;
