@@ -222,8 +222,18 @@ __device__ inline float rowRor8(float v) { return __builtin_bit_cast(float, __bu
 // travels WITH the j-slot by a one-lane DPP row rotation per step (v_add_f32_dpp: one VALU op per component, no LDS),
 // so after 16 steps lane c holds the force on j-slot c.  j-atom data is read from LDS (staged once per tile, each
 // 16-atom half stored twice so the rotated index c+16-s needs no wrap).
+template <typename Real, bool ENERGY> __device__ __forceinline__ void exceptionsBody(const PairListParams<Real>& p, const int blk);
+template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionAtomsBody(const PairListParams<Real>& p, const int blk);
+// (as in k_directPacked: the first nListBlocks work-groups of the launch run the O(N) pair lists -- exclusion corrections, then 1-4
+// exceptions -- so that their latency-bound work overlaps the tile work instead of trailing it as a 65 us launch of its own on c5)
 template <typename Real, int MC, bool WRAP, bool ENERGY>
-__global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)) void k_direct(const DirectParams<Real> p) {
+__global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)) void k_direct(const DirectParams<Real> p, const PairListParams<Real> q, const int nExclBlocks, const int nListBlocks) {
+    if ((int)blockIdx.x < nListBlocks) {      // (energy steps: the list bodies reduce their slice energies in 2 S doubles of dynamic LDS)
+        if ((int)blockIdx.x < nExclBlocks) { PairListParams<Real> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<Real, ENERGY>(qe, blockIdx.x); }
+        else exceptionsBody<Real, ENERGY>(q, blockIdx.x - nExclBlocks);
+        return;
+    }
+    const int tileBlock = blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
     double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
     using T4 = typename Vec<Real>::T4;
     using T2 = typename Vec<Real>::T2;
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int item = blockIdx.x * 4 + wid; item < p.numWork; item += gridDim.x * 4) {   // no block-level barrier inside the loop
+    for (int item = tileBlock * 4 + wid; item < p.numWork; item += nTileBlocks * 4) {   // no block-level barrier inside the loop
     const int4 wi = p.workItems[p.workStart + item * p.workStride];
     const int I = __builtin_amdgcn_readfirstlane(wi.x);
     const int tBegin = __builtin_amdgcn_readfirstlane(wi.y), tEnd = tBegin + __builtin_amdgcn_readfirstlane(wi.z);
@@ -647,14 +657,23 @@ template <typename Real, int MC> static bool launchDirectMC(const DirectParams<R
             return lists != nullptr;
         }
     }
+    // the scalar tile kernel (double precision, per-pair wrapping, the switches above) carries the pair lists the same way
+    PairListParams<Real> q;
+    std::memset(&q, 0, sizeof(q));
+    int nExclBlocks = 0, nListBlocks = 0;
+    static const bool noFusedLists = getenv("SNB_NO_FUSED_LISTS") != nullptr;
+    const bool fuseLists = lists != nullptr && !noFusedLists;
+    if (fuseLists) { q = *lists; nExclBlocks = (q.nExclAtoms + 255) / 256; nListBlocks = nExclBlocks + (q.n + 255) / 256; }
+    const size_t listLds = (fuseLists && energy) ? sizeof(double) * 2 * q.nSlices : 0;
+    dim3 gridAll(nwg + nListBlocks);
     if (wrap) {
-        if (energy) SNB_LAUNCH((k_direct<Real, MC, true, true>), grid, p);
-        else SNB_LAUNCH((k_direct<Real, MC, true, false>), grid, p);
+        if (energy) SNB_LAUNCH_LDS((k_direct<Real, MC, true, true>), gridAll, listLds, p, q, nExclBlocks, nListBlocks);
+        else SNB_LAUNCH_LDS((k_direct<Real, MC, true, false>), gridAll, listLds, p, q, nExclBlocks, nListBlocks);
     } else {
-        if (energy) SNB_LAUNCH((k_direct<Real, MC, false, true>), grid, p);
-        else SNB_LAUNCH((k_direct<Real, MC, false, false>), grid, p);
+        if (energy) SNB_LAUNCH_LDS((k_direct<Real, MC, false, true>), gridAll, listLds, p, q, nExclBlocks, nListBlocks);
+        else SNB_LAUNCH_LDS((k_direct<Real, MC, false, false>), gridAll, listLds, p, q, nExclBlocks, nListBlocks);
     }
-    return false;
+    return fuseLists;
 }
 
 // Returns true when the launch also ran the pair lists passed in `lists` (single-precision forces-only tile kernel); otherwise the
