@@ -1758,6 +1758,17 @@ template <typename Real> static int pickBatch(size_t bytesPerBatchElem, int maxB
     return b;
 }
 
+// Columns per work-group of the y pass.  Single precision: as many as fit the LDS budget, at most 32 (c3: 32 + 29 columns 27.8 us, three
+// tiles of 21 28.4).  Double precision (round 3): at least three tiles of even width -- 90^3 (46 columns) 16 + 16 + 14: 16.5 / 14.9 us per
+// pass against 21.5 / 20.6 for 32 + 14; 180^3 six tiles of 16: 139 / 128 against 145 / 133 for 17 x 5 + 6; 120^3 keeps three tiles
+// (four tiles of 16: 48.6 against 40.8)
+template <typename Real> static int fftyBatch(int ny, int nzc, int forced) {
+    const int cap = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), forced > 0 ? forced : 32);
+    if (forced > 0 || sizeof(Real) == 4) return cap;
+    const int tiles = (nzc + cap - 1) / cap;
+    if (tiles < 3 && nzc >= 24) return (nzc + 2) / 3;
+    return cap > 2 ? (cap & ~1) : cap;      // (balanced tiles of 21 on the 120^3 mesh: 42.6 us against 40.8 for 25 + 25 + 11)
+}
 template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s, bool zDone) {
     const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc;
     // z: real -> half complex (unless the brick spreader already did it)
@@ -1772,8 +1783,8 @@ template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipS
     }
     // y
     {
-        static const int nbMax = getenv("SNB_FFTY_NB") ? atoi(getenv("SNB_FFTY_NB")) : 32;   // measured on c3: 8: 40 us, 16: 31, 21: 28.4, 32: 27.8
-        const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), nbMax);
+        static const int nbEnv = getenv("SNB_FFTY_NB") ? atoi(getenv("SNB_FFTY_NB")) : 0;   // measured on c3: 8: 40 us, 16: 31, 21: 28.4, 32: 27.8
+        const int NB = fftyBatch<Real>(ny, nzc, nbEnv);
         const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>) + (size_t)ny * sizeof(Cx<Real>);
         const int tilesPerA = (nzc + NB - 1) / NB;
         launchFftStrided<Real>(p.d.ry1, p.d.ry2, dim3((unsigned)(p.nsub * nx * tilesPerA)), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB, tilesPerA, -1, 1);
@@ -1797,8 +1808,8 @@ template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hip
 template <typename Real> void launchPmeInverseFFT(const PmeParams<Real>& p, hipStream_t s) {
     const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc;
     {
-        static const int nbMax = getenv("SNB_FFTY_NB") ? atoi(getenv("SNB_FFTY_NB")) : 32;   // measured on c3: 8: 40 us, 16: 31, 21: 28.4, 32: 27.8
-        const int NB = pickBatch<Real>((size_t)2 * ny * sizeof(Cx<Real>), nbMax);
+        static const int nbEnv = getenv("SNB_FFTY_NB") ? atoi(getenv("SNB_FFTY_NB")) : 0;   // measured on c3: 8: 40 us, 16: 31, 21: 28.4, 32: 27.8
+        const int NB = fftyBatch<Real>(ny, nzc, nbEnv);
         const size_t lds = (size_t)2 * ny * NB * sizeof(Cx<Real>) + (size_t)ny * sizeof(Cx<Real>);
         const int tilesPerA = (nzc + NB - 1) / NB;
         launchFftStrided<Real>(p.d.ry1, p.d.ry2, dim3((unsigned)(p.nsub * nx * tilesPerA)), lds, s, p, ny, (size_t)ny * nzc, nzc, (size_t)nzc, NB, tilesPerA, +1, 1);
