@@ -726,13 +726,15 @@ def test_changing_subsets_through_update_parameters(snb, F, oev, prec):
     check()
 
 
-def test_derivative_only_steps_evaluate_only_the_bound_slices(snb, F, oev, prec):
+@pytest.mark.parametrize("mesh", [48, 54], ids=["three_pass_48", "plane_path_54"])
+def test_derivative_only_steps_evaluate_only_the_bound_slices(mesh, snb, F, oev, prec):
     """A force with energy-parameter derivatives accumulates dE/dlambda on every evaluation, energy requested or not (Q4,
     ReferenceNonbondedSlicingKernels.cpp:259-265).  Such derivative-only steps run with include_energy == 2: only the slices bound to a
     derivative-requested parameter are evaluated (snb_set_energy_slices), the pair kernel runs forces-only arithmetic on every other
-    tile.  Forces and derivatives must still be the oracle's, step after step (graph replay included)."""
+    tile.  Forces and derivatives must still be the oracle's, step after step (graph replay included).  Both reciprocal pipelines: on the 54^3
+    mesh the wanted slices' energies come from the plane kernel's Parseval sums, on the 48^3 mesh from k_convolveX's Gram sums."""
     n, L = 13824, 6.0
-    force, pos, box = systems.random_box(F, n, 4, 4, L, 1.0, pme=(2.6283, 48, 48, 48))
+    force, pos, box = systems.random_box(F, n, 4, 4, L, 1.0, pme=(2.6283, mesh, mesh, mesh))
     system = snb.System()
     for _ in range(n):
         system.addParticle(1.0)
