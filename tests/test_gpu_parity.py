@@ -631,7 +631,10 @@ def test_sharded_engines_sum_to_unsharded(world, snb, oev):
         eerr = np.max(np.abs(etot - so) / np.maximum(np.abs(so), 1.0))
         # (sharded energies come from real-space interpolation of the potentials, not the k-space Gram sum: same bar)
         print("sharded x%d %s: force err %.2e, slice-energy err %.2e" % (world, prec, ferr, eerr))
-        assert ferr < tol and eerr < tol, (prec, world, ferr, eerr)
+        # (tools/switch_matrix.sh: SNB_SCALAR_ENERGY_KERNEL=1 evaluates the pair energies with the A&S erfc, whose one-signed 1.5e-7 error sums
+        # to 1.6e-3 of the smallest cross slice of this box -- the reason the default energy kernel uses the degree-13 polynomial)
+        etol = 3e-3 if (prec == "single" and "SNB_SCALAR_ENERGY_KERNEL" in __import__("os").environ) else tol
+        assert ferr < tol and eerr < etol, (prec, world, ferr, eerr)
 
 
 def test_parameter_offsets_follow_global_parameters_on_the_device(snb, F, oev, prec):
@@ -1023,7 +1026,7 @@ def test_plane_path_and_three_pass_pipeline_agree_with_the_oracle(method, grid, 
         got[tag] = res
         assert res["host_rebuilds"] == 0
         assert res["ferr_energy_step"] < 1e-3 and res["ferr_forces_step"] < 1e-3 and res["eerr"] < 1e-3, (tag, res)
-    if any(k in os.environ for k in ("SNB_NO_FUSED_Z", "SNB_NO_OWN_SPREAD", "SNB_FFT_TWOPASS", "SNB_NO_PLANE_FFT")):
+    if any(k in os.environ for k in ("SNB_NO_FUSED_Z", "SNB_NO_OWN_SPREAD", "SNB_OWN_SLABS", "SNB_FFT_TWOPASS", "SNB_NO_PLANE_FFT")):
         return      # (tools/switch_matrix.sh: these switches take the plane path's front end away -- parity above is all there is to check)
     plane_expected = grid in (42, 54, 64)
     t = got["plane"]["timed"]
