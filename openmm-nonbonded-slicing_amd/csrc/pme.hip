@@ -910,12 +910,11 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
     Cx<Real>* out = reinterpret_cast<Cx<Real>*>(p.gridCplx) + (size_t)slot * nx * ny * nzc;
     const FastDiv dzc(nzc), dcy2(cy);
     if (FUSEZ && !s_any && nStray == 0) {      // nothing of this subset anywhere near (uniform): the brick's spectrum is zero
-        if (plane) {      // plane-major spectrum [slot][kz][x][y] (the plane path, k_planeXY)
+        if (plane) {      // plane-major, brick-tiled spectrum [slot][kz][brick][line] (the plane path, k_planeXY)
             const FastDiv dnl(nl);
             for (int it = tid; it < nl * nzc; it += NT) {
                 const int k = dnl.div(it), l = it - k * nl;
-                const int lx = dcy2.div(l), ly = l - lx * cy;
-                out[((size_t)k * nx + (x0 + lx)) * ny + (y0 + ly)] = {Real(0), Real(0)};
+                out[((size_t)k * (nbx * nby) + bcol) * nl + l] = {Real(0), Real(0)};
             }
             return;
         }
@@ -1040,17 +1039,23 @@ template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __globa
         Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, -1, tw, nb, BS, tid, NT);
         __syncthreads();
         if (trace) tr2 = wall_clock64();
-        if (plane) {      // plane-major [slot][kz][x][y]: consecutive lanes = consecutive line pairs of one kz (runs of cy elements per x row)
+        if (plane) {
+            // plane-major and brick-tiled, [slot][kz][brick][line]: the brick's lines of one kz are ONE contiguous run (288 bytes on c3) and a
+            // line pair is one 16-byte store.  (As [slot][kz][x][y] the same data went out in 48-byte runs a row apart: by SNB_PME_TRACE a busy
+            // brick's store phase took 8.1 us against 3.2 for the line-major layout of the three-pass pipeline, and its loads 2.7 us more.)
             const FastDiv dnb(nb);
+            Cx<Real>* tiled = out + (size_t)bcol * nl;
+            const size_t kStride = (size_t)(nbx * nby) * nl;
             for (int it = tid; it < nb * nzc; it += NT) {
                 const int k = dnb.div(it), c = it - k * nb;
                 const Cx<Real> z = R[k * BS + c], m = R[(k == 0 ? 0 : nz - k) * BS + c];
-                const int l0 = 2 * c, lx0 = dcy2.div(l0), ly0 = l0 - lx0 * cy;
-                out[((size_t)k * nx + (x0 + lx0)) * ny + (y0 + ly0)] = {Real(0.5) * (z.x + m.x), Real(0.5) * (z.y - m.y)};
-                if (l0 + 1 < nl) {
-                    const int l1 = l0 + 1, lx1 = dcy2.div(l1), ly1 = l1 - lx1 * cy;
-                    out[((size_t)k * nx + (x0 + lx1)) * ny + (y0 + ly1)] = {Real(0.5) * (z.y + m.y), Real(0.5) * (m.x - z.x)};
+                const Cx<Real> a = {Real(0.5) * (z.x + m.x), Real(0.5) * (z.y - m.y)}, b = {Real(0.5) * (z.y + m.y), Real(0.5) * (m.x - z.x)};
+                Cx<Real>* dst = tiled + k * kStride + 2 * c;
+                if constexpr (std::is_same<Real, float>::value) {
+                    if (2 * c + 1 < nl && !(nl & 1)) { *reinterpret_cast<float4*>(dst) = make_float4(a.x, a.y, b.x, b.y); continue; }
                 }
+                dst[0] = a;
+                if (2 * c + 1 < nl) dst[1] = b;
             }
         } else
         for (int it = tid; it < nb * nzc; it += NT) {
@@ -1431,10 +1436,21 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeX
     const FastDiv dNBY(NBY);
     for (int k = tid; k < nx; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twx)[k];
     const FastDiv dny(ny);
-    const int nPairs = (int)(planeElems >> 1);                         // ny is even (launcher): 16-byte loads never straddle a row
-    batchedCopy<8, float4>(tid, nPairs, NT,
-        [&](int e) { return reinterpret_cast<const float4*>(in)[e]; },
-        [&](int e, const float4& v) { const int x = dny.div(2 * e), y = 2 * e - x * ny; P[x * PY + y] = {v.x, v.y}; P[x * PY + y + 1] = {v.z, v.w}; });
+    const int nPairs = (int)(planeElems >> 1);                         // ny is even (launcher): 16-byte accesses never straddle a row
+    // the merge kernel's planes are brick-tiled, [kz][brick][line of the brick]: element e sits at x = bx cx + lx, y = by cy + ly
+    const int cx = p.groupX * (nx / p.sortNcx), cy = p.groupY * (ny / p.sortNcy), nbyT = p.sortNcy / p.groupY, nlT = cx * cy;
+    const FastDiv dnlT(nlT), dnbyT(nbyT), dcyT(cy);
+    auto tiledIndex = [&](int e) { const int b = dnlT.div(e), w = e - b * nlT, bxi = dnbyT.div(b), byi = b - bxi * nbyT, lx = dcyT.div(w), ly = w - lx * cy;
+                                   return (bxi * cx + lx) * PY + byi * cy + ly; };
+    const bool pairsOk = !(cy & 1);                                    // an even brick width keeps a 16-byte pair inside one line of the brick
+    if (pairsOk)
+        batchedCopy<8, float4>(tid, nPairs, NT,
+            [&](int e) { return reinterpret_cast<const float4*>(in)[e]; },
+            [&](int e, const float4& v) { const int i = tiledIndex(2 * e); P[i] = {v.x, v.y}; P[i + 1] = {v.z, v.w}; });
+    else
+        batchedCopy<8, float2>(tid, (int)planeElems, NT,
+            [&](int e) { return reinterpret_cast<const float2*>(in)[e]; },
+            [&](int e, const float2& v) { P[tiledIndex(e)] = {v.x, v.y}; });
     __syncthreads();
     // forward y (lines = x rows, elements along y), forward x (lines = y columns, elements along x, stride PY)
     planePass<Real, R1, -1, 1, true>(P, nx, PY, 1, R2, tw, tid, NT, PlaneNoScale());
@@ -1471,9 +1487,10 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeX
             const int gi = p.gridSubset[I];
             const int slice = gi > gj ? gi * (gi + 1) / 2 + gj : gj * (gj + 1) / 2 + gi;
             if (!p.sliceNeed[slice]) continue;      // (uniform)
-            const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const Cx<Real>*>(p.gridCplx) + ((size_t)I * nzc + kz) * planeElems);
+            const Cx<Real>* qc = reinterpret_cast<const Cx<Real>*>(p.gridCplx) + ((size_t)I * nzc + kz) * planeElems;      // (brick-tiled, like this work-group's input)
+            const float4* q = reinterpret_cast<const float4*>(qc);
             double acc = 0;
-            for (int e0 = tid; e0 < nPairs; e0 += 4 * NT) {
+            if (pairsOk) for (int e0 = tid; e0 < nPairs; e0 += 4 * NT) {
                 float4 v[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) { const int e = e0 + u * NT; if (e < nPairs) v[u] = q[e]; }
@@ -1482,10 +1499,19 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeX
                 for (int u = 0; u < 4; u++) {
                     const int e = e0 + u * NT;
                     if (e < nPairs) {
-                        const int x = dny.div(2 * e), y = 2 * e - x * ny;
-                        const Cx<Real> a = P[x * PY + y], b = P[x * PY + y + 1];
+                        const int i = tiledIndex(2 * e);
+                        const Cx<Real> a = P[i], b = P[i + 1];
                         part += (v[u].x * a.x + v[u].y * a.y) + (v[u].z * b.x + v[u].w * b.y);
                     }
+                }
+                acc += (double)part;
+            }
+            else for (int e0 = tid; e0 < (int)planeElems; e0 += 4 * NT) {
+                float part = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u * NT;
+                    if (e < (int)planeElems) { const Cx<Real> v = qc[e], a = P[tiledIndex(e)]; part += v.x * a.x + v.y * a.y; }
                 }
                 acc += (double)part;
             }
