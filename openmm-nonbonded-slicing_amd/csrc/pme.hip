@@ -1545,11 +1545,18 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_fftZIn
     const int x = blockIdx.x / tilesY, y0 = (blockIdx.x - x * tilesY) * NBY;
     const int nby = (ny - y0) < NBY ? (ny - y0) : NBY;
     const int nb = nby * NP, BS = NBY * NP + 1;
+    // With a two-pass split the inverse transform runs IN PLACE, as in k_planeXY: the half-complex lines are written at the permuted positions
+    // the forward passes would have left (frequency k1 + R1 k2 at position k1 R2 + k2), the inverse passes run in the opposite order and
+    // leave z in natural order -- one LDS buffer instead of two, 16 KB instead of 33 KB on c3, i.e. seven work-groups per CU instead of four:
+    // the 1800 work-groups of a 120^3 mesh are resident at once instead of in 1.8 rounds.  (Staged Stockham fallback: two buffers.)
+    constexpr bool INPLACE = R1 > 0;
     Cx<Real>* A = reinterpret_cast<Cx<Real>*>(s_dyn);
-    Cx<Real>* B = A + (size_t)nz * BS;
+    Cx<Real>* B = A + (INPLACE ? (size_t)0 : (size_t)nz * BS);
     Cx<Real>* tw = B + (size_t)nz * BS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < nz; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twz)[k];
+    const FastDiv dR1(INPLACE ? R1 : 1);
+    auto zpos = [&](int k) { if constexpr (INPLACE) { const int k2 = dR1.div(k); return (k - k2 * R1) * R2 + k2; } else return k; };      // LDS position of frequency k
     const int term = p.dispersion ? 1 : 0;
     float aReg[2][8];
 #pragma unroll
@@ -1598,12 +1605,18 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_fftZIn
                 Cx<Real> b = {0.f, 0.f};
                 if (2 * m + 1 < nsub) b = {re[g][r + 1], im[g][r + 1]};
                 const int c = yy * NP + m;
-                A[kz * BS + c] = {a.x - b.y, a.y + b.x};                                          // A_k + i B_k
-                if (kz > 0 && nz - kz >= nzc) A[(nz - kz) * BS + c] = {a.x + b.y, b.x - a.y};    // conj(A_k) + i conj(B_k)
+                A[zpos(kz) * BS + c] = {a.x - b.y, a.y + b.x};                                          // A_k + i B_k
+                if (kz > 0 && nz - kz >= nzc) A[zpos(nz - kz) * BS + c] = {a.x + b.y, b.x - a.y};    // conj(A_k) + i conj(B_k)
             }
         }
     }
-    Cx<Real>* R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, +1, tw, nb, BS, tid, NT);
+    Cx<Real>* R = A;
+    if constexpr (INPLACE) {
+        __syncthreads();
+        planePass<Real, R2, +1, 0, false>(A, nb, 1, BS, R1, tw, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePass<Real, R1, +1, 2, true>(A, nb, 1, BS, R2, tw, tid, NT, PlaneNoScale());
+    } else R = fftLines<Real, R1, R2>(A, B, nz, p.d.fz, p.d.nfz, +1, tw, nb, BS, tid, NT);
     __syncthreads();
     const FastDiv dz(nz), dnp(NP);
     for (int it = tid; it < nb * nz; it += NT) {
@@ -1681,7 +1694,11 @@ static void launchPlaneXY(const PmeParams<float>& p, hipStream_t s) {
 static void launchFftZInvMix(const PmeParams<float>& p, hipStream_t s) {
     const int NP = (p.nsub + 1) / 2;
     const int NBY = planeTileY(p);
-    const size_t lds = sizeof(Cx<float>) * ((size_t)2 * p.d.nz * (NBY * NP + 1) + p.d.nz);
+    bool twoPass = false;
+#define X(A, B) if (p.d.rz1 == A && p.d.rz2 == B) twoPass = true;
+    SNB_FFT_PAIRS(X)
+#undef X
+    const size_t lds = sizeof(Cx<float>) * ((size_t)(twoPass ? 1 : 2) * p.d.nz * (NBY * NP + 1) + p.d.nz);      // (in place with a two-pass split)
     const dim3 grid((unsigned)(p.d.nx * ((p.d.ny + NBY - 1) / NBY)));
     static const int ntEnv = getenv("SNB_ZMIX_NT") ? atoi(getenv("SNB_ZMIX_NT")) : 0;
     const bool wide = ntEnv ? ntEnv == 512 : NBY * NP >= 24;      // 24+ complex transforms per work-group (5-8 subsets): 512 threads
