@@ -149,7 +149,7 @@ CONFIGS = {
 }
 # 1-GPU rates of this build on MI355X (bench.py --config <name>, round 3, random-walk coordinates, the step each config names: c3 with derivatives,
 # c4 / c2 forces only), quoted beside N > 1 results of the same workload
-ONE_GPU_NS_DAY = {"c4": 300.0, "c3": 418.2, "c2": 985.0}
+ONE_GPU_NS_DAY = {"c4": 303.0, "c3": 419.2, "c2": 985.0}
 ALPHA = 2.6283
 CUTOFF = 1.0
 # configs whose BASELINE.json line names energy-parameter derivatives ("300k-atom solvated protein, 4 subsets with lambda_elec/lambda_vdW derivatives"):
