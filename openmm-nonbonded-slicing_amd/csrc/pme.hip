@@ -1359,7 +1359,7 @@ template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void 
 // Plane path (round 3).  The y pass, the fused x kernel and the inverse y pass above are three trips of the complex meshes through HBM and
 // ~80 us of latency-bound work-groups on c3 (21 + 38..44 + 21).  A (subset, kz) plane of a mesh up to ~128^2 is 115 KB in single
 // precision: it fits the 160 KB of LDS of one CU, and a 120^3 mesh with 4 subsets has 244 such planes -- one round of 256 CUs.  So, when
-// the merge kernel has written the half-complex spectrum plane-major ([slot][kz][x][y]), ONE kernel does, per plane and entirely in LDS:
+// the merge kernel has written the half-complex spectrum plane-major and brick-tiled ([slot][kz][brick][line]), ONE kernel does, per plane and entirely in LDS:
 // forward FFT_y, forward FFT_x, multiplication by the reciprocal-space kernel, inverse FFT_x, inverse FFT_y, and (energy steps) the
 // slice energies.  The transforms are the two-pass register FFT run IN PLACE: the forward passes leave frequency k1 + R1 k2 at position
 // k1 R2 + k2, the kernel value is looked up at that permuted index, and the inverse passes run in the opposite order and undo the

@@ -129,9 +129,9 @@ template <typename Real> struct PmeParams {
     int cellsReady;           // cells[] already hold this mesh's cells (written by the position-gather pass)
     int* cells;               // [Npad] scratch: packed mesh cell per atom (k_pmeCells), brick spreader only
     Real* gridReal;           // [nsub][nx][ny][nz]
-    typename Vec<Real>::T2* gridCplx;   // [nsub][nx][ny][nzc]  (plane path: [nsub][nzc][nx][ny], the z-transformed charges)
+    typename Vec<Real>::T2* gridCplx;   // [nsub][nx][ny][nzc]  (plane path: [nsub][nzc][brick][line of the brick], the z-transformed charges)
     const Real* planeEterm;             // plane path: reciprocal-space kernel values [nzc][nx][ny] in the permuted order of the in-place transforms (filled at rebuild time)
-    typename Vec<Real>::T2* planeB;     // plane path (pme.hip k_planeXY): [nsub][nzc][nx][ny] convolved potentials before the lambda mix; null: path off
+    typename Vec<Real>::T2* planeB;     // plane path (pme.hip k_planeXY): convolved potentials before the lambda mix, in the inverse z kernel's order [nx][y tile][nsub][nzc][8]; null: path off
     const typename Vec<Real>::T2* twx; const typename Vec<Real>::T2* twy; const typename Vec<Real>::T2* twz;   // roots of unity exp(-2 pi i k/n)
     const Real* modx; const Real* mody; const Real* modz;       // B-spline moduli
     Real recip[9];            // reciprocal box (ReferencePME.cpp:186-194)
