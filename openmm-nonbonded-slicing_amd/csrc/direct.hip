@@ -15,6 +15,8 @@
 // per-pair slice arithmetic at all (the reference computes the slice index and loads LAMBDA[slice] per pair).
 #include "snb_internal.h"
 #include <hip/hip_ext.h>
+#include <algorithm>
+#include <map>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -74,6 +76,68 @@ __device__ inline double waveSum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// Physical CU of the calling wave: XCC_ID[2:0] (hardware register 20) and the SE_ID | SH_ID | CU_ID bits 15:8 of HW_ID (register 4).
+// Used only to count co-resident work-groups of one launch (SNB_CU_SLOTS entries).
+__device__ inline int physicalCu() {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);      // size-1 = 3, offset 0
+    const unsigned cu = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);        // size-1 = 7, offset 8
+    return (int)(((xcc & 7u) << 8) | (cu & 255u));
+}
+
+// CU-limited launch of an overlapped step (engine.hip, overlapMode): may this work-group stay on its CU?  Called by every thread (one barrier).
+// The reciprocal pipeline's work-groups need what the limit leaves free IN ONE PIECE: registers are allocated as contiguous ranges per
+// wave, and two resident pair work-groups picked by order of arrival sit at random two of the four positions the dispatcher filled,
+// which leaves the plane kernel's 4 x 64 registers per SIMD without room on a third of the CUs (measured: it then waits for the pair
+// kernel to end).  So the rule is positional: a work-group stays when each of its four waves was allocated within the lowest
+// cuBaseMax + its own size registers of its SIMD (VGPR_BASE, bits 5:0 of GPR_ALLOC, in units of 8 registers) -- on an idle CU exactly the
+// first cuLimit work-groups the dispatcher placed -- and everything above them stays free and contiguous.  cuBaseMax < 0: the arrival-count rule.
+// cuSlots[key]: arrivals in the low half, work-groups that stayed in the high half (statistics, SNB_OVERLAP_DEBUG).
+template <typename P> __device__ inline bool cuResident(const P& p) {
+    __shared__ int s_base[4];
+    __shared__ int s_stay;
+    if ((threadIdx.x & 63) == 0) s_base[threadIdx.x >> 6] = (int)__builtin_amdgcn_s_getreg((5 << 11) | (0 << 6) | 5);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int maxBase = max(max(s_base[0], s_base[1]), max(s_base[2], s_base[3]));
+        const int key = physicalCu();
+        int stay, old;
+        if (p.cuBaseMax >= 0) { stay = maxBase <= p.cuBaseMax ? 1 : 0; old = atomicAdd(&p.cuSlots[key], stay ? 0x10001 : 1) & 0xFFFF; }
+        else { old = atomicAdd(&p.cuSlots[key], 1) & 0xFFFF; stay = old < p.cuLimit ? 1 : 0; if (stay) atomicAdd(&p.cuSlots[key], 0x10000); }
+        s_stay = stay;
+        if (p.cuTrace && old < 4) { p.cuTrace[(key * 4 + old) * 2] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 5) ^ (stay << 31); p.cuTrace[(key * 4 + old) * 2 + 1] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 6); }      // GPR_ALLOC (top bit: stayed), LDS_ALLOC
+    }
+    __syncthreads();
+    return s_stay != 0;
+}
+
+// Work items of an overlapped step are handed out through SNB_WORK_SHARDS counters, each on a 128-byte line of its own; counter k owns items
+// k, k + SNB_WORK_SHARDS, ... (the list is sorted longest first, so every counter's sequence is too).  One counter for all waves serialises
+// at ~15 ns per claim (same-address device-scope atomics: 28 768 claims = 0.44 ms, measured) -- sixteen are far below that rate.
+// A wave starts at a home counter and, once that one is exhausted, reads all counters in one load and moves to the next one with items left.
+struct WorkClaim {
+    int* ctr; int numWork, shard, lane;
+    __device__ int issue() const { int v = 0; if (lane == 0) v = atomicAdd(&ctr[shard * 32], 1); return v; }      // lane 0 holds the claim
+    __device__ bool anyLeft() const {      // (one load of all counters: a launch that arrives when everything is claimed leaves after one round trip)
+        int left = 0;
+        if (lane < SNB_WORK_SHARDS) left = (numWork - lane + SNB_WORK_SHARDS - 1) / SNB_WORK_SHARDS - __hip_atomic_load(&ctr[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __ballot(left > 0) != 0;
+    }
+    __device__ int resolve(int v) {      // item index of a claim issued on `shard`, moving on to other counters when that one has run out; numWork: no items left
+        int idx = shard + SNB_WORK_SHARDS * __builtin_amdgcn_readfirstlane(v);
+        while (idx >= numWork) {
+            int left = 0;
+            if (lane < SNB_WORK_SHARDS) left = (numWork - lane + SNB_WORK_SHARDS - 1) / SNB_WORK_SHARDS - __hip_atomic_load(&ctr[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned m = (unsigned)__ballot(left > 0);
+            if (m == 0) return numWork;
+            const int from = (shard + 1) & (SNB_WORK_SHARDS - 1);
+            const unsigned rot = ((m | (m << SNB_WORK_SHARDS)) >> from) & ((1u << SNB_WORK_SHARDS) - 1);
+            shard = (from + __builtin_ctz(rot)) & (SNB_WORK_SHARDS - 1);
+            idx = shard + SNB_WORK_SHARDS * __builtin_amdgcn_readfirstlane(issue());
+        }
+        return idx;
+    }
+};
 
 __device__ inline int sliceOf(int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
 
@@ -228,21 +292,30 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
 // exceptions -- so that their latency-bound work overlaps the tile work instead of trailing it as a 65 us launch of its own on c5)
 template <typename Real, int MC, bool WRAP, bool ENERGY>
 __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)) void k_direct(const DirectParams<Real> p, const PairListParams<Real> q, const int nExclBlocks, const int nListBlocks) {
-    if ((int)blockIdx.x < nListBlocks) {      // (energy steps: the list bodies reduce their slice energies in 2 S doubles of dynamic LDS)
-        if ((int)blockIdx.x < nExclBlocks) { PairListParams<Real> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<Real, ENERGY>(qe, blockIdx.x); }
-        else exceptionsBody<Real, ENERGY>(q, blockIdx.x - nExclBlocks);
+    // (a CU-limited launch takes its list blocks LAST: its tile work-groups must be the first thing the dispatcher places on the idle CUs)
+    const int listBlock = p.listsLast ? (int)blockIdx.x - ((int)gridDim.x - nListBlocks) : (int)blockIdx.x;
+    if (listBlock >= 0 && listBlock < nListBlocks) {      // (energy steps: the list bodies reduce their slice energies in 2 S doubles of dynamic LDS)
+        if (listBlock < nExclBlocks) { PairListParams<Real> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<Real, ENERGY>(qe, listBlock); }
+        else exceptionsBody<Real, ENERGY>(q, listBlock - nExclBlocks);
         return;
     }
-    const int tileBlock = blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
+    const int tileBlock = p.listsLast ? (int)blockIdx.x : (int)blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
     double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
     using T4 = typename Vec<Real>::T4;
     using T2 = typename Vec<Real>::T2;
     __shared__ T4 s_pos[4][64];
     __shared__ T2 s_se[4][64];
-
+    // (overlapped steps: CU-limited first launch and items through the device counters, as in k_directPacked)
+    if (p.cuSlots != nullptr && p.cuLimit > 0 && !cuResident(p)) return;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int item = tileBlock * 4 + wid; item < p.numWork; item += nTileBlocks * 4) {   // no block-level barrier inside the loop
+    const bool dyn = p.workCounter != nullptr;
+    WorkClaim wc{p.workCounter, p.numWork, (tileBlock * 4 + wid) & (SNB_WORK_SHARDS - 1), lane};
+    int item = tileBlock * 4 + wid;
+    if (dyn) item = wc.anyLeft() ? wc.resolve(wc.issue()) : p.numWork;
+    for (; item < p.numWork; ) {   // no block-level barrier inside the loop
+    int claimed = 0;
+    if (dyn) claimed = wc.issue();
     const int4 wi = p.workItems[p.workStart + item * p.workStride];
     const int I = __builtin_amdgcn_readfirstlane(wi.x);
     const int tBegin = __builtin_amdgcn_readfirstlane(wi.y), tEnd = tBegin + __builtin_amdgcn_readfirstlane(wi.z);
@@ -353,6 +426,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
         if (lane == 0) { atomicAdd(&sliceE[2 * curSlice], a); atomicAdd(&sliceE[2 * curSlice + 1], b); }
     }
     __builtin_amdgcn_wave_barrier();
+    item = dyn ? wc.resolve(claimed) : item + nTileBlocks * 4;
     }   // work-item loop
 }
 
@@ -479,12 +553,13 @@ template <typename Real, bool ENERGY> __device__ __forceinline__ void exclusionA
 // work that overlaps the VALU-bound tile work instead of trailing it as a launch of its own); the others loop over tile work items.
 template <int MC, bool POLY, bool ENERGY, bool SWITCH, bool FIXED>
 __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<float> p, const PairListParams<float> q, const int nExclBlocks, const int nListBlocks) {
-    if ((int)blockIdx.x < nListBlocks) {      // (energy steps: the list bodies reduce their slice energies in 2 S doubles of dynamic LDS)
-        if ((int)blockIdx.x < nExclBlocks) { PairListParams<float> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<float, ENERGY>(qe, blockIdx.x); }
-        else exceptionsBody<float, ENERGY>(q, blockIdx.x - nExclBlocks);
+    const int listBlock = p.listsLast ? (int)blockIdx.x - ((int)gridDim.x - nListBlocks) : (int)blockIdx.x;      // (CU-limited launch: list blocks last, see k_direct)
+    if (listBlock >= 0 && listBlock < nListBlocks) {      // (energy steps: the list bodies reduce their slice energies in 2 S doubles of dynamic LDS)
+        if (listBlock < nExclBlocks) { PairListParams<float> qe = q; qe.n = q.nExclAtoms; exclusionAtomsBody<float, ENERGY>(qe, listBlock); }
+        else exceptionsBody<float, ENERGY>(q, listBlock - nExclBlocks);
         return;
     }
-    const int tileBlock = blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
+    const int tileBlock = p.listsLast ? (int)blockIdx.x : (int)blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
     double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
     __shared__ float4 s_pos[4][64];
     __shared__ float2 s_se[4][64];
@@ -495,10 +570,19 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         const float ka = float(kx - 2), kb = float(ky - 2), kc = float(kz - 2);
         s_shift[sc] = sc < 125 ? make_float4(ka * p.box[0] + kb * p.box[3] + kc * p.box[6], kb * p.box[4] + kc * p.box[7], kc * p.box[8], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();
+    // CU-limited first launch of an overlapped step: work-groups beyond the limit leave at once (the items are handed out through the
+    // counters, so nothing is lost) and the reciprocal pipeline's work-groups always find the registers and LDS the limit leaves free
+    if (p.cuSlots != nullptr && p.cuLimit > 0) { if (!cuResident(p)) return; }
+    else __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int item = tileBlock * 4 + wid; item < p.numWork; item += nTileBlocks * 4) {   // no block-level barrier inside the loop
+    const bool dyn = p.workCounter != nullptr;      // (uniform) items through the device counters: every wave of either launch claims one at a time
+    WorkClaim wc{p.workCounter, p.numWork, (tileBlock * 4 + wid) & (SNB_WORK_SHARDS - 1), lane};
+    int item = tileBlock * 4 + wid;
+    if (dyn) item = wc.anyLeft() ? wc.resolve(wc.issue()) : p.numWork;
+    for (; item < p.numWork; ) {   // no block-level barrier inside the loop
+    int claimed = 0;
+    if (dyn) claimed = wc.issue();      // the next item, requested a whole item ahead (claims past the end are harmless)
     const int4 wi = p.workItems[p.workStart + item * p.workStride];
     const int I = __builtin_amdgcn_readfirstlane(wi.x);
     const int tBegin = __builtin_amdgcn_readfirstlane(wi.y), tEnd = tBegin + __builtin_amdgcn_readfirstlane(wi.z);
@@ -539,7 +623,11 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     // (the j-force atomics of a tile are issued at the start of the NEXT trip: an atomic sits behind a conditional skip the wait-count
     // pass cannot count, so any wait after it degrades to "everything"; issued first, they are a whole tile old when that wait comes)
     float pendX = 0.f, pendY = 0.f, pendZ = 0.f; int pendIdx = -1;
+#ifdef SNB_EXP_NO_JATOMICS      // experiment builds only (wrong forces): the kernel without its j-force scatter
+    auto flushPending = [&]() { asm volatile("" :: "v"(pendX), "v"(pendY), "v"(pendZ), "v"(pendIdx)); };
+#else
     auto flushPending = [&]() { if (pendIdx >= 0) { fAddT<FIXED>(p, p.fx, pendIdx, pendX); fAddT<FIXED>(p, p.fy, pendIdx, pendY); fAddT<FIXED>(p, p.fz, pendIdx, pendZ); } };
+#endif
     auto requestList = [&](TileRegs& r, int t) {                    // list entry + header of tile t
         r.jcode = p.tileJ[t * 32 + stageJ];
         const int2 v = *reinterpret_cast<const int2*>(&p.tileInfo[t + vzero]);
@@ -618,20 +706,35 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     if (row == 1) { fAddT<FIXED>(p, p.fx, (I * 32 + 16 + c), ux); fAddT<FIXED>(p, p.fy, (I * 32 + 16 + c), uy); fAddT<FIXED>(p, p.fz, (I * 32 + 16 + c), uz); }
     if (ENERGY) { if (curNeeded) flushEnergy(); curSlice = -1; curNeeded = false; }
     __builtin_amdgcn_wave_barrier();
+    item = dyn ? wc.resolve(claimed) : item + nTileBlocks * 4;
     }   // work-item loop
 }
 
 
 // evStart/evStop (both or neither): hipExtLaunchKernelGGL stamps them with the kernel's own begin and end -- the duration rocprofv3 reports,
 // without the marker-packet overhead of hipEventRecord pairs around the launch.  *timed tells the caller whether a kernel took them.
-#define SNB_LAUNCH_LDS(KERNEL, GRID, LDS, ...) do { if (evStart) { hipExtLaunchKernelGGL(KERNEL, GRID, block, LDS, s, evStart, evStop, 0, __VA_ARGS__); *timed = true; } \
-                                                    else hipLaunchKernelGGL(KERNEL, GRID, block, LDS, s, __VA_ARGS__); } while (0)
+// (a CU-limited launch of an overlapped step is told where its resident work-groups may sit: below (cuLimit - 1) allocations of this kernel)
+#define SNB_LAUNCH_LDS(KERNEL, GRID, LDS, P, ...) do { auto p_ = (P); if (p_.cuSlots && p_.cuLimit > 0 && p_.cuBaseMax == 0x7fffffff) p_.cuBaseMax = (p_.cuLimit - 1) * vgprUnits((const void*)(KERNEL)); \
+                                                    if (evStart) { hipExtLaunchKernelGGL(KERNEL, GRID, block, LDS, s, evStart, evStop, 0, p_, __VA_ARGS__); *timed = true; } \
+                                                    else hipLaunchKernelGGL(KERNEL, GRID, block, LDS, s, p_, __VA_ARGS__); } while (0)
+// register allocation of a kernel in the hardware's units of 8 VGPRs (accumulation registers included), looked up once per kernel
+static int vgprUnits(const void* kernel) {
+    static std::map<const void*, int> cache;
+    auto it = cache.find(kernel);
+    if (it != cache.end()) return it->second;
+    hipFuncAttributes attr;
+    int units = 16;
+    if (hipFuncGetAttributes(&attr, kernel) == hipSuccess && attr.numRegs > 0) units = (attr.numRegs + 7) / 8;
+    cache[kernel] = units;
+    return units;
+}
 #define SNB_LAUNCH(KERNEL, GRID, ...) SNB_LAUNCH_LDS(KERNEL, GRID, 0, __VA_ARGS__)
 template <typename Real, int MC> static bool launchDirectMC(const DirectParams<Real>& p, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s, hipEvent_t evStart, hipEvent_t evStop, bool* timed) {
     const int myItems = p.numWork;
     if (myItems <= 0) return false;
     int nwg = (myItems + 3) / 4;
     { static const int cap = getenv("SNB_DIRECT_WGS") ? atoi(getenv("SNB_DIRECT_WGS")) : 0; if (cap > 0 && nwg > cap) nwg = cap; }
+    if (p.workCounter && p.gridCap > 0) nwg = p.cuLimit > 0 ? p.gridCap : std::min(nwg, p.gridCap);      // overlapped step: resident waves claim their items
     dim3 grid(nwg), block(256);
     if constexpr (std::is_same<Real, float>::value) {
         static const bool scalarEnergy = getenv("SNB_SCALAR_ENERGY_KERNEL") != nullptr;

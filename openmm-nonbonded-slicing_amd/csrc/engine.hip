@@ -181,6 +181,10 @@ template <typename Real> struct PmePlan {
     void init(const int g[3], int nGrids, hipStream_t s) {
         d.nx = g[0]; d.ny = g[1]; d.nz = g[2]; d.nzc = g[2] / 2 + 1;
         if (!factorize(d.nx, d.fx, &d.nfx) || !factorize(d.ny, d.fy, &d.nfy) || !factorize(d.nz, d.fz, &d.nfz)) throw HipError{"PME mesh size is not FFT-legal"};
+        // pme.hip divides index values by reciprocal multiplication (FastDiv: exact for dividends below 2^22).  Its dividends are LDS element
+        // indices of one work-group (< 40 960), line / chunk counts of one brick, and indices into one mesh plane or one (y, kz) slab:
+        // at most 1024 x 1024 = 2^20 under this cap.
+        if (d.nx > 1024 || d.ny > 1024 || d.nz > 1024) throw HipError{"PME mesh dimensions above 1024 are not supported"};
         splitTwoPass(d.nx, &d.rx1, &d.rx2); splitTwoPass(d.ny, &d.ry1, &d.ry2); splitTwoPass(d.nz, &d.rz1, &d.rz2);
         // measured on MI355X (120^3 = 8 x 15, 4 grids, single precision, Winograd radix-3/5 butterflies): two-pass register FFT vs
         // staged Stockham: inverse z 18.2 vs 23.5 us, y 30.6 vs 32.4, fused x/convolution 68.6 vs 71.0.  SNB_FFT_TWOPASS=0/1 overrides.
@@ -221,10 +225,21 @@ public:
     static constexpr int RING = 32;
     hipEvent_t evRebuild[3] = {nullptr, nullptr, nullptr};
     hipEvent_t evStepDone[2] = {nullptr, nullptr}; long long stepCounter = 0;      // displacement-triggered rebuilds: end-of-execute events
-    hipStream_t stream2 = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipStream_t stream2 = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr, evPairA = nullptr;
     // measured on c3: serial 0.80 ms/step, forked 0.87 (default priority) / 1.32 (high or low priority): the graph's cross-stream
     // dependencies cost more than the overlap returns, so the fork is opt-in
     bool concurrentPme = getenv("SNB_CONCURRENT_PME") && atoi(getenv("SNB_CONCURRENT_PME"));
+    // Overlapped steps (round 4; the reference runs its reciprocal pipeline on a queue of its own beside the pair kernel,
+    // CommonNonbondedSlicingKernels.cpp:520-530, 1176-1179, 1377-1380).  Graph steps run the PME chain on stream2 while a first launch of
+    // the tile kernel, held to overlapCuLimit work-groups per CU (its work-groups count themselves per physical CU and leave when the
+    // CU is full), runs beside it; a second launch behind the chain fills the chip.  Both launches claim their work items from one
+    // device counter, so the split follows the chain's actual duration.  Eager (stamped) steps stay serial: the per-kernel timers keep
+    // measuring every kernel alone.  dOverlap: [0] the counter, [16 ...] the SNB_CU_SLOTS residency counts; zeroed by the gather pass.
+    int overlapMode = getenv("SNB_OVERLAP") ? atoi(getenv("SNB_OVERLAP")) : 0;
+    int overlapCuLimit = getenv("SNB_OVERLAP_CU_LIMIT") ? atoi(getenv("SNB_OVERLAP_CU_LIMIT")) : 2;
+    int overlapGridA = getenv("SNB_OVERLAP_GRID_A") ? atoi(getenv("SNB_OVERLAP_GRID_A")) : 0;      // 0: six work-groups per CU
+    int overlapGridB = getenv("SNB_OVERLAP_GRID_B") ? atoi(getenv("SNB_OVERLAP_GRID_B")) : 0;      // 0: four work-groups per CU
+    int numCUs = 256; DevBuf<int> dOverlap, dOverlapTrace;
     struct EvSet { hipEvent_t e[5]; bool pending = false; KernelStamps ks; };   // start, direct0, direct1(=recip0 after pair lists), recip1, end; per-kernel stamps (snb_stats.sum_kernel_ms)
     std::vector<EvSet> ring; int ringPos = 0;
     // host-side definition
@@ -319,6 +334,9 @@ public:
         HIPCHECK(hipSetDevice(c.device));
         if (c.stream) stream = (hipStream_t)c.stream; else { HIPCHECK(hipStreamCreate(&stream)); ownStream = true; }
         ring.resize(RING);
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0) numCUs = prop.multiProcessorCount; }
+        if (overlapMode) { dOverlap.resize(SNB_OVERLAP_INTS); HIPCHECK(hipMemsetAsync(dOverlap.p, 0, sizeof(int) * SNB_OVERLAP_INTS, stream)); }
+        if (overlapMode && getenv("SNB_OVERLAP_DEBUG")) { dOverlapTrace.resize(SNB_CU_SLOTS * 8); HIPCHECK(hipMemsetAsync(dOverlapTrace.p, 0xff, sizeof(int) * SNB_CU_SLOTS * 8, stream)); }
         for (auto& r : ring) { for (int k = 0; k < 5; k++) HIPCHECK(hipEventCreate(&r.e[k])); for (int k = 0; k < 16; k++) { HIPCHECK(hipEventCreate(&r.ks.start[k])); HIPCHECK(hipEventCreate(&r.ks.stop[k])); } }
         charge.assign(N, 0.0); sigma.assign(N, 1.0); epsilon.assign(N, 0.0); subset.assign(N, 0);
         lambdas.assign((size_t)S * 2, 1.0); dispCoef.assign(S, 0.0); hostSliceE.assign((size_t)S * 2, 0.0);
@@ -364,7 +382,7 @@ public:
         for (int k = 0; k < 3; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
         for (int k = 0; k < 2; k++) if (evStepDone[k]) (void)hipEventDestroy(evStepDone[k]);
         if (hDispFlags) (void)hipHostFree(hDispFlags);
-        if (stream2) { (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); (void)hipStreamDestroy(stream2); }
+        if (stream2) { (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); (void)hipEventDestroy(evPairA); (void)hipStreamDestroy(stream2); }
         if (ownStream) (void)hipStreamDestroy(stream);
     }
     // Real-space Ewald force factor of the single-precision forces-only pair kernel:
@@ -1281,11 +1299,11 @@ public:
             hipGraphExec_t graphExec = nullptr;
             for (auto& g : graphs) if (g.key == key) { graphExec = g.exec; break; }
             if (!graphExec) {
-                if (!stream2 && concurrentPme) {   // created outside the capture
+                if (!stream2 && (concurrentPme || overlapMode)) {   // created outside the capture
                     int lo = 0, hi = 0;
                     HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
                     HIPCHECK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, getenv("SNB_PME_PRIO_LOW") ? lo : (getenv("SNB_PME_PRIO_HIGH") ? hi : (lo + hi) / 2)));
-                    HIPCHECK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
+                    HIPCHECK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&evPairA, hipEventDisableTiming));
                 }
                 hipGraph_t graph = nullptr;
                 HIPCHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -1298,6 +1316,7 @@ public:
                 else { (void)hipGraphExecDestroy(graphs[graphVictim].exec); graphs[graphVictim] = {key, graphExec}; graphVictim = (graphVictim + 1) % MAX_GRAPHS; }
             }
             HIPCHECK(hipGraphLaunch(graphExec, stream));
+            if (overlapMode && dOverlap.p) { static int dbg = getenv("SNB_OVERLAP_DEBUG") ? 3 : 0; if (dbg > 0) { dbg--; dumpOverlapTable(); } }
         }
         if (autoMode && cfg.neighbor_padding > 0) {
             hipEvent_t& ev = evStepDone[stepCounter & 1];
@@ -1309,6 +1328,32 @@ public:
             energyPending = true;
             if (energyOut) { fetchSliceEnergies(); double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }      // (synchronises)
         } else if (energyOut) *energyOut = 0.0;
+    }
+
+    // SNB_OVERLAP_DEBUG: how the limited launch of the last overlapped step spread over the physical CUs (synchronises)
+    void dumpOverlapTable() {
+        std::vector<int> h(SNB_OVERLAP_INTS);
+        HIPCHECK(hipStreamSynchronize(stream));
+        HIPCHECK(hipMemcpy(h.data(), dOverlap.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+        int keys = 0, stayed = 0, arrived = 0, hist[8] = {0}; unsigned orKey = 0;
+        const int* cu = h.data() + SNB_WORK_SHARDS * 32; int claims = 0; for (int k = 0; k < SNB_WORK_SHARDS; k++) claims += h[k * 32];
+        int stayHist[8] = {0};
+        for (int k = 0; k < SNB_CU_SLOTS; k++) if (cu[k] > 0) { const int arr = cu[k] & 0xFFFF, st = cu[k] >> 16; keys++; arrived += arr; stayed += st; hist[std::min(arr, 7)]++; stayHist[std::min(st, 7)]++; orKey |= (unsigned)k; }
+        fprintf(stderr, "[snb] overlap: items claimed %d of %d; %d CU keys seen (or of keys 0x%x), %d work-groups arrived, %d stayed; arrivals per key 1..7+:", claims, numWorkItems, keys, orKey, arrived, stayed);
+        for (int k = 1; k < 8; k++) fprintf(stderr, " %d", hist[k]);
+        fprintf(stderr, "; CUs with 0..4 resident:");
+        for (int k = 0; k < 5; k++) fprintf(stderr, " %d", stayHist[k]);
+        fprintf(stderr, "\n");
+        if (dOverlapTrace.p) {
+            std::vector<int> t(SNB_CU_SLOTS * 8);
+            HIPCHECK(hipMemcpy(t.data(), dOverlapTrace.p, sizeof(int) * t.size(), hipMemcpyDeviceToHost));
+            int shown = 0;
+            for (int k = 0; k < SNB_CU_SLOTS && shown < 12; k++) if (cu[k] > 0) {
+                fprintf(stderr, "[snb] overlap: CU key 0x%03x arrivals %d, stayed %d: (GPR_ALLOC, LDS_ALLOC) of the first four:", k, cu[k] & 0xFFFF, cu[k] >> 16);
+                for (int a = 0; a < 4; a++) fprintf(stderr, " (%08x, %08x)", (unsigned)t[(k * 4 + a) * 2], (unsigned)t[(k * 4 + a) * 2 + 1]);
+                fprintf(stderr, "\n"); shown++;
+            }
+        }
     }
 
     // The raw slice energies of the last energy step, read back on demand (the only synchronisation of an energy / derivative step)
@@ -1352,12 +1397,15 @@ public:
         }
         if (energy && Npad > 0) { gc.clearE = sliceE.p; gc.nClearE = S * 2 * SNB_SLICE_E_PARTS; }
         if (includeRecip && isPme() && dStrayCount.p) { gc.zeroInts = dStrayCount.p; gc.nZeroInts = 2; }
+        if (!ev && overlapMode && dOverlap.p) { gc.zeroInts2 = dOverlap.p; gc.nZeroInts2 = SNB_OVERLAP_INTS; }
         launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, forceBuf.p, forceArrays(), gc, stream);
         if (energy && Npad <= 0) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2 * SNB_SLICE_E_PARTS, stream));
         const bool ew = cfg.method >= SNB_Ewald;
         // Opt-in (SNB_CONCURRENT_PME=1): forces-only graph steps run the reciprocal pipeline on a second stream beside the pair
         // kernel (disjoint force arrays fx.. / fpx..).  Timed (eager) steps stay serial so the per-kernel event timers stay clean.
-        const bool fork = !ev && !energy && includeDirect && includeRecip && isPme() && nGrids > 0 && concurrentPme && stream2;
+        // overlapped step (see overlapMode above): any graph step with both halves; needs the GPU-built work list (static item order is irrelevant)
+        const bool overlap = !ev && overlapMode && includeDirect && includeRecip && isPme() && nGrids > 0 && stream2 && dOverlap.p && numWorkItems > 0;
+        const bool fork = overlap || (!ev && !energy && includeDirect && includeRecip && isPme() && nGrids > 0 && concurrentPme && stream2);
         hipStream_t pmeStream = stream;
         if (fork) {
             HIPCHECK(hipEventRecord(evFork, stream));
@@ -1379,6 +1427,8 @@ public:
             q.nExclAtoms = (ew && nExcl > 0) ? Npad : 0;
         }
         bool listsDone = !haveLists, kernelTimed = false, finished = false;
+        DirectParams<Real> directB; int directMc = 0;      // overlapped step: the second launch of the tile kernel
+        std::memset(&directB, 0, sizeof(directB));
         if (includeDirect) {
             DirectParams<Real> p;
             std::memset(&p, 0, sizeof(p));
@@ -1412,10 +1462,18 @@ public:
             else if (cfg.method == SNB_Ewald || cfg.method == SNB_PME) mc = MC_EWALD;
             else if (cfg.method == SNB_LJPME) mc = MC_LJPME;
             static const bool noFuse = getenv("SNB_NO_FUSED_LISTS") != nullptr;
+            if (overlap) {      // first launch: resident beside the reciprocal pipeline, at most overlapCuLimit work-groups per CU
+                p.workCounter = dOverlap.p; p.cuSlots = dOverlap.p + SNB_WORK_SHARDS * 32; p.cuLimit = overlapCuLimit;
+                { static const bool byCount = getenv("SNB_OVERLAP_BY_COUNT") != nullptr; p.cuBaseMax = byCount ? -1 : 0x7fffffff; }      // (0x7fffffff: the launcher fills in the kernel's own allocation)
+                p.gridCap = overlapGridA > 0 ? overlapGridA : 6 * numCUs; p.listsLast = 1;
+                p.cuTrace = dOverlapTrace.p;      // (SNB_OVERLAP_DEBUG; null otherwise)
+                directB = p; directMc = mc;
+            }
             if (launchDirect<Real>(p, mc, wrapMode, energy, (haveLists && !noFuse) ? &q : nullptr, stream, ev ? ev->e[1] : nullptr, ev ? ev->e[2] : nullptr, &kernelTimed)) listsDone = true;
         }
         if (ev && !kernelTimed) { HIPCHECK(hipEventRecord(ev->e[1], stream)); HIPCHECK(hipEventRecord(ev->e[2], stream)); }   // no tile kernel this step
         if (!listsDone) launchPairLists<Real>(q, energy, stream);
+        if (overlap) HIPCHECK(hipEventRecord(evPairA, stream));      // the first launch of the tile kernel (and the pair lists) are done
         if (ev) HIPCHECK(hipEventRecord(ev->e[3], stream));
         if (includeRecip && isPme()) {
             if (nGrids > 0) {
@@ -1424,14 +1482,32 @@ public:
                 // the interpolation of the step's last mesh also writes the user-order force (no k_finishForces launch): unsharded, brick path,
                 // reciprocal work on the step's own stream (the pair kernel's accumulators are complete by then)
                 static const bool noFuse = getenv("SNB_NO_FUSED_FINISH") != nullptr;
-                const bool canFinish = outPtr && !fork && !noFuse && cfg.shard_count == 1;
+                // (an overlapped step keeps the fused finish: its last interpolation waits for both launches of the tile kernel)
+                const bool canFinish = outPtr && (!fork || overlap) && !noFuse && cfg.shard_count == 1;
                 auto withOutput = [&](PmeParams<Real>& q, bool last) {
                     q.outForces = (canFinish && last) ? outPtr : nullptr; q.outIsDouble = outIsDouble; q.outAccumulate = outAccumulate;
                     q.dfx = fx.p; q.dfy = fy.p; q.dfz = fz.p; q.dfs = fstride; q.dfixed = fixedForces(); q.sortedToUser = dSortedToUser.p;
                 };
+                // Overlapped step: everything up to the last mesh's inverse transform runs beside the resident first launch of the tile kernel;
+                // then the second launch (unlimited: it takes what the first has not claimed, and the first keeps claiming) fills the chip,
+                // and the last interpolation -- which also delivers the step's forces -- follows both.
+                auto beforeLastInterpolation = [&]() {
+                    if (!overlap) return;
+                    directB.cuSlots = nullptr; directB.cuLimit = 0; directB.listsLast = 0; directB.gridCap = overlapGridB > 0 ? overlapGridB : 4 * numCUs;
+                    bool t = false;
+                    launchDirect<Real>(directB, directMc, wrapMode, energy, nullptr, stream2, nullptr, nullptr, &t);
+                    HIPCHECK(hipStreamWaitEvent(stream2, evPairA, 0));
+                };
                 fillPme(pp, pme, energy); withOutput(pp, cfg.method != SNB_LJPME);
-                finished = runPme(pp, pmeStream);
-                if (cfg.method == SNB_LJPME) { fillPme(pp, dpme, energy); withOutput(pp, true); finished = runPme(pp, pmeStream); }
+                runPmeFront(pp, pmeStream);
+                if (cfg.method != SNB_LJPME) beforeLastInterpolation();
+                finished = launchPmeInterpolate<Real>(pp, pmeStream);
+                if (cfg.method == SNB_LJPME) {
+                    fillPme(pp, dpme, energy); withOutput(pp, true);
+                    runPmeFront(pp, pmeStream);
+                    beforeLastInterpolation();
+                    finished = launchPmeInterpolate<Real>(pp, pmeStream);
+                }
             }
         }
         if (fork) { HIPCHECK(hipEventRecord(evJoin, stream2)); HIPCHECK(hipStreamWaitEvent(stream, evJoin, 0)); }
@@ -1499,7 +1575,7 @@ public:
     // (also restarts the eager-step cadence: the first step after a reset is a timed one, so even a short measured region has a sample)
     void resetTimers() override { for (auto& r : ring) if (r.pending) harvest(r); stats.sum_direct_ms = stats.sum_recip_ms = stats.sum_total_ms = 0; stats.n_timed = 0; for (int k = 0; k < 16; k++) { stats.sum_kernel_ms[k] = 0; stats.n_kernel_timed[k] = 0; } execCount = 0; stampCounter = 0; }
 
-    bool runPme(PmeParams<Real>& pp, hipStream_t st) {      // true: its interpolation kernel delivered the user-order forces (pp.outForces)
+    void runPmeFront(PmeParams<Real>& pp, hipStream_t st) {      // one mesh up to its potentials in real space; launchPmeInterpolate follows
         const int zDone = launchPmeSpread<Real>(pp, st);
         if (zDone == 2) launchPmePlanePath<Real>(pp, st);      // per-plane x / y transforms + convolution in LDS, then mix + inverse z
         else {
@@ -1507,7 +1583,6 @@ public:
             launchPmeConvolution<Real>(pp, st);
             launchPmeInverseFFT<Real>(pp, st);
         }
-        return launchPmeInterpolate<Real>(pp, st);
     }
 
     void setForceOutput(void* out, int isDouble, int accumulate) override { outPtr = out; outIsDouble = isDouble; outAccumulate = accumulate; outputWritten = false; }

@@ -15,6 +15,7 @@ __global__ void k_gatherPositions(const In* __restrict__ userPos, int stride, co
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (gc.clearE) for (int i = s; i < gc.nClearE; i += gridDim.x * blockDim.x) gc.clearE[i] = 0.0;
     if (gc.zeroInts && s < gc.nZeroInts) gc.zeroInts[s] = 0;
+    if (gc.zeroInts2) for (int i = s; i < gc.nZeroInts2; i += gridDim.x * blockDim.x) gc.zeroInts2[i] = 0;
     if (s >= nPadded) return;
     if (forces) {
         for (int k = 0; k < nClear; k++) forces[(size_t)k * nPadded + s] = Real(0);      // 7: 4 n direct-space (either layout) + 3 n reciprocal; 10 with 64-bit accumulators

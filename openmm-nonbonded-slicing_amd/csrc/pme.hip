@@ -26,7 +26,9 @@ namespace snb {
 thread_local KernelStamps* g_stamps = nullptr;
 template <typename Real> static inline int stampSlot(const PmeParams<Real>& p, int k) { return k + (p.dispersion ? 8 : 0); }
 
-// x / d for 0 <= x < 2^22 without the ~35-instruction integer division: (x + 0.5) * (1/d) never lands within rounding error of an integer
+// x / d for 0 <= x < 2^22 without the ~35-instruction integer division: (x + 0.5) * (1/d) never lands within rounding error of an integer.
+// Every dividend in this file is bounded by a work-group's LDS element count, a brick's line count or a mesh plane / slab of at most
+// 1024 x 1024 points (PmePlan::init in engine.hip rejects larger meshes).
 struct FastDiv {
     float inv; int d;
     __device__ explicit FastDiv(int d_) : inv(1.0f / (float)d_), d(d_) {}
@@ -1725,9 +1727,8 @@ template void launchPlaneEterm<double>(const PmeParams<double>&, double*, hipStr
 // The middle of the pipeline on the plane path (after a spreader that returned 2): convolution + x / y transforms per plane, then mix + inverse z.
 template <typename Real> void launchPmePlanePath(const PmeParams<Real>& p, hipStream_t s) {
     if constexpr (std::is_same<Real, float>::value) {
-        static const int dbg = getenv("SNB_PLANE_DEBUG") ? atoi(getenv("SNB_PLANE_DEBUG")) : 0;      // diagnosis: 1 = skip the z kernel, 2 = skip the plane kernel, 3 = skip both
-        if (!(dbg & 2)) launchPlaneXY(p, s);
-        if (!(dbg & 1)) launchFftZInvMix(p, s);
+        launchPlaneXY(p, s);
+        launchFftZInvMix(p, s);
     }
 }
 template void launchPmePlanePath<float>(const PmeParams<float>&, hipStream_t);

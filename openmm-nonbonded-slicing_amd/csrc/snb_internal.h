@@ -73,7 +73,21 @@ template <typename Real> struct DirectParams {
     int useSwitch; Real switchDist, invSwitchWidth;
     Real box[9]; Real invBoxDiag[3];                       // for the per-pair wrap variant
     Real boxDiag[3];                                       // rectangular box edge lengths (image codes are decoded against them)
+    // Overlapped steps (engine.hip enqueueStep, "overlap"): the work items are handed out through a device counter to two launches of
+    // the tile kernel -- a resident first launch beside the reciprocal pipeline, held to cuLimit work-groups per CU so that the PME
+    // work-groups always find room, and a second launch that fills the chip once the pipeline is done.  Null: the static item loop.
+    int* workCounter;         // [SNB_WORK_SHARDS][32] claim counters, one per 128-byte line (zeroed by the position-gather pass); direct.hip WorkClaim
+    int* cuSlots;             // [SNB_CU_SLOTS] resident work-groups of the limited launch per physical CU (zeroed by the same pass), or null
+    int cuLimit;              // work-groups of this launch allowed to stay on one CU (0: no limit)
+    int cuBaseMax;            // ... chosen by position: highest VGPR_BASE (units of 8 registers) a staying wave may have; < 0: by order of arrival (direct.hip cuResident)
+    int* cuTrace;             // SNB_OVERLAP_DEBUG: [SNB_CU_SLOTS][4][2] raw GPR_ALLOC / LDS_ALLOC registers of the first four arrivals per CU, or null
+    int gridCap;              // work-groups to launch in the dynamic mode
+    int listsLast;            // the launch's pair-list work-groups (exclusion corrections, 1-4) come after its tile work-groups instead of before them
 };
+// physical CU key of a work-group: XCC_ID (3 bits) | SE_ID, SH_ID, CU_ID of HW_ID (bits 15:8)
+#define SNB_CU_SLOTS 2048
+#define SNB_WORK_SHARDS 16
+#define SNB_OVERLAP_INTS (SNB_WORK_SHARDS * 32 + SNB_CU_SLOTS)      // the step's overlap scratch: claim counters, then the CU table
 
 template <typename Real> struct PairListParams {  // 1-4 exceptions: one thread per pair; exclusion corrections: one thread per atom
     const typename Vec<Real>::T4* posq;
@@ -279,6 +293,7 @@ template <typename Real> struct GatherCells {
     const typename Vec<Real>::T4* posRef; int* flags; Real warn2, fail2;
     double* clearE; int nClearE;      // energy steps: the slice-energy partitions, zeroed by this pass (a memset of their own was a 5 us launch)
     int* zeroInts; int nZeroInts;     // small per-step counters reset by this pass (the spreader's stray-atom counts)
+    int* zeroInts2; int nZeroInts2;   // ... and the work counter + CU table of an overlapped step's pair kernel
 };
 
 template <typename Real> void launchGatherPositions(const void* userPos, int isDouble, int stride4, const int* sortedToUser, const Real* imageOffset,
