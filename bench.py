@@ -622,7 +622,7 @@ def main():
         cpu_ms = tsum / reps * 1e3
         cpu_full_ms = cpu_ms * N / len(ws["q"])
         out["cpu_baseline"] = {"value": round(86.4 * 2.0 / cpu_full_ms, 5), "unit": "ns/day", "cores": cores, "kind": "port",
-                               "sample": "CPU oracle (C restatement of the Reference platform; pair loop serial like the reference, PME FFT/interpolation OpenMP), "
+                               "sample": "CPU oracle (C restatement of the Reference platform; pair list, pair loop and PME FFT / interpolation on OpenMP threads; the reference itself is single-threaded), "
                                          "%d evaluations of a %d-atom/%d-subset box of the same generator (density, cutoff, alpha, 54^3 grid): %.0f ms per evaluation, %d pairs; "
                                          "value = the per-atom cost scaled to the full workload: %.0f ms per evaluation" % (reps, len(ws["q"]), ws["nsub"], cpu_ms, pairs, cpu_full_ms),
                                "ms_per_step_sample": round(cpu_ms, 1), "ms_per_step_scaled": round(cpu_ms * N / len(ws["q"]), 1)}

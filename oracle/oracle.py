@@ -12,6 +12,7 @@ TEST INFRASTRUCTURE ONLY: imported by ``tests/``, ``__graft_entry__.smoke()`` an
 from __future__ import annotations
 
 import ctypes
+import hashlib
 import os
 import subprocess
 
@@ -150,8 +151,39 @@ def evaluate(force, positions, box=None, parameters=None, include_direct=True, i
     forces = np.zeros((r["n"], 3)); sliceE = np.zeros((r["S"], 2))
     lam = np.ascontiguousarray(r["lam"])
     coef = dispersion_coefficients(force) if force.getUseDispersionCorrection() else np.zeros(r["S"])
-    rc = L.orc_evaluate(ctypes.byref(cfg), _dp(pos), _dp(box), _dp(r["q"]), _dp(r["sigma"]), _dp(r["epsilon"]), _ip(r["subset"]),
+    # The parity tests evaluate the same definition and coordinates once per engine precision: identical inputs (every array and scalar
+    # that reaches orc_evaluate) return the stored result instead of a second evaluation.
+    h = hashlib.sha1()
+    for a in (pos, box, r["q"], r["sigma"], r["epsilon"], r["subset"], r["pairs"][:r["m"]], r["qq"][:r["m"]], r["esig"][:r["m"]], r["eeps"][:r["m"]], lam, coef):
+        h.update(np.ascontiguousarray(a).tobytes()); h.update(b"|")
+    h.update(bytes(cfg))
+    key = h.hexdigest()
+    if key in _memo:
+        forces, sliceE, npairs = _memo[key]
+        forces = forces.copy(); sliceE = sliceE.copy()
+        rc = 0
+    else:
+        rc = _call(L, cfg, pos, box, r, lam, coef, forces, sliceE)
+        npairs = int(L.orc_last_pair_count())
+        if rc == 0 and forces.nbytes <= (8 << 20):      # (the test modules run precision by precision: keep a whole pass, up to 400 MB, oldest out first)
+            global _memo_bytes
+            while _memo and _memo_bytes + forces.nbytes > (400 << 20):
+                _memo_bytes -= _memo.pop(next(iter(_memo)))[0].nbytes
+            _memo[key] = (forces.copy(), sliceE.copy(), npairs)
+            _memo_bytes += forces.nbytes
+    return _finish(rc, r, lam, forces, sliceE, npairs)
+
+
+_memo = {}
+_memo_bytes = 0
+
+
+def _call(L, cfg, pos, box, r, lam, coef, forces, sliceE):
+    return L.orc_evaluate(ctypes.byref(cfg), _dp(pos), _dp(box), _dp(r["q"]), _dp(r["sigma"]), _dp(r["epsilon"]), _ip(r["subset"]),
                         r["m"], _ip(r["pairs"]), _dp(r["qq"]), _dp(r["esig"]), _dp(r["eeps"]), _dp(lam), _dp(coef), _dp(forces), _dp(sliceE))
+
+
+def _finish(rc, r, lam, forces, sliceE, npairs):
     if rc == -1:
         raise RuntimeError("The periodic box size has decreased to less than twice the nonbonded cutoff.")
     if rc != 0:
@@ -161,7 +193,7 @@ def evaluate(force, positions, box=None, parameters=None, include_direct=True, i
     for (s, t), name in r["binding"].items():
         if name in derivs:
             derivs[name] += sliceE[s, t]
-    return dict(energy=energy, forces=forces, slice_energies=sliceE, derivatives=derivs, lambdas=lam, pairs=int(L.orc_last_pair_count()))
+    return dict(energy=energy, forces=forces, slice_energies=sliceE, derivatives=derivs, lambdas=lam, pairs=npairs)
 
 
 def dispersion_coefficients(force, parameters=None):

@@ -4,10 +4,13 @@
  * Plain-C restatement of the Reference-platform arithmetic of craabreu/openmm-nonbonded-slicing.
  * Every function cites the reference lines it follows (paths relative to /root/reference).
  * Build: gcc -O2 -fopenmp -shared -fPIC snb_oracle.c -o libsnb_oracle.so -lm   (oracle/Makefile)
+ * The reference's code is single-threaded; here the pair-list build, the pair loops and the PME passes run on OpenMP threads
+ * (round 4: the full-size parity cases must fit the driver's time limit).  Only the order of summation differs between thread counts.
  */
 #include "snb_oracle.h"
 #include <complex.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -91,59 +94,92 @@ static void free_exclusions(excl_t* ex) { free(ex->start); free(ex->list); }
  * Stands in for OpenMM's computeNeighborListVoxelHash (third-party; only the summation order of the
  * pair loop depends on it).  Cell grid for rectangular periodic boxes, brute force otherwise.
  * ---------------------------------------------------------------------------------------------- */
-typedef struct { int* ij; long long n, cap; } pairlist_t;
+typedef struct pairlist_s { int* ij; long long n, cap; struct pairlist_s* parts; int nparts; } pairlist_t;      /* large lists stay in the chunks they were built in (parts; ij == NULL) */
+static void free_pairlist(pairlist_t* pl) { free(pl->ij); for (int k = 0; k < pl->nparts; k++) free(pl->parts[k].ij); free(pl->parts); pl->ij = NULL; pl->parts = NULL; pl->nparts = 0; pl->n = 0; }
 
 static void pl_push(pairlist_t* pl, int i, int j) {
-    if (pl->n == pl->cap) { pl->cap = pl->cap ? pl->cap * 2 : 1 << 16; pl->ij = (int*)realloc(pl->ij, sizeof(int) * 2 * (size_t)pl->cap); }
+    if (pl->n == pl->cap) { pl->cap = pl->cap ? pl->cap * 2 : 1 << 12; pl->ij = (int*)realloc(pl->ij, sizeof(int) * 2 * (size_t)pl->cap); }
     pl->ij[2 * pl->n] = i; pl->ij[2 * pl->n + 1] = j; pl->n++;
 }
 
-/* pairs with r2lo <= r^2 < r2hi (r2lo < 0: everything below r2hi); `cutoff` bounds the cell size and must be >= sqrt(r2hi) */
+/* pairs with r2lo <= r^2 < r2hi (r2lo < 0: everything below r2hi); `cutoff` bounds the cell size and must be >= sqrt(r2hi).
+ * The rows i are cut into chunks that OpenMP threads take in any order; every chunk fills a list of its own and the lists are
+ * concatenated in chunk order, so the result is the list the serial double loop would produce, pair for pair. */
+#define PL_CHUNK 64
 static void build_pairlist_band(int n, const double* pos, const double* box, int periodic, double cutoff, double r2lo, double rc2, const excl_t* ex, pairlist_t* pl) {
-    pl->ij = NULL; pl->n = 0; pl->cap = 0;
+    pl->ij = NULL; pl->n = 0; pl->cap = 0; pl->parts = NULL; pl->nparts = 0;
     int rect = periodic && box[3] == 0 && box[6] == 0 && box[7] == 0;
     int nc[3] = {0, 0, 0};
     if (rect) for (int d = 0; d < 3; d++) { nc[d] = (int)floor(box[4 * d] / cutoff); }
-    if (!rect || n < 2000 || nc[0] < 3 || nc[1] < 3 || nc[2] < 3) {
-        for (int i = 0; i < n; i++)
-            for (int j = i + 1; j < n; j++) {
-                double d[3];
-                if (periodic) delta_periodic(pos + 3 * j, pos + 3 * i, box, d); else delta_plain(pos + 3 * j, pos + 3 * i, d);
-                double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-                if (r2 < rc2 && r2 >= r2lo && !is_excluded(ex, i, j)) pl_push(pl, i, j);
+    const int brute = !rect || n < 2000 || nc[0] < 3 || nc[1] < 3 || nc[2] < 3;
+    int *cstart = NULL, *order = NULL, *cell = NULL; double* spos = NULL;
+    if (!brute) {      /* cell grid: atoms counting-sorted by cell (ascending index inside a cell), positions gathered in that order */
+        long long ncell = (long long)nc[0] * nc[1] * nc[2];
+        cstart = (int*)calloc((size_t)ncell + 1, sizeof(int));
+        order = (int*)malloc(sizeof(int) * (size_t)n);
+        cell = (int*)malloc(sizeof(int) * (size_t)n);
+        spos = (double*)malloc(sizeof(double) * 3 * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            int c[3];
+            for (int d = 0; d < 3; d++) {
+                double f = pos[3 * i + d] / box[4 * d]; f -= floor(f);
+                c[d] = (int)(f * nc[d]); if (c[d] >= nc[d]) c[d] = nc[d] - 1;
             }
-        return;
-    }
-    /* cell grid */
-    long long ncell = (long long)nc[0] * nc[1] * nc[2];
-    int* head = (int*)malloc(sizeof(int) * (size_t)ncell);
-    int* next = (int*)malloc(sizeof(int) * (size_t)n);
-    int* cell = (int*)malloc(sizeof(int) * (size_t)n);
-    for (long long c = 0; c < ncell; c++) head[c] = -1;
-    for (int i = n - 1; i >= 0; i--) {
-        int c[3];
-        for (int d = 0; d < 3; d++) {
-            double f = pos[3 * i + d] / box[4 * d]; f -= floor(f);
-            c[d] = (int)(f * nc[d]); if (c[d] >= nc[d]) c[d] = nc[d] - 1;
+            cell[i] = (c[0] * nc[1] + c[1]) * nc[2] + c[2];
+            cstart[cell[i] + 1]++;
         }
-        cell[i] = (c[0] * nc[1] + c[1]) * nc[2] + c[2];
-        next[i] = head[cell[i]]; head[cell[i]] = i;
+        for (long long c = 0; c < ncell; c++) cstart[c + 1] += cstart[c];
+        int* fill = (int*)malloc(sizeof(int) * (size_t)ncell);
+        memcpy(fill, cstart, sizeof(int) * (size_t)ncell);
+        for (int i = 0; i < n; i++) { int k = fill[cell[i]]++; order[k] = i; spos[3 * k] = pos[3 * i]; spos[3 * k + 1] = pos[3 * i + 1]; spos[3 * k + 2] = pos[3 * i + 2]; }
+        free(fill);
     }
-    for (int i = 0; i < n; i++) {
-        int ci = cell[i];
-        int cx = ci / (nc[1] * nc[2]), cy = (ci / nc[2]) % nc[1], cz = ci % nc[2];
-        for (int dx = -1; dx <= 1; dx++) for (int dy = -1; dy <= 1; dy++) for (int dz = -1; dz <= 1; dz++) {
-            int c2 = (((cx + dx + nc[0]) % nc[0]) * nc[1] + (cy + dy + nc[1]) % nc[1]) * nc[2] + (cz + dz + nc[2]) % nc[2];
-            for (int j = head[c2]; j >= 0; j = next[j]) {
-                if (j <= i) continue;
-                double d[3];
-                delta_periodic(pos + 3 * j, pos + 3 * i, box, d);
-                double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-                if (r2 < rc2 && r2 >= r2lo && !is_excluded(ex, i, j)) pl_push(pl, i, j);
+    const int nchunk = (n + PL_CHUNK - 1) / PL_CHUNK;
+    const double tp0 = omp_get_wtime();
+    pairlist_t* part = (pairlist_t*)calloc((size_t)(nchunk > 0 ? nchunk : 1), sizeof(pairlist_t));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int ch = 0; ch < nchunk; ch++) {
+        pairlist_t* my = &part[ch];
+        const int i1 = (ch + 1) * PL_CHUNK < n ? (ch + 1) * PL_CHUNK : n;
+        for (int i = ch * PL_CHUNK; i < i1; i++) {
+            if (brute) {
+                for (int j = i + 1; j < n; j++) {
+                    double d[3];
+                    if (periodic) delta_periodic(pos + 3 * j, pos + 3 * i, box, d); else delta_plain(pos + 3 * j, pos + 3 * i, d);
+                    double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                    if (r2 < rc2 && r2 >= r2lo && !is_excluded(ex, i, j)) pl_push(my, i, j);
+                }
+                continue;
+            }
+            int ci = cell[i];
+            int cx = ci / (nc[1] * nc[2]), cy = (ci / nc[2]) % nc[1], cz = ci % nc[2];
+            for (int dx = -1; dx <= 1; dx++) for (int dy = -1; dy <= 1; dy++) for (int dz = -1; dz <= 1; dz++) {
+                int c2 = (((cx + dx + nc[0]) % nc[0]) * nc[1] + (cy + dy + nc[1]) % nc[1]) * nc[2] + (cz + dz + nc[2]) % nc[2];
+                for (int k = cstart[c2]; k < cstart[c2 + 1]; k++) {
+                    const int j = order[k];
+                    if (j <= i) continue;
+                    double d[3];
+                    delta_periodic(spos + 3 * k, pos + 3 * i, box, d);
+                    double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                    if (r2 < rc2 && r2 >= r2lo && !is_excluded(ex, i, j)) pl_push(my, i, j);
+                }
             }
         }
     }
-    free(head); free(next); free(cell);
+    const double tp1 = omp_get_wtime();
+    long long total = 0;
+    for (int ch = 0; ch < nchunk; ch++) total += part[ch].n;
+    if (total > (4LL << 20)) {      /* (copying half a gigabyte of pairs into one array costs more than finding them) */
+        pl->parts = part; pl->nparts = nchunk; pl->n = total; part = NULL;
+    } else {
+        pl->cap = total > 0 ? total : 1; pl->ij = (int*)malloc(sizeof(int) * 2 * (size_t)pl->cap);
+        for (int ch = 0; ch < nchunk; ch++) {
+            if (part[ch].n) memcpy(pl->ij + 2 * pl->n, part[ch].ij, sizeof(int) * 2 * (size_t)part[ch].n);
+            pl->n += part[ch].n; free(part[ch].ij);
+        }
+    }
+    free(part); free(cstart); free(order); free(cell); free(spos);
+    if (getenv("ORC_TRACE")) fprintf(stderr, "[orc] pair list: search %.2f s on %d threads, concatenation %.2f s\n", tp1 - tp0, omp_get_max_threads(), omp_get_wtime() - tp1);
 }
 static void build_pairlist(int n, const double* pos, const double* box, int periodic, double cutoff, const excl_t* ex, pairlist_t* pl) {
     build_pairlist_band(n, pos, box, periodic, cutoff, -1.0, cutoff * cutoff, ex, pl);
@@ -596,6 +632,41 @@ static void ewald_pair(const ctx_t* c, int ii, int jj, double* fi, double* fj, d
     sliceE[2 * slice + COUL] += qq * inverseR * erfc(alphaR);
 }
 
+/* The pair loops below visit a list of independent pairs; only the ORDER in which their contributions are added to the force and
+ * slice-energy sums depends on how the list is walked (the reference walks OpenMM's neighbour list, a third-party order in any case).
+ * They are therefore split over OpenMP threads, each with force and energy sums of its own, added up afterwards: the full-size parity
+ * cases spend their time here (c5: 1.4e8 pairs), and the arithmetic of every pair is untouched. */
+typedef void (*pair_fn)(const ctx_t* c, int ii, int jj, double* fi, double* fj, double* sliceE);
+static void pairs_threaded(const ctx_t* c, const pairlist_t* pl, pair_fn fn, double* forces, double* sliceE) {
+    const int n = c->cfg->n_atoms, ns = c->cfg->n_subsets, S2 = ns * (ns + 1);
+    if (pl->ij && (pl->n < 200000 || omp_get_max_threads() == 1)) {
+        for (long long p = 0; p < pl->n; p++) { int ii = pl->ij[2 * p], jj = pl->ij[2 * p + 1]; fn(c, ii, jj, forces + 3 * ii, forces + 3 * jj, sliceE); }
+        return;
+    }
+    const int nt = omp_get_max_threads();
+    double* f = (double*)calloc((size_t)nt * 3 * (size_t)n, sizeof(double));
+    double* e = (double*)calloc((size_t)nt * (size_t)S2, sizeof(double));
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num();
+        double* mf = f + (size_t)t * 3 * (size_t)n; double* me = e + (size_t)t * (size_t)S2;
+        if (pl->ij) {
+#pragma omp for schedule(static)
+            for (long long p = 0; p < pl->n; p++) { int ii = pl->ij[2 * p], jj = pl->ij[2 * p + 1]; fn(c, ii, jj, mf + 3 * ii, mf + 3 * jj, me); }
+        } else {
+#pragma omp for schedule(dynamic, 4)
+            for (int k = 0; k < pl->nparts; k++) {
+                const int* ij = pl->parts[k].ij;
+                for (long long p = 0; p < pl->parts[k].n; p++) { int ii = ij[2 * p], jj = ij[2 * p + 1]; fn(c, ii, jj, mf + 3 * ii, mf + 3 * jj, me); }
+            }
+        }
+#pragma omp for schedule(static)
+        for (long long k = 0; k < 3LL * n; k++) { double a = 0; for (int u = 0; u < nt; u++) a += f[(size_t)u * 3 * (size_t)n + (size_t)k]; forces[k] += a; }
+    }
+    for (int k = 0; k < S2; k++) { double a = 0; for (int u = 0; u < nt; u++) a += e[(size_t)u * (size_t)S2 + k]; sliceE[k] += a; }
+    free(f); free(e);
+}
+
 /* ReferenceSlicedLJCoulombIxn.cpp:179-507 */
 static void ewald_ixn(const ctx_t* c, const excl_t* ex, const pairlist_t* pl, double* forces, double* sliceE) {
     const orc_config* cfg = c->cfg;
@@ -695,10 +766,7 @@ static void ewald_ixn(const ctx_t* c, const excl_t* ex, const pairlist_t* pl, do
     if (!cfg->include_direct) return;
 
     /* real space (:367-445); the list already holds exactly the non-excluded pairs within the cutoff (Q5) */
-    for (long long p = 0; p < pl->n; p++) {
-        int ii = pl->ij[2 * p], jj = pl->ij[2 * p + 1];
-        ewald_pair(c, ii, jj, forces + 3 * ii, forces + 3 * jj, sliceE);
-    }
+    { const double t0 = omp_get_wtime(); pairs_threaded(c, pl, ewald_pair, forces, sliceE); if (getenv("ORC_TRACE")) fprintf(stderr, "[orc] real-space pairs %.2f s\n", omp_get_wtime() - t0); }
 
     /* exclusion correction (:449-506) */
     double TWO_OVER_SQRT_PI = 2 / sqrt(ORC_PI);
@@ -753,13 +821,18 @@ int orc_evaluate(const orc_config* cfg, const double* pos, const double* box,
     double* eps = (double*)malloc(sizeof(double) * (size_t)(n + 1));
     for (int i = 0; i < n; i++) { sig[i] = 0.5 * sigma[i]; eps[i] = 2.0 * sqrt(epsilon[i]); }
 
+    const int trace = getenv("ORC_TRACE") != NULL;      /* diagnostic: where the time of a large evaluation goes */
+    double tt0 = omp_get_wtime();
     excl_t ex; build_exclusions(n, n_exc, exc_pairs, &ex);
-    pairlist_t pl = {NULL, 0, 0};
+    if (trace) fprintf(stderr, "[orc] exclusions %.2f s\n", omp_get_wtime() - tt0);
+    pairlist_t pl = {NULL, 0, 0, NULL, 0};
     if (anyPeriodic) {
         double minAllowed = 1.999999 * cfg->cutoff; /* :201-204 */
         if (box[0] < minAllowed || box[4] < minAllowed || box[8] < minAllowed) { free(sig); free(eps); free_exclusions(&ex); return -1; }
     }
+    tt0 = omp_get_wtime();
     if (method != ORC_NoCutoff) build_pairlist(n, pos, box, anyPeriodic, cfg->cutoff, &ex, &pl);
+    if (trace) fprintf(stderr, "[orc] pair list (%lld pairs) %.2f s\n", pl.n, omp_get_wtime() - tt0);
     g_last_pairs = pl.n;
 
     ctx_t c;
@@ -779,7 +852,7 @@ int orc_evaluate(const orc_config* cfg, const double* pos, const double* box,
         ewald_ixn(&c, &ex, &pl, forces, sliceE);
     } else if (local.include_direct) {
         if (method != ORC_NoCutoff) {
-            for (long long p = 0; p < pl.n; p++) one_ixn(&c, pl.ij[2 * p], pl.ij[2 * p + 1], forces, sliceE);
+            pairs_threaded(&c, &pl, one_pair, forces, sliceE);
         } else {
             for (int ii = 0; ii < n; ii++)
                 for (int jj = ii + 1; jj < n; jj++)
@@ -820,7 +893,7 @@ int orc_evaluate(const orc_config* cfg, const double* pos, const double* box,
             free(coef);
         }
     }
-    free(sig); free(eps); free_exclusions(&ex); free(pl.ij);
+    free(sig); free(eps); free_exclusions(&ex); free_pairlist(&pl);
     return 0;
 }
 
@@ -844,8 +917,11 @@ long long orc_cutoff_band_pairs(const orc_config* cfg, const double* pos, const 
     double* sig = (double*)malloc(sizeof(double) * (size_t)(n + 1));
     double* eps = (double*)malloc(sizeof(double) * (size_t)(n + 1));
     for (int i = 0; i < n; i++) { sig[i] = 0.5 * sigma[i]; eps[i] = 2.0 * sqrt(epsilon[i]); }
+    const int trace = getenv("ORC_TRACE") != NULL;      /* diagnostic: where the time of a large evaluation goes */
+    double tt0 = omp_get_wtime();
     excl_t ex; build_exclusions(n, n_exc, exc_pairs, &ex);
-    pairlist_t pl = {NULL, 0, 0};
+    if (trace) fprintf(stderr, "[orc] exclusions %.2f s\n", omp_get_wtime() - tt0);
+    pairlist_t pl = {NULL, 0, 0, NULL, 0};
     const double rc2 = cfg->cutoff * cfg->cutoff;
     build_pairlist_band(n, pos, box, anyPeriodic, cfg->cutoff * sqrt(1.0 + rel_eps) * (1.0 + 1e-12), rc2 * (1.0 - rel_eps), rc2 * (1.0 + rel_eps), &ex, &pl);
     ctx_t c;
@@ -869,7 +945,7 @@ long long orc_cutoff_band_pairs(const orc_config* cfg, const double* pos, const 
         out_vals[4 * p + 2] = sliceE[2 * slice + COUL]; out_vals[4 * p + 3] = sliceE[2 * slice + VDW];
     }
     long long count = pl.n;
-    free(sliceE); free(sig); free(eps); free_exclusions(&ex); free(pl.ij);
+    free(sliceE); free(sig); free(eps); free_exclusions(&ex); free_pairlist(&pl);
     return count;
 }
 

@@ -106,3 +106,31 @@ def compare(f, se, fo, so, tol, force_allow, energy_allow):
         ok = ok and eex.max() <= tol
     rec["ok"] = bool(ok)
     return rec
+
+
+# Session cache of the full-size cases (tests/test_gpu_fullsize.py): workload, oracle forces / slice energies and band allowance per
+# (config, coordinates rounded to float or not).  c3 single / mixed and c4 single / c4 as eight ranks share their inputs, so the oracle
+# evaluates every distinct input once per session (the GPU suite must stay inside the driver's limit).
+_FULLSIZE = {}
+_BANDS = {}
+
+
+def fullsize_case(name, precision):
+    """(workload, oracle forces, oracle slice energies, oracle seconds, pairs within the cutoff, force allowance, energy allowance, band pairs)
+    of a bench config at full size, for the coordinates an engine of this precision receives."""
+    n_target, Lbox, nsub, method, grid, dgrid, _ = bench.CONFIGS[name]
+    rounded = precision != "double"
+    key = (name, rounded)
+    if key not in _FULLSIZE:
+        w = bench.build_workload(n_target, Lbox, nsub, np.random.default_rng(bench.SEED))
+        if rounded:
+            w = float_positions(w)
+        fo, so, seconds, pairs = bench.oracle_eval(w, method, grid, dgrid)
+        _FULLSIZE[key] = (w, fo, so, seconds, pairs)
+    w, fo, so, seconds, pairs = _FULLSIZE[key]
+    rel = band_rel(w, precision)
+    bkey = (name, rounded, rel)
+    if bkey not in _BANDS:
+        _BANDS[bkey] = band_allowance(w, method, grid, dgrid, rel)
+    fa, ea, nband = _BANDS[bkey]
+    return w, fo, so, seconds, pairs, fa, ea, nband
