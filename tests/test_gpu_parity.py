@@ -1037,3 +1037,74 @@ def test_plane_path_and_three_pass_pipeline_agree_with_the_oracle(method, grid, 
         assert (t[8 + 3] == 0 and t[8 + 5] == 0) == (dgrid in (42, 54, 64)), ("dispersion mesh", t)
     t = got["three_pass"]["timed"]
     assert t[3] > 0 and t[5] > 0, t
+
+
+_OVERLAP_SCRIPT = r'''
+import sys, json
+import numpy as np, torch, importlib
+sys.path[:0] = [ROOT, ROOT + "/tests", ROOT + "/oracle"]
+import bench
+snb = importlib.import_module("openmm-nonbonded-slicing_amd")
+method, dgrid, prec = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+n = len(w["q"]); isd = prec == "double"; dt = torch.float64 if isd else torch.float32
+S = 10
+eng = bench.Engine(snb, w, method, 54, dgrid, prec, 0, 0, 1, 0.2, 1 << 30)
+eng.set_timing_interval(0)                      # no eager (serial) steps in between: every step after the first is a replayed graph
+eng.set_energy_slices(np.ones(S, dtype=np.int32))
+rng = np.random.default_rng(5)
+pos = w["pos"].copy()
+forces = torch.zeros((n, 3), dtype=dt, device="cuda")
+out = {}
+for step in range(6):
+    if step:
+        pos = pos + rng.uniform(-0.004, 0.004, pos.shape)
+    pt = torch.tensor(pos, dtype=dt, device="cuda")
+    eng.set_positions_device(pt.data_ptr(), isd)
+    derivative = step % 2 == 1                  # alternate forces-only steps and derivative steps (include_energy = 2)
+    if derivative:
+        eng.execute(2, fetch=False)
+    else:
+        eng.execute(False)
+    eng.forces_to(forces.data_ptr(), isd); eng.sync()
+    w2 = dict(w); w2["pos"] = np.ascontiguousarray(pt.double().cpu().numpy())
+    fo, so, _, _ = bench.oracle_eval(w2, method, 54, dgrid)
+    f = forces.double().cpu().numpy()
+    rec = dict(ferr=float(np.max(np.linalg.norm(f - fo, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0))), derivative=derivative)
+    if derivative:
+        se = eng.slice_energies(S)
+        rec["eerr"] = float(np.max(np.abs(se - so) / np.maximum(np.abs(so), 1.0)))
+    out[step] = rec
+# the same step twice: 64-bit fixed-point force sums do not depend on which launch took which work item
+pt = torch.tensor(pos, dtype=dt, device="cuda"); eng.set_positions_device(pt.data_ptr(), isd)
+eng.execute(False); eng.forces_to(forces.data_ptr(), isd); eng.sync(); a = forces.clone()
+eng.execute(False); eng.forces_to(forces.data_ptr(), isd); eng.sync()
+out["bitwise_equal"] = bool(torch.equal(a, forces))
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("method,dgrid,prec", [(4, 0, "single"), (4, 0, "mixed"), (5, 27, "double")])
+def test_overlapped_steps_match_the_oracle(method, dgrid, prec, snb):
+    """SNB_OVERLAP=1 (engine.hip, overlapMode): graph steps run the reciprocal pipeline beside a CU-limited resident launch of the tile
+    kernel and finish the pair work with a second launch; both claim their work items from device counters.  Forces-only and derivative
+    steps, replayed, against the oracle; in mixed precision the force of a step must also be bit-for-bit reproducible (integer sums do
+    not depend on which launch took which item).  The reference's counterpart is its separate PME queue
+    (platforms/common/src/CommonNonbondedSlicingKernels.cpp:520-530, 1176-1179, 1377-1380).  A child process: the switch is read once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e["SNB_OVERLAP"] = "1"
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _OVERLAP_SCRIPT, str(method), str(dgrid), prec], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    tol = 1e-5 if prec == "double" else 1e-3
+    for step in range(6):
+        rec = res[str(step)]
+        assert rec["ferr"] < tol, (step, rec)
+        if rec["derivative"]:
+            assert rec["eerr"] < tol, (step, rec)
+    if prec == "mixed":
+        assert res["bitwise_equal"], res
