@@ -147,9 +147,6 @@ CONFIGS = {
     "c3t": (300000, 14.42, 4, 4, 120, 0, "single"),      # c3 in a triclinic cell (shear_workload)
     "c3l": (300000, 14.42, 4, 5, 120, 60, "single"),     # c3 with LJPME (dispersion mesh 60^3)
 }
-# 1-GPU rates of this build on MI355X (bench.py --config <name>, round 3, random-walk coordinates, the step each config names: c3 with derivatives,
-# c4 / c2 forces only), quoted beside N > 1 results of the same workload
-ONE_GPU_NS_DAY = {"c4": 303.0, "c3": 419.2, "c2": 985.0}
 ALPHA = 2.6283
 CUTOFF = 1.0
 # configs whose BASELINE.json line names energy-parameter derivatives ("300k-atom solvated protein, 4 subsets with lambda_elec/lambda_vdW derivatives"):
@@ -201,7 +198,7 @@ class ForceView:
     def getIncludeDirectSpace(self): return True
 
 
-def oracle_eval(w, method, grid, dgrid):
+def oracle_eval(w, method, grid, dgrid, include_direct=1, include_reciprocal=1):
     import oracle
     fv = ForceView(w, method, grid, dgrid)
     # resolve() would loop in Python over every atom; feed the C entry point directly instead
@@ -211,7 +208,7 @@ def oracle_eval(w, method, grid, dgrid):
     cfg.n_atoms = n; cfg.n_subsets = w["nsub"]; cfg.method = method; cfg.cutoff = CUTOFF; cfg.rf_dielectric = 78.3
     cfg.alpha = ALPHA; cfg.grid[0] = cfg.grid[1] = cfg.grid[2] = grid
     cfg.alpha_d = ALPHA; cfg.dgrid[0] = cfg.dgrid[1] = cfg.dgrid[2] = max(dgrid, 1)
-    cfg.include_direct = 1; cfg.include_reciprocal = 1; cfg.background_term = 1; cfg.correct_q1 = 1
+    cfg.include_direct = int(include_direct); cfg.include_reciprocal = int(include_reciprocal); cfg.background_term = 1; cfg.correct_q1 = 1
     S = w["nsub"] * (w["nsub"] + 1) // 2
     forces = np.zeros((n, 3)); sliceE = np.zeros((S, 2))
     box = workload_box(w)
@@ -350,7 +347,7 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream())
     dev = torch.device("cuda", local)
     # N = 1: the headline workload c3 (BASELINE.json config 3).  N > 1: BASELINE.json config 4 -- the same 300k-atom box cut into 8 subsets,
-    # whose 8 subset grids shard over the ranks (strong scaling; `config.one_gpu_value_same_workload` carries the 1-GPU rate of c4)
+    # whose 8 subset grids shard over the ranks (strong scaling; `one_gpu_same_workload` is the unsharded engine on the same workload and step kind, measured by rank 0 in the same run)
     cfg_name = args.config or ("c3" if world == 1 else "c4")
     n_target, Lbox, nsub, method, grid, dgrid, precision = CONFIGS[cfg_name]
     precision = args.precision or precision
@@ -479,6 +476,39 @@ def main():
         torch.cuda.synchronize()
         allreduce_ms = (time.perf_counter() - ta) * 1e3 / args.steps
     overruns = int(eng.stats().n_list_overruns)
+    one_gpu_same = None; world_facts = None
+    if world > 1:
+        # The curve's own anchor, measured in THIS run: rank 0 runs the UNSHARDED engine of the same workload, the same
+        # step kind (the one `value` quotes), walk and rebuild cadence for K steps on its GPU while the other ranks wait at the barrier.
+        if rank == 0:
+            e1 = Engine(pkg, w, method, grid, dgrid, precision, local, 0, 1, args.padding, args.rebuild_interval, stream=torch.cuda.current_stream().cuda_stream)
+            p1 = pos0.clone(); f1 = torch.zeros((N, 3), dtype=tdtype, device=dev)
+            e1.set_force_output(f1.data_ptr(), is_double); e1.set_energy_slices(deriv_slices)
+
+            def step1(i):
+                p1.add_(walk[i % 16], alpha=float(walk_sign[i % len(walk_sign)]))
+                e1.set_positions_device(p1.data_ptr(), is_double)
+                e1.execute(2, fetch=False) if headline_deriv else e1.execute(False)
+                e1.forces_to(f1.data_ptr(), is_double)
+            for i in range(90):      # (not a multiple of the rebuild interval: the region's rebuilds fall mid-region, as in the main one)
+                step1(i)
+            e1.sync(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step1(90 + i)
+            e1.sync(); torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t1) * 1e3 / args.steps
+            e1.close()
+            one_gpu_same = {"value": round(86.4 * 2.0 / ms1, 3), "unit": "ns/day", "ms_per_step": round(ms1, 4), "steps": args.steps, "measured_in_this_run": True,
+                            "workload": cfg_name, "step": "with derivatives" if headline_deriv else "forces only", "device": torch.cuda.get_device_name(local)}
+        torch.cuda.synchronize(); dist.barrier()
+        # did the collective backend see N ranks on N devices?  Answerable from the line itself.
+        mine = {"rank": rank, "local_rank": local, "device_index": int(torch.cuda.current_device()), "device_name": torch.cuda.get_device_name(local),
+                "pci_bus_id": getattr(torch.cuda.get_device_properties(local), "pci_bus_id", None), "host": os.uname().nodename}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        world_facts = {"world_size": int(dist.get_world_size()), "backend": str(dist.get_backend()), "ranks": every,
+                       "distinct_devices": len({(r_["host"], r_["device_index"]) for r_ in every})}
     if world == 1:
         # For the record (never `value`): the same evaluations fed from two coordinate sets generated beforehand, i.e. nothing but
         # force evaluations on the stream.  The coordinate-update kernel of the main region stands where an integrator would.
@@ -498,6 +528,30 @@ def main():
     itemsize = 8 if is_double else 4
     G = grid ** 3; Gh = grid * grid * (grid // 2 + 1)
 
+    def valu_issue(kern, tiles, launch_ms):
+        """The bound that applies to the pair kernel: SQ_INSTS_VALU per launch from the newest committed --pmc pass
+        (profiles/rNN_<config>_pmc_sq.txt, taken at the tile count of profiles/rNN_<config>_default_bench.json) scaled to this run's tile
+        count, x 4 cycles per wave instruction (packed fp32: 64 lanes x 2 on a 32-lane-pair VALU), over SIMDs x clock x the launch time."""
+        here = os.path.dirname(os.path.abspath(__file__))
+        for tag in ("r04", "r03"):
+            fsq = os.path.join(here, "profiles", "%s_%s_pmc_sq.txt" % (tag, cfg_name)); fb = os.path.join(here, "profiles", "%s_%s_default_bench.json" % (tag, cfg_name))
+            if not (os.path.exists(fsq) and os.path.exists(fb)) or launch_ms <= 0:
+                continue
+            try:
+                prof_tiles = json.loads(open(fb).read().strip().splitlines()[-1])["config"]["tiles_32x32"]
+                short = kern.replace("snb::", "")
+                for line in open(fsq):
+                    if short in line and "SQ_INSTS_VALU" in line:
+                        insts = float(line.split("'SQ_INSTS_VALU':")[1].split(",")[0].split("}")[0])
+                        scaled = insts * tiles / max(prof_tiles, 1)
+                        simds, clock_ghz = 1024, 2.4
+                        issue_ms = scaled * 4.0 / (simds * clock_ghz * 1e9) * 1e3
+                        return {"insts_per_launch": int(scaled), "source": "profiles/%s: SQ_INSTS_VALU %d at %d tiles, scaled to %d tiles" % (os.path.basename(fsq), int(insts), prof_tiles, tiles),
+                                "cycles_per_inst": 4, "simds": simds, "clock_ghz": clock_ghz, "issue_ms": round(issue_ms, 4), "frac": round(issue_ms / launch_ms, 4), "measured_in_this_run": False}
+            except Exception:
+                continue
+        return None
+
     def pair_roofline(stx, derivatives):
         """N*(posq+sigeps+subset) + N*24 force write + T*32*(posq+sigeps+subset+index) + T*32*24 j-force scatter, over the
         average launch duration of the pair kernel on the region's eager steps (begin/end stamps of hipExtLaunchKernelGGL)."""
@@ -509,7 +563,9 @@ def main():
             kern = "snb::k_direct<double, %d, false, %s>" % (2 if method == 4 else 3, "true" if derivatives else "false")
         else:
             kern = "snb::k_directPacked<%d, true, %s, false, %s>" % (2 if method == 4 else 3, "true" if derivatives else "false", "true" if precision == "mixed" else "false")
-        return {"bound": "hbm", "kernel": kern, "step": "with derivatives (energies on the tiles of the bound slices)" if derivatives else "forces only",
+        valu = valu_issue(kern, Tx, d_ms)
+        return {"bound": "valu" if valu else "hbm", "bound_note": "VALU-issue-bound in practice (DESIGN.md 4.1); achieved / peak / frac are the HBM figures the bench contract asks for (algorithmic bytes over the launch time), valu_issue is the bound that applies",
+                "valu_issue": valu, "kernel": kern, "step": "with derivatives (energies on the tiles of the bound slices)" if derivatives else "forces only",
                 "timing": "kernel begin/end stamps of hipExtLaunchKernelGGL on the eager steps of the timed region (snb_set_timing_interval: at least 4 of them)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes": int(nbytes), "tiles": Tx, "avg_launch_ms": round(d_ms, 4), "timed_launches": int(stx.n_timed)}
@@ -592,7 +648,7 @@ def main():
     # HBM-side traffic of the pair kernel: PMC passes cannot run inside this process (rocprofv3 --pmc wraps the whole command, in separate
     # FETCH_SIZE / WRITE_SIZE passes: tools/pmc_hbm.sh).  `traffic` therefore stays null here; the figure of the committed profile of this
     # command is quoted under its own key, with the tile count it was taken at.
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "%s_%s_pmc_hbm.json" % (tag, cfg_name))
         if os.path.exists(pmc_file) and world == 1:
             try:
@@ -605,27 +661,29 @@ def main():
             break
     if block_ranges is not None:
         out["config"]["i_block_ranges_of_128"] = [list(r) for r in block_ranges]
-    if world > 1 and cfg_name in ONE_GPU_NS_DAY:
-        # the 1-GPU rate of the SAME workload (c3 by default; c4 is the 8-subset box of BASELINE.json's multi-GPU config)
-        out["config"]["one_gpu_value_same_workload"] = ONE_GPU_NS_DAY[cfg_name]
+    if world > 1:
+        out["one_gpu_same_workload"] = one_gpu_same
+        out["distributed"] = world_facts
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # bounded sample: the same workload generator at 24k atoms (same density, cutoff, alpha, grid spacing), a few evaluations
-        ws = build_workload(24000, 6.2145, min(nsub, 4), np.random.default_rng(SEED))
-        ws["pos"] = np.ascontiguousarray(ws["pos"].astype(np.float32).astype(np.float64))      # float-representable coordinates: the oracle and engines of either precision see identical inputs
+        # The CPU oracle on the FULL workload (round 4: its pair list and pair loops are threaded, one evaluation of c3 takes seconds, so
+        # nothing is scaled any more): one evaluation to size the sample, then as many as fit ~20 s, at least 2, at most 6.
         import oracle as _o
         cores = int(_o.lib().orc_num_threads())
-        reps = 10; tsum = 0.0; pairs = 0
-        fo_s = so_s = None
+        _, _, dt0, pairs = oracle_eval(w, method, grid, dgrid)
+        reps = int(max(2, min(6, round(20.0 / max(dt0, 1e-3))))); tsum = 0.0
         for _ in range(reps):
-            fo_s, so_s, dt, pairs = oracle_eval(ws, 4 if method == 4 else 5, 54, 27 if method == 5 else 0)
+            _, _, dt, pairs = oracle_eval(w, method, grid, dgrid)
             tsum += dt
-        cpu_ms = tsum / reps * 1e3
-        cpu_full_ms = cpu_ms * N / len(ws["q"])
+        cpu_full_ms = tsum / reps * 1e3
         out["cpu_baseline"] = {"value": round(86.4 * 2.0 / cpu_full_ms, 5), "unit": "ns/day", "cores": cores, "kind": "port",
-                               "sample": "CPU oracle (C restatement of the Reference platform; pair list, pair loop and PME FFT / interpolation on OpenMP threads; the reference itself is single-threaded), "
-                                         "%d evaluations of a %d-atom/%d-subset box of the same generator (density, cutoff, alpha, 54^3 grid): %.0f ms per evaluation, %d pairs; "
-                                         "value = the per-atom cost scaled to the full workload: %.0f ms per evaluation" % (reps, len(ws["q"]), ws["nsub"], cpu_ms, pairs, cpu_full_ms),
-                               "ms_per_step_sample": round(cpu_ms, 1), "ms_per_step_scaled": round(cpu_ms * N / len(ws["q"]), 1)}
+                               "sample": "CPU oracle (C restatement of the Reference platform; pair list, pair loop and PME passes on %d OpenMP threads; the reference itself is single-threaded): "
+                                         "%d evaluations (forces + slice energies) of the full workload, %d atoms, %d pairs inside the cutoff: %.0f ms per evaluation" % (cores, reps, N, pairs, cpu_full_ms),
+                               "ms_per_step": round(cpu_full_ms, 1)}
+        # the 24k-atom box of the same generator (density, cutoff, alpha, 54^3 mesh): parity sample of the precision legs below
+        ws = build_workload(24000, 6.2145, min(nsub, 4), np.random.default_rng(SEED))
+        ws["pos"] = np.ascontiguousarray(ws["pos"].astype(np.float32).astype(np.float64))      # float-representable coordinates: the oracle and engines of either precision see identical inputs
+        ms24, ds24 = (4 if method == 4 else 5), (27 if method == 5 else 0)
+        fo_s, so_s, _, _ = oracle_eval(ws, ms24, 54, ds24)
     if rank == 0 and world == 1 and not args.no_double and not is_double:
         # north_star couples the roofline target with "per-slice energies to 1e-5", which only double precision delivers: the same workload in
         # SNB_DOUBLE beside the headline (its own K-step regions, same walk and cadence), the pair kernel against the double-precision byte
@@ -664,14 +722,22 @@ def main():
                                    "byte_model": "76*N + 2560*T (SURVEY 8d with 32-byte positions and 8-byte reals)"}
         if not args.no_cpu_baseline and fo_s is not None:
             par = {}
-            for pr in ("double", "single"):
-                e24 = Engine(pkg, ws, 4 if method == 4 else 5, 54, 27 if method == 5 else 0, pr, local, 0, 1, 0.1, 1 << 30, stream=torch.cuda.current_stream().cuda_stream)
+            rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)))
+            for pr in ("double", "single", "mixed"):
+                e24 = Engine(pkg, ws, ms24, 54, ds24, pr, local, 0, 1, 0.1, 1 << 30, stream=torch.cuda.current_stream().cuda_stream)
                 dtp = torch.float64 if pr == "double" else torch.float32
                 p24 = torch.tensor(ws["pos"], dtype=dtp, device=dev); f24 = torch.zeros((len(ws["q"]), 3), dtype=dtp, device=dev)
                 e24.set_positions_device(p24.data_ptr(), pr == "double"); e24.execute(True); e24.forces_to(f24.data_ptr(), pr == "double"); e24.sync()
                 se = e24.slice_energies(so_s.shape[0]); f = f24.double().cpu().numpy()
-                par[pr] = {"max_slice_energy_rel_err": float(np.max(np.abs(se - so_s) / np.maximum(np.abs(so_s), 1.0))),
+                par[pr] = {"max_slice_energy_rel_err": rel(se, so_s),
                            "max_force_rel_err": float(np.max(np.linalg.norm(f - fo_s, axis=1) / np.maximum(np.linalg.norm(fo_s, axis=1), 1.0)))}
+                if pr != "double":
+                    # where the single-precision slice-energy error sits: each half of the Ewald split against the oracle's
+                    for half, (d_, r_) in (("direct_space_only", (1, 0)), ("reciprocal_only", (0, 1))):
+                        _, so_h, _, _ = oracle_eval(ws, ms24, 54, ds24, d_, r_)
+                        eh = ctypes.c_double(); e24.ok(e24.L.snb_execute(e24.h, 1, 1, d_, r_, ctypes.byref(eh)))
+                        # (each half's absolute error over the magnitude of the FULL slice energy: the two figures add up to the total's at worst)
+                        par[pr]["slice_energy_err_of_%s_over_full_magnitude" % half] = float(np.max(np.abs(e24.slice_energies(so_h.shape[0]) - so_h) / np.maximum(np.abs(so_s), 1.0)))
                 e24.close()
             out["double_precision"]["parity_vs_oracle_24k_atoms"] = par
         eng = None
