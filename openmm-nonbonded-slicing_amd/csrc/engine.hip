@@ -186,6 +186,7 @@ template <typename Real> struct PmePlan {
         // at most 1024 x 1024 = 2^20 under this cap.
         if (d.nx > 1024 || d.ny > 1024 || d.nz > 1024) throw HipError{"PME mesh dimensions above 1024 are not supported"};
         splitTwoPass(d.nx, &d.rx1, &d.rx2); splitTwoPass(d.ny, &d.ry1, &d.ry2); splitTwoPass(d.nz, &d.rz1, &d.rz2);
+        splitPlane(d.nx, &d.px1, &d.px2); splitPlane(d.ny, &d.py1, &d.py2);
         // measured on MI355X (120^3 = 8 x 15, 4 grids, single precision, Winograd radix-3/5 butterflies): two-pass register FFT vs
         // staged Stockham: inverse z 18.2 vs 23.5 us, y 30.6 vs 32.4, fused x/convolution 68.6 vs 71.0.  SNB_FFT_TWOPASS=0/1 overrides.
         // Round 3, double precision (c5, 180^3 = 12 x 15 and 90^3 = 9 x 10): the register passes win on the y and z axes (y 183 -> 150 us,
@@ -197,7 +198,7 @@ template <typename Real> struct PmePlan {
         if (sizeof(Real) == 8 && std::max(d.rx1, d.rx2) > 12 && !getenv("SNB_FFT_TWOPASS")) d.rx1 = d.rx2 = 0;
         gridReal.resize((size_t)nGrids * d.nx * d.ny * d.nz);
         gridCplx.resize((size_t)nGrids * d.nx * d.ny * d.nzc);
-        if (sizeof(Real) == 4 && d.nx == d.ny && d.nx <= 144) { gridCplxB.resize((size_t)nGrids * d.nx * (d.ny + 8) * d.nzc);      // (y padded to whole tiles of the inverse z kernel)
+        if (sizeof(Real) == 4 && (size_t)d.nx * (d.ny | 1) * 8 <= 156 * 1024) { gridCplxB.resize((size_t)nGrids * d.nx * (d.ny + 8) * d.nzc);      // (plane path, planes that fit LDS; y padded to whole tiles of the inverse z kernel)
              planeEterm.resize((size_t)d.nx * d.ny * d.nzc); planeEtermReady = false; }
         auto tw = [&](int n, DevBuf<typename Vec<Real>::T2>& buf) {
             std::vector<typename Vec<Real>::T2> h(n);

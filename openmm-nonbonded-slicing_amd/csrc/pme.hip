@@ -1410,23 +1410,60 @@ __device__ __forceinline__ void planePass(Cx<Real>* P, const int lines, const in
 }
 struct PlaneNoScale { template <typename... A> __device__ float operator()(A...) const { return 1.0f; } };
 
+// Rectangular planes and square ones without a kernel of their own (round 4): the two axes take splits of their own from the plan at run
+// time (PmePlanDims px1..py2, any product of two of the radices below).  One kernel serves every combination: each pass is a switch over
+// the pass bodies per radix -- inlined, it allocates the registers of its largest arm (120 VGPRs, no scratch at 1024 threads; as calls
+// the bodies needed 160 B of stack per lane).  The bodies address LDS through offsets from s_dyn, so they stay ds_ instructions either way.
+#define SNB_PLANE_RADICES(X) X(5) X(6) X(7) X(8) X(9) X(10) X(12) X(15) X(16)
+template <int R, int SIGN, int TWMODE, bool STRIDED, typename PRE>
+__device__ __forceinline__ void planePassCall(const int pOff, const int lines, const int lineStride, const int elemStride, const int other, const int twOff,
+                                                        const int tid, const int NT, PRE pre) {
+    Cx<float>* base = reinterpret_cast<Cx<float>*>(s_dyn);
+    planePass<float, R, SIGN, TWMODE, STRIDED>(base + pOff, lines, lineStride, elemStride, other, base + twOff, tid, NT, pre);
+}
+template <int SIGN, int TWMODE, bool STRIDED, typename PRE>
+__device__ __forceinline__ void planePassDyn(const int R, const int pOff, const int lines, const int lineStride, const int elemStride, const int other, const int twOff,
+                                             const int tid, const int NT, PRE pre) {
+    switch (R) {
+#define X(A) case A: planePassCall<A, SIGN, TWMODE, STRIDED>(pOff, lines, lineStride, elemStride, other, twOff, tid, NT, pre); break;
+        SNB_PLANE_RADICES(X)
+#undef X
+        default: break;
+    }
+}
+// what k_planeXY needs from its two axes: static splits (square planes, R1 x R2 on both axes, one table of roots) or the plan's
+template <int R1, int R2> struct PlaneSplitsStatic {
+    static constexpr bool dynamic = false;
+    __device__ PlaneSplitsStatic(const PmePlanDims&) {}
+    __device__ int rx1() const { return R1; } __device__ int rx2() const { return R2; } __device__ int ry1() const { return R1; } __device__ int ry2() const { return R2; }
+};
+struct PlaneSplitsDynamic {
+    static constexpr bool dynamic = true;
+    int x1, x2, y1, y2;
+    __device__ PlaneSplitsDynamic(const PmePlanDims& d) : x1(d.px1), x2(d.px2), y1(d.py1), y2(d.py2) {}
+    __device__ int rx1() const { return x1; } __device__ int rx2() const { return x2; } __device__ int ry1() const { return y1; } __device__ int ry2() const { return y2; }
+};
+
 // The reciprocal-space kernel value of every plane position, in the permuted order the in-place forward passes leave (position q of an
 // axis holds frequency q / R2 + R1 (q % R2)): [kz][px][py], filled at rebuild time (the box and alpha are fixed between rebuilds).
-template <typename Real> __global__ __launch_bounds__(256) void k_planeEterm(const PmeParams<Real> p, Real* table, const int R1, const int R2) {
+template <typename Real> __global__ __launch_bounds__(256) void k_planeEterm(const PmeParams<Real> p, Real* table) {
     const int nx = p.d.nx, ny = p.d.ny;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)p.d.nzc * nx * ny) return;
     const int py = (int)(i % ny), px = (int)((i / ny) % nx), kz = (int)(i / ((size_t)nx * ny));
-    table[i] = recipTerm<Real>(p, px / R2 + R1 * (px % R2), py / R2 + R1 * (py % R2), kz);
+    table[i] = recipTerm<Real>(p, px / p.d.px2 + p.d.px1 * (px % p.d.px2), py / p.d.py2 + p.d.py1 * (py % p.d.py2), kz);      // (each axis in the permuted order of its own in-place transform)
 }
 
 template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeXY(const PmeParams<float> p, const int NBY) {
     using Real = float;
-    const int nx = p.d.nx, ny = p.d.ny, nzc = p.d.nzc;      // launcher: nx == ny == R1 * R2
+    using Splits = typename std::conditional<R1 == 0, PlaneSplitsDynamic, PlaneSplitsStatic<R1, R2>>::type;      // R1 == 0: rectangular plane, splits from the plan
+    const Splits sp(p.d);
+    const int nx = p.d.nx, ny = p.d.ny, nzc = p.d.nzc;      // launcher: static splits: nx == ny == R1 * R2; dynamic: nx = rx1 rx2, ny = ry1 ry2
     const int PY = ny | 1;                                  // odd pitch: lanes along x (stride PY) and lanes along y (stride 1) are both conflict-free
     const int slot = blockIdx.x / nzc, kz = blockIdx.x - slot * nzc;
     Cx<Real>* P = reinterpret_cast<Cx<Real>*>(s_dyn);                  // [nx][PY]
-    Cx<Real>* tw = P + (size_t)nx * PY;                                // [nx] roots of unity (nx == ny)
+    Cx<Real>* tw = P + (size_t)nx * PY;                                // [nx] roots of unity of the x axis (and of y on square planes), then [ny] for y on rectangular ones
+    const int twXOff = nx * PY, twYOff = Splits::dynamic ? nx * PY + nx : nx * PY;
     __shared__ double s_red[NT / 64];
     const int tid = threadIdx.x;
     const size_t planeElems = (size_t)nx * ny;
@@ -1437,6 +1474,7 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeX
     const size_t tileStride = (size_t)p.nsub * nzc * NBY;
     const FastDiv dNBY(NBY);
     for (int k = tid; k < nx; k += NT) tw[k] = reinterpret_cast<const Cx<Real>*>(p.twx)[k];
+    if (Splits::dynamic) for (int k = tid; k < ny; k += NT) tw[nx + k] = reinterpret_cast<const Cx<Real>*>(p.twy)[k];
     const FastDiv dny(ny);
     const int nPairs = (int)(planeElems >> 1);                         // ny is even (launcher): 16-byte accesses never straddle a row
     // the merge kernel's planes are brick-tiled, [kz][brick][line of the brick]: element e sits at x = bx cx + lx, y = by cy + ly
@@ -1454,27 +1492,45 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeX
             [&](int e) { return reinterpret_cast<const float2*>(in)[e]; },
             [&](int e, const float2& v) { P[tiledIndex(e)] = {v.x, v.y}; });
     __syncthreads();
-    // forward y (lines = x rows, elements along y), forward x (lines = y columns, elements along x, stride PY)
-    planePass<Real, R1, -1, 1, true>(P, nx, PY, 1, R2, tw, tid, NT, PlaneNoScale());
-    __syncthreads();
-    planePass<Real, R2, -1, 0, false>(P, nx, PY, 1, R1, tw, tid, NT, PlaneNoScale());
-    __syncthreads();
-    planePass<Real, R1, -1, 1, true>(P, ny, 1, PY, R2, tw, tid, NT, PlaneNoScale());
-    __syncthreads();
-    planePass<Real, R2, -1, 0, false>(P, ny, 1, PY, R1, tw, tid, NT, PlaneNoScale());
-    __syncthreads();
-    // position q of an axis now holds frequency (q / R2) + R1 * (q % R2); the kernel value (tabulated in that order) is applied while the
-    // first inverse pass loads
+    // forward y (lines = x rows, elements along y), forward x (lines = y columns, elements along x, stride PY); then position q of an axis
+    // holds frequency (q / r2) + r1 * (q % r2): the kernel value (tabulated in that order) is applied while the first inverse pass loads
     const Real* et = p.planeEterm + (size_t)kz * planeElems;
-    planePass<Real, R2, +1, 0, false>(P, ny, 1, PY, R1, tw, tid, NT,
-        [&](int line, int pos) { return et[pos * ny + line]; });
-    __syncthreads();
-    planePass<Real, R1, +1, 2, true>(P, ny, 1, PY, R2, tw, tid, NT, PlaneNoScale());
-    __syncthreads();
-    planePass<Real, R2, +1, 0, false>(P, nx, PY, 1, R1, tw, tid, NT, PlaneNoScale());
-    __syncthreads();
-    planePass<Real, R1, +1, 2, true>(P, nx, PY, 1, R2, tw, tid, NT, PlaneNoScale());
-    __syncthreads();
+    auto eterm = [et, ny](int line, int pos) { return et[pos * ny + line]; };
+    if constexpr (!Splits::dynamic) {
+        planePass<Real, R1, -1, 1, true>(P, nx, PY, 1, R2, tw, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePass<Real, R2, -1, 0, false>(P, nx, PY, 1, R1, tw, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePass<Real, R1, -1, 1, true>(P, ny, 1, PY, R2, tw, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePass<Real, R2, -1, 0, false>(P, ny, 1, PY, R1, tw, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePass<Real, R2, +1, 0, false>(P, ny, 1, PY, R1, tw, tid, NT, eterm);
+        __syncthreads();
+        planePass<Real, R1, +1, 2, true>(P, ny, 1, PY, R2, tw, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePass<Real, R2, +1, 0, false>(P, nx, PY, 1, R1, tw, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePass<Real, R1, +1, 2, true>(P, nx, PY, 1, R2, tw, tid, NT, PlaneNoScale());
+        __syncthreads();
+    } else {
+        planePassDyn<-1, 1, true>(sp.ry1(), 0, nx, PY, 1, sp.ry2(), twYOff, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePassDyn<-1, 0, false>(sp.ry2(), 0, nx, PY, 1, sp.ry1(), twYOff, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePassDyn<-1, 1, true>(sp.rx1(), 0, ny, 1, PY, sp.rx2(), twXOff, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePassDyn<-1, 0, false>(sp.rx2(), 0, ny, 1, PY, sp.rx1(), twXOff, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePassDyn<+1, 0, false>(sp.rx2(), 0, ny, 1, PY, sp.rx1(), twXOff, tid, NT, eterm);
+        __syncthreads();
+        planePassDyn<+1, 2, true>(sp.rx1(), 0, ny, 1, PY, sp.rx2(), twXOff, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePassDyn<+1, 0, false>(sp.ry2(), 0, nx, PY, 1, sp.ry1(), twYOff, tid, NT, PlaneNoScale());
+        __syncthreads();
+        planePassDyn<+1, 2, true>(sp.ry1(), 0, nx, PY, 1, sp.ry2(), twYOff, tid, NT, PlaneNoScale());
+        __syncthreads();
+    }
     batchedCopy<8, float4>(tid, nPairs, NT,
         [&](int e) { const int x = dny.div(2 * e), y = 2 * e - x * ny; const Cx<Real> a = P[x * PY + y], b = P[x * PY + y + 1]; return make_float4(a.x, a.y, b.x, b.y); },
         [&](int e, const float4& v) { const int x = dny.div(2 * e), y = 2 * e - x * ny, t = dNBY.div(y); *reinterpret_cast<float4*>(out + ((size_t)x * tilesY + t) * tileStride + (y - t * NBY)) = v; });
@@ -1662,17 +1718,23 @@ template <typename Real> static void launchConvolveX(int r1, int r2, dim3 grid, 
 // Plane path (k_planeXY + k_fftZInvMix): single precision, a square mesh plane that fits LDS with its row padding, an instantiated
 // two-pass split, at most 8 held subsets, and the own-atoms spreader's merge kernel in front (it writes the plane-major spectrum).
 #define SNB_PLANE_PAIRS(X) X(6, 7) X(6, 9) X(8, 8) X(8, 10) X(9, 10) X(8, 12) X(10, 10) X(9, 12) X(10, 12) X(8, 16)
-template <typename Real> static size_t planeLds(const PmeParams<Real>& p) { return sizeof(Cx<Real>) * ((size_t)p.d.nx * (p.d.ny | 1) + p.d.nx); }
-template <typename Real> static bool planePathOK(const PmeParams<Real>& p) {
-    static const bool off = getenv("SNB_NO_PLANE_FFT") != nullptr;      // test switch: the three-kernel y / x / y pipeline
-    if (off || !std::is_same<Real, float>::value || !p.planeB || !p.planeEterm) return false;
-    if (p.d.nx != p.d.ny || (p.d.ny & 1) || p.d.rx1 <= 0 || p.d.rx1 != p.d.ry1 || p.d.rx2 != p.d.ry2 || p.d.rx1 * p.d.rx2 != p.d.nx) return false;
-    if (p.nsub > 8 || planeLds(p) > 156 * 1024) return false;
-    bool inst = false;
-#define X(A, B) if (p.d.rx1 == A && p.d.rx2 == B) inst = true;
+// square plane with a split that has a kernel of its own (static splits: no calls, one table of roots); everything else takes the run-time kernel
+static bool planeSquare(const PmePlanDims& d) {
+    static const bool dyn = getenv("SNB_PLANE_DYNAMIC") != nullptr;      // measurement aid: the run-time-split kernel on square planes too
+    if (dyn || d.nx != d.ny || d.px1 != d.py1 || d.px2 != d.py2) return false;
+#define X(A, B) if (d.px1 == A && d.px2 == B) return true;
     SNB_PLANE_PAIRS(X)
 #undef X
-    return inst;
+    return false;
+}
+template <typename Real> static size_t planeLds(const PmeParams<Real>& p) { return sizeof(Cx<Real>) * ((size_t)p.d.nx * (p.d.ny | 1) + p.d.nx + (planeSquare(p.d) ? 0 : p.d.ny)); }
+template <typename Real> static bool planePathOK(const PmeParams<Real>& p) {
+    static const bool off = getenv("SNB_NO_PLANE_FFT") != nullptr;      // test switch: the three-kernel y / x / y pipeline
+    static const bool noRect = getenv("SNB_NO_RECT_PLANES") != nullptr; // test switch: rectangular planes on the three-pass pipeline, as before round 4
+    if (off || !std::is_same<Real, float>::value || !p.planeB || !p.planeEterm) return false;
+    if ((p.d.ny & 1) || p.d.px1 <= 0 || p.d.py1 <= 0 || p.d.px1 * p.d.px2 != p.d.nx || p.d.py1 * p.d.py2 != p.d.ny) return false;
+    if (p.nsub > 8 || planeLds(p) > 156 * 1024) return false;
+    return planeSquare(p.d) || !noRect;
 }
 // y lines per work-group of the inverse z kernel = tile of the convolved planes' layout (c4, 8 subsets: plane + z kernel 45.5 + 55.0 us with 8, 61.2 + 42.4 with 4: 32-byte runs in the plane kernel's store)
 static int planeTileY(const PmeParams<float>& p) {
@@ -1684,7 +1746,12 @@ static void launchPlaneXY(const PmeParams<float>& p, hipStream_t s) {
     const int NBY = planeTileY(p);
     const dim3 grid((unsigned)(p.nsub * p.d.nzc));
     static const int nt = getenv("SNB_PLANE_NT") ? atoi(getenv("SNB_PLANE_NT")) : 1024;      // threads per plane: 1024 or 768
-#define X(A, B) if (p.d.rx1 == A && p.d.rx2 == B) { \
+    if (!planeSquare(p.d)) {      // rectangular plane: the kernel with run-time splits
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_planeXY<0, 0, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_planeXY<0, 0, 1024>), grid, dim3(1024), lds, s, p, NBY);
+        return;
+    }
+#define X(A, B) if (p.d.px1 == A && p.d.px2 == B) { \
         if (nt == 768) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_planeXY<A, B, 768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                          SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_planeXY<A, B, 768>), grid, dim3(768), lds, s, p, NBY); } \
         else { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_planeXY<A, B, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -1720,7 +1787,7 @@ template <typename Real> void launchPlaneEterm(const PmeParams<Real>& p, Real* t
     PmeParams<Real> q = p; q.planeEterm = table;
     if (!table || !planePathOK<Real>(q)) return;
     const size_t n = (size_t)p.d.nzc * p.d.nx * p.d.ny;
-    hipLaunchKernelGGL((k_planeEterm<Real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, table, p.d.rx1, p.d.rx2);
+    hipLaunchKernelGGL((k_planeEterm<Real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, table);
 }
 template void launchPlaneEterm<float>(const PmeParams<float>&, float*, hipStream_t);
 template void launchPlaneEterm<double>(const PmeParams<double>&, double*, hipStream_t);
@@ -2265,6 +2332,24 @@ bool factorize(int n, int* factors, int* nf) {
 }
 
 // n = r1 * r2 for one of the instantiated (R1, R2) pairs; false (and 0, 0) if n is not in the list
+// plane path: n = r1 * r2 with both factors among the radices k_planeXY has pass bodies for, r1 <= r2, the most balanced pair; the
+// pairs with a kernel of their own (SNB_PLANE_PAIRS) first
+bool splitPlane(int n, int* r1, int* r2) {
+#define X(A, B) if (n == (A) * (B)) { *r1 = A; *r2 = B; return true; }
+    SNB_PLANE_PAIRS(X)
+#undef X
+    const int radices[] = {
+#define X(A) A,
+        SNB_PLANE_RADICES(X)
+#undef X
+    };
+    int best = 0;
+    for (int a : radices) for (int b : radices) if (a <= b && a * b == n && a > best) { best = a; *r1 = a; *r2 = b; }
+    if (best) return true;
+    *r1 = *r2 = 0;
+    return false;
+}
+
 bool splitTwoPass(int n, int* r1, int* r2) {
 #define X(A, B) if (n == (A) * (B)) { *r1 = A; *r2 = B; return true; }
     SNB_FFT_PAIRS(X)

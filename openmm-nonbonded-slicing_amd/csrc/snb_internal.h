@@ -118,6 +118,7 @@ struct PmePlanDims {
     int nfx, nfy, nfz;        // number of radix factors per axis
     int fx[16], fy[16], fz[16];
     int rx1, rx2, ry1, ry2, rz1, rz2;   // two-pass register-FFT split n = r1*r2 per axis (0 = use the staged Stockham path)
+    int px1, px2, py1, py2;             // plane path (pme.hip k_planeXY): splits of the x and y axes into radices it has pass bodies for (0 = none)
 };
 
 // Per-kernel begin/end stamps of a timed (eager) step: the engine points g_stamps at a set of event pairs before it enqueues the step;
@@ -324,5 +325,6 @@ void launchExceptionParams(int n, const double* base, const int* offStart, const
 int legalGridSize(int n);
 bool factorize(int n, int* factors, int* nfactors);
 bool splitTwoPass(int n, int* r1, int* r2);
+bool splitPlane(int n, int* r1, int* r2);
 
 }  // namespace snb

@@ -3,6 +3,7 @@ of the reference interface, against (a) the reference's closed-form known answer
 identical seeded inputs.  Tolerances: 1e-3 single / 1e-5 double relative with the reference's max(|x|,1) scaling
 (BASELINE.json north_star; openmmapi/include/internal/AssertionUtilities.h:7-26)."""
 import functools
+import os
 
 import numpy as np
 import pytest
@@ -183,7 +184,8 @@ BIG_CASES = [
     ("ljpme_grids48_24_13824_n3", 13824, 3, 5, 6.0, (2.6283, 48, 48, 48), (2.6283, 24, 24, 24)),    # dispersion mesh: bricks of column groups
     ("pme_grid54_13824_n4", 13824, 4, 4, 6.0, (2.6283, 54, 54, 54), None),                          # 54 = 6 x 9 two-pass FFT split
     ("pme_grid54x54x50_13824_n3", 13824, 3, 4, 6.0, (2.6283, 54, 54, 50), None),                    # plane path (square 54 x 54 planes) with a z length that has no two-pass split: staged inverse z FFT behind the mix
-    ("pme_grid54x60x54_13824_n2", 13824, 2, 4, 6.0, (2.6283, 54, 60, 54), None),                    # non-square planes: the three-pass pipeline
+    ("pme_grid54x60x54_13824_n2", 13824, 2, 4, 6.0, (2.6283, 54, 60, 54), None),                    # non-square planes (round 4: plane path with run-time splits 6 x 9 and 6 x 10; nx = nz, Q1)
+    ("pme_grid48x56x48_13824_n3", 13824, 3, 4, 6.0, (2.6283, 48, 56, 48), None),                    # non-square planes, 6 x 8 and 7 x 8: neither axis has a kernel of its own
 ]
 
 
@@ -193,6 +195,9 @@ def test_gpu_builder_and_brick_kernels_vs_oracle(case, snb, F, oev, prec):
     force, pos, box = systems.random_box(F, n, nsub, method, L, 1.0, pme=pme, ljpme=ljpme)
     r, o = _compare(make_ev(snb, prec), oev, force, pos, box, TOLS[prec])
     assert r["stats"].n_tiles > 0 and r["stats"].n_host_rebuilds == 0
+    if "x" in name.split("_")[1] and prec != "double" and name.split("_")[1].startswith(("grid54x60", "grid48x56")) and not any(k in os.environ for k in ("SNB_NO_FUSED_Z", "SNB_NO_OWN_SPREAD", "SNB_OWN_SLABS", "SNB_NO_PLANE_FFT", "SNB_NO_RECT_PLANES")):
+        t = [int(x) for x in r["stats"].n_kernel_timed]      # stamp slots of the first (eager) step: 4 = plane kernel / fused x kernel, 3 and 5 = the y passes of the three-pass pipeline
+        assert t[4] > 0 and t[3] == 0 and t[5] == 0, ("rectangular planes must run the plane path", t)
 
 
 FORCE_ONLY_CASES = [
@@ -1011,8 +1016,8 @@ def test_plane_path_and_three_pass_pipeline_agree_with_the_oracle(method, grid, 
     matrix cores + inverse z FFT) instead of the y pass, k_convolveX and the inverse y / z passes.  Both pipelines (SNB_NO_PLANE_FFT=1
     selects the old one; switches are read once per process: child processes) must meet the oracle on forces and slice energies, for an
     odd number of subsets (one line of a pair empty), for more than four (two groups of matrix-core output rows), for one subset, for the
-    dispersion mesh of LJPME, and the stamp slots must show which pipeline ran (slots 3 / 5 are the y passes).  A 48^3 mesh (6 x 8 is not an
-    instantiated split) stays on the old pipeline either way."""
+    dispersion mesh of LJPME, and the stamp slots must show which pipeline ran (slots 3 / 5 are the y passes).  The 48^3 mesh (6 x 8 is not an
+    instantiated split) runs the plane kernel with run-time splits (round 4)."""
     import json
     import os
     import subprocess
@@ -1029,7 +1034,7 @@ def test_plane_path_and_three_pass_pipeline_agree_with_the_oracle(method, grid, 
         assert res["ferr_energy_step"] < 1e-3 and res["ferr_forces_step"] < 1e-3 and res["eerr"] < 1e-3, (tag, res)
     if any(k in os.environ for k in ("SNB_NO_FUSED_Z", "SNB_NO_OWN_SPREAD", "SNB_OWN_SLABS", "SNB_FFT_TWOPASS", "SNB_NO_PLANE_FFT")):
         return      # (tools/switch_matrix.sh: these switches take the plane path's front end away -- parity above is all there is to check)
-    plane_expected = grid in (42, 54, 64)
+    plane_expected = grid in (42, 54, 64, 48)      # (round 4: 48 = 6 x 8 has no kernel of its own and runs the kernel with run-time splits)
     t = got["plane"]["timed"]
     assert t[4] > 0 and t[6] > 0, t
     assert (t[3] == 0 and t[5] == 0) == plane_expected, ("y-pass stamps", t)
