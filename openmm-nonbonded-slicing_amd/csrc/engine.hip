@@ -195,7 +195,8 @@ template <typename Real> struct PmePlan {
         bool twoPass = true;
         if (const char* e = getenv("SNB_FFT_TWOPASS")) twoPass = atoi(e) != 0;
         if (!twoPass) d.rx1 = d.ry1 = d.rz1 = d.rx2 = d.ry2 = d.rz2 = 0;
-        if (sizeof(Real) == 8 && std::max(d.rx1, d.rx2) > 12 && !getenv("SNB_FFT_TWOPASS")) d.rx1 = d.rx2 = 0;
+        // (round 4: the fused x kernel runs 15- / 16-point transforms in double with 256 threads and 256 registers; SNB_CONVX_STAGED_F64=1 restores the staged form)
+        if (sizeof(Real) == 8 && std::max(d.rx1, d.rx2) > 12 && getenv("SNB_CONVX_STAGED_F64")) d.rx1 = d.rx2 = 0;
         gridReal.resize((size_t)nGrids * d.nx * d.ny * d.nz);
         gridCplx.resize((size_t)nGrids * d.nx * d.ny * d.nzc);
         if (sizeof(Real) == 4 && (size_t)d.nx * (d.ny | 1) * 8 <= 156 * 1024) { gridCplxB.resize((size_t)nGrids * d.nx * (d.ny + 8) * d.nzc);      // (plane path, planes that fit LDS; y padded to whole tiles of the inverse z kernel)

@@ -1145,8 +1145,9 @@ template <typename Real> __device__ inline Real recipTerm(const PmeParams<Real>&
 
 // ---- fused x-axis kernel: forward FFT_x, sliced energy, lambda-mixed convolution, inverse FFT_x ---------
 // One work-group owns NB adjacent (ky,kz) columns for ALL held subsets: batch index = sub*NB + col.
-template <typename Real, int R1, int R2> __global__ __launch_bounds__(512) void k_convolveX(const PmeParams<Real> p, int NB, int nCols) {
-    constexpr int NT = 512;
+// (NT = 256 for double precision with a 15- or 16-point register transform: at 512 threads the kernel is capped at 128 VGPRs and spilled
+// -- 351 -> 488 us on c5's 180^3 mesh in round 3, which therefore stayed on the staged transform; at 256 threads it has 256)
+template <typename Real, int R1, int R2, int NT = 512> __global__ __launch_bounds__(NT) void k_convolveX(const PmeParams<Real> p, int NB, int nCols) {
     const int nx = p.d.nx, nsub = p.nsub;
     const int BS = nsub * NB;
     const int c0 = blockIdx.x * NB;
@@ -1707,7 +1708,12 @@ template <typename Real> static void launchFftStrided(int r1, int r2, dim3 grid,
     SNB_STAMPED_LAUNCH(axis == 1 ? stampSlot(p, sign < 0 ? 3 : 5) : -1, (k_fftStrided<Real, 0, 0>), grid, dim3(fftyThreads()), lds, s, p, n, strideA, nbTotal, strideK, NB, tilesPerA, sign, axis);
 }
 template <typename Real> static void launchConvolveX(int r1, int r2, dim3 grid, size_t lds, hipStream_t s, const PmeParams<Real>& p, int NB, int nCols) {
-#define X(A, B) if (r1 == A && r2 == B) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_convolveX<Real, A, B>), grid, dim3(512), lds, s, p, NB, nCols); return; }
+#define X(A, B) if (r1 == A && r2 == B) { \
+        if constexpr (sizeof(Real) == 8 && (A > 12 || B > 12)) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, A, B, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                                                 SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_convolveX<Real, A, B, 256>), grid, dim3(256), lds, s, p, NB, nCols); } \
+        else { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, A, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+               SNB_STAMPED_LAUNCH(stampSlot(p, 4), (k_convolveX<Real, A, B>), grid, dim3(512), lds, s, p, NB, nCols); } \
+        return; }
     SNB_FFT_PAIRS(X)
 #undef X
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convolveX<Real, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
