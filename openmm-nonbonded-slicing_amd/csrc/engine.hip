@@ -237,7 +237,7 @@ public:
     // CU is full), runs beside it; a second launch behind the chain fills the chip.  Both launches claim their work items from one
     // device counter, so the split follows the chain's actual duration.  Eager (stamped) steps stay serial: the per-kernel timers keep
     // measuring every kernel alone.  dOverlap: [0] the counter, [16 ...] the SNB_CU_SLOTS residency counts; zeroed by the gather pass.
-    int overlapMode = getenv("SNB_OVERLAP") ? atoi(getenv("SNB_OVERLAP")) : 0;
+    int overlapMode = getenv("SNB_OVERLAP") ? atoi(getenv("SNB_OVERLAP")) : 1;      // default on (round 4: c3 0.414 -> 0.377 ms per step with derivatives)
     int overlapCuLimit = getenv("SNB_OVERLAP_CU_LIMIT") ? atoi(getenv("SNB_OVERLAP_CU_LIMIT")) : 2;
     int overlapGridA = getenv("SNB_OVERLAP_GRID_A") ? atoi(getenv("SNB_OVERLAP_GRID_A")) : 0;      // 0: six work-groups per CU
     int overlapGridB = getenv("SNB_OVERLAP_GRID_B") ? atoi(getenv("SNB_OVERLAP_GRID_B")) : 0;      // 0: four work-groups per CU
@@ -320,13 +320,17 @@ public:
     };
     void* outPtr = nullptr; int outIsDouble = 0, outAccumulate = 0; bool outputWritten = false;   // snb_set_force_output
     // captured step graphs, a few at a time: a caller that alternates between position (or output) buffers keeps one graph per buffer
-    struct CachedGraph { GraphKey key; hipGraphExec_t exec; };
+    struct CachedGraph { GraphKey key; hipGraphExec_t exec; bool stale; };      // stale: the arguments changed (rebuild, parameters): re-captured and UPDATED in place at the next use
     std::vector<CachedGraph> graphs; size_t graphVictim = 0; long long execCount = 0;
     static constexpr size_t MAX_GRAPHS = 4;
     int timingInterval = 32; long long stampCounter = 0;
     void setTimingInterval(int n) override { timingInterval = n; execCount = 0; }
     hipGraphExec_t sortGraphExec = nullptr; std::vector<unsigned char> sortGraphKey; bool sortGraphBroken = false;      // phase A of the neighbour rebuild
-    void dropGraph() { for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); graphs.clear(); graphVictim = 0; }
+    // A rebuild (or a changed 1-4 list, box, dispersion table) changes kernel arguments, not the step's kernels: the executable graphs are kept
+    // and refreshed with hipGraphExecUpdate from a new capture.  Instantiating the forked graph of an overlapped step anew costs the host
+    // ~0.7 ms (a linear one 10 us), i.e. 0.3 ms of idle GPU after every rebuild; an update that fails falls back to a new instantiation.
+    void dropGraph() { for (auto& g : graphs) g.stale = true; }
+    void destroyGraphs() { for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); graphs.clear(); graphVictim = 0; }
     bool lastRecip = false;
     snb_stats stats;
 
@@ -378,7 +382,7 @@ public:
             if (g[7] > 0) fprintf(stderr, "[snb] spreading (busy work-groups; scanning spreader: scan / entries / z FFT + store; merge kernel: sums / strays + z FFT / store): %.2f us, %.2f us, %.2f us per work-group (%lld work-groups)\n", g[4] / 100.0 / g[7], g[5] / 100.0 / g[7], g[6] / 100.0 / g[7], g[7]);
         }
         if (dPmeTrace.p) { long long h[4] = {0, 0, 0, 0}; (void)hipMemcpy(h, dPmeTrace.p, 32, hipMemcpyDeviceToHost); if (h[2] > 0) fprintf(stderr, "[snb] interpolation bricks: mean load %.2f us, mean compute %.2f us per work-group (%lld work-groups)\n", h[0] / 100.0 / h[2], h[1] / 100.0 / h[2], h[2]); }
-        dropGraph();
+        destroyGraphs();
         if (sortGraphExec) { (void)hipGraphExecDestroy(sortGraphExec); sortGraphExec = nullptr; }
         for (auto& r : ring) { for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]); for (int k = 0; k < 16; k++) { (void)hipEventDestroy(r.ks.start[k]); (void)hipEventDestroy(r.ks.stop[k]); } }
         for (int k = 0; k < 3; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
@@ -1290,16 +1294,23 @@ public:
         // at the next step, while this one is executing)
         // Energy steps (per-slice energies, the step of every force with energy-parameter derivatives, Q4) are graph steps like any other:
         // they end with the device-side sum of the slice-energy partitions and leave the result there until it is asked for.
-        const bool eager = cfg.disable_graph || noStepGraph || rebuilding || (timingInterval > 0 && execCount++ % timingInterval == 0);
+        // (round 4: a rebuild step replays its graph too when one exists for these buffers -- refreshing it costs the host ~20 us of capture +
+        // hipGraphExecUpdate, against ~40 us of launch gaps of an eager step, and an overlapped step is 37 us shorter than a serial one)
+        const GraphKey stepKey{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0, energy ? (energySelective ? 2 : 1) : 0, outPtr, outIsDouble, outAccumulate};
+        bool haveGraph = false;
+        for (auto& g : graphs) if (g.key == stepKey && g.exec) haveGraph = true;
+        static const bool eagerRebuildSteps = getenv("SNB_EAGER_REBUILD_STEP") != nullptr;      // test switch: the rebuild step as plain launches (rounds 1-3)
+        const bool eager = cfg.disable_graph || noStepGraph || (rebuilding && (!haveGraph || eagerRebuildSteps)) || (timingInterval > 0 && execCount++ % timingInterval == 0);
         if (eager) {
             EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
             if (ev.pending) harvest(ev);
             enqueueStep(energy, includeDirect != 0, includeRecip != 0, &ev);
             ev.pending = true;
         } else {
-            GraphKey key{devUserPos, posIsDouble, posStride4, includeDirect != 0, includeRecip != 0, energy ? (energySelective ? 2 : 1) : 0, outPtr, outIsDouble, outAccumulate};
+            const GraphKey& key = stepKey;
             hipGraphExec_t graphExec = nullptr;
-            for (auto& g : graphs) if (g.key == key) { graphExec = g.exec; break; }
+            CachedGraph* cached = nullptr;
+            for (auto& g : graphs) if (g.key == key) { cached = &g; if (!g.stale) graphExec = g.exec; break; }
             if (!graphExec) {
                 if (!stream2 && (concurrentPme || overlapMode)) {   // created outside the capture
                     int lo = 0, hi = 0;
@@ -1308,14 +1319,29 @@ public:
                     HIPCHECK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&evPairA, hipEventDisableTiming));
                 }
                 hipGraph_t graph = nullptr;
+                const auto tc0 = std::chrono::steady_clock::now();
                 HIPCHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
                 try { enqueueStep(energy, includeDirect != 0, includeRecip != 0, nullptr); }
                 catch (...) { (void)hipStreamEndCapture(stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
                 HIPCHECK(hipStreamEndCapture(stream, &graph));
-                HIPCHECK(hipGraphInstantiate(&graphExec, graph, nullptr, nullptr, 0));
+                const auto tc1 = std::chrono::steady_clock::now();
+                bool updated = false;
+                static const bool noUpdate = getenv("SNB_NO_GRAPH_UPDATE") != nullptr;      // test switch: a new instantiation after every rebuild, as before round 4
+                if (cached && cached->exec && !noUpdate) {
+                    hipGraphNode_t errNode = nullptr; hipGraphExecUpdateResult res;
+                    if (hipGraphExecUpdate(cached->exec, graph, &errNode, &res) == hipSuccess) { graphExec = cached->exec; cached->stale = false; updated = true; }
+                    else (void)hipGetLastError();
+                }
+                if (!updated) {
+                    HIPCHECK(hipGraphInstantiate(&graphExec, graph, nullptr, nullptr, 0));
+                    if (cached) { if (cached->exec) (void)hipGraphExecDestroy(cached->exec); cached->exec = graphExec; cached->stale = false; }
+                    else if (graphs.size() < MAX_GRAPHS) graphs.push_back({key, graphExec, false});
+                    else { (void)hipGraphExecDestroy(graphs[graphVictim].exec); graphs[graphVictim] = {key, graphExec, false}; graphVictim = (graphVictim + 1) % MAX_GRAPHS; }
+                }
                 HIPCHECK(hipGraphDestroy(graph));
-                if (graphs.size() < MAX_GRAPHS) graphs.push_back({key, graphExec});
-                else { (void)hipGraphExecDestroy(graphs[graphVictim].exec); graphs[graphVictim] = {key, graphExec}; graphVictim = (graphVictim + 1) % MAX_GRAPHS; }
+                { static const bool verbose = getenv("SNB_VERBOSE") != nullptr;
+                  if (verbose) fprintf(stderr, "[snb] step graph: capture %.0f us, %s %.0f us (host)\n", std::chrono::duration<double, std::micro>(tc1 - tc0).count(), updated ? "update" : "instantiate",
+                                       std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc1).count()); }
             }
             HIPCHECK(hipGraphLaunch(graphExec, stream));
             if (overlapMode && dOverlap.p) { static int dbg = getenv("SNB_OVERLAP_DEBUG") ? 3 : 0; if (dbg > 0) { dbg--; dumpOverlapTable(); } }

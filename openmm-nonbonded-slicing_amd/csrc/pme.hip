@@ -26,6 +26,17 @@ namespace snb {
 thread_local KernelStamps* g_stamps = nullptr;
 template <typename Real> static inline int stampSlot(const PmeParams<Real>& p, int k) { return k + (p.dispersion ? 8 : 0); }
 
+// Wave priority of the reciprocal pipeline's front kernels (the ones an overlapped step runs beside the resident pair kernel, engine.hip
+// overlapMode).  0 = none: the arbiter then serves the older pair-kernel waves first (measured best, docs/MEASUREMENT_LOG.md round 4).
+#ifndef SNB_PME_PRIO_LEVEL
+#define SNB_PME_PRIO_LEVEL 0
+#endif
+#if SNB_PME_PRIO_LEVEL > 0
+#define SNB_PME_PRIO() __builtin_amdgcn_s_setprio(SNB_PME_PRIO_LEVEL)
+#else
+#define SNB_PME_PRIO() do {} while (0)
+#endif
+
 // x / d for 0 <= x < 2^22 without the ~35-instruction integer division: (x + 0.5) * (1/d) never lands within rounding error of an integer.
 // Every dividend in this file is bounded by a work-group's LDS element count, a brick's line count or a mesh plane / slab of at most
 // 1024 x 1024 points (PmePlan::init in engine.hip rejects larger meshes).
@@ -738,6 +749,7 @@ template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bound
 // Replaces gridSpreadCharge (platforms/common/src/kernels/pme.cc:24-122) + the sort it relies on + the forward z pass.
 // ---------------------------------------------------------------------------------------------------
 template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_spreadOwn(const PmeParams<Real> p) {
+    SNB_PME_PRIO();
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
     constexpr int NT = 512;
     using Acc = typename std::conditional<FIXED, int, double>::type;
@@ -856,6 +868,7 @@ template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_sp
 // line: at most 3 x 3 bricks and 2 slabs cover it; per y neighbour the 6 (predicated) loads are issued back to back -- the first version
 // walked the candidates one dependent load at a time and took 101 us on c3.
 template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_spreadMerge(const PmeParams<Real> p, const int chunk, const int plane) {
+    SNB_PME_PRIO();
     // NT = 256      // (a brick is ~18 complex lines: 512 threads left most of them idle in the FFT passes, and at the ~120 VGPRs of those passes 256-thread groups go four to a CU)
     using Acc = typename std::conditional<FIXED, int, double>::type;
     constexpr int CMAX = FIXED ? 4 : 2;                                    // values per 16-byte load
@@ -1456,6 +1469,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_planeEterm(con
 }
 
 template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeXY(const PmeParams<float> p, const int NBY) {
+    SNB_PME_PRIO();
     using Real = float;
     using Splits = typename std::conditional<R1 == 0, PlaneSplitsDynamic, PlaneSplitsStatic<R1, R2>>::type;      // R1 == 0: rectangular plane, splits from the plan
     const Splits sp(p.d);
@@ -1596,6 +1610,7 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeX
 // imaginary line of one complex transform (Z = A + iB with A, B Hermitian) and runs the inverse z FFT into the real mesh [slot][x][y][z]
 // the interpolation reads.  mix == 0 (sharded engines): no mix, the subsets' own potentials.
 template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_fftZInvMix(const PmeParams<float> p, const int NBY) {
+    SNB_PME_PRIO();
     using Real = float;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc, nsub = p.nsub;
