@@ -640,6 +640,9 @@ def main():
                    "derivative_slices": [int(i) for i in np.nonzero(deriv_slices)[0]], "list_overruns": overruns, "preconditioning_steps": precondition, "allreduce_ms": round(allreduce_ms, 4) if allreduce_ms is not None else None,
                    "first_call_ms": round(first_ms, 1), "energy_step_ms": round(energy_ms, 3), "energy_step_gpu_ms": round(eng.stats().last_total_ms, 3),
                    "gpu_ms_per_step": round(gpu_ms, 4), "direct_kernel_ms": round(direct_ms, 4), "reciprocal_ms": round(recip_ms, 4),
+                   # replayed steps run the PME chain beside a CU-limited resident launch of the pair kernel (engine.hip overlapMode; the eager stamped
+                   # steps behind `roofline` stay serial, so every kernel is still timed alone): the engine's own rule, restated
+                   "overlap": os.environ.get("SNB_OVERLAP", "1") != "0" and T >= int(os.environ.get("SNB_OVERLAP_MIN_TILES", "100000")),
                    "parallelism": ("subset-grid + i-block sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},
         "roofline": roof,
         "roofline_other_step": roof_plain if headline_deriv else roof_deriv,

@@ -241,6 +241,7 @@ public:
     int overlapCuLimit = getenv("SNB_OVERLAP_CU_LIMIT") ? atoi(getenv("SNB_OVERLAP_CU_LIMIT")) : 2;
     int overlapGridA = getenv("SNB_OVERLAP_GRID_A") ? atoi(getenv("SNB_OVERLAP_GRID_A")) : 0;      // 0: six work-groups per CU
     int overlapGridB = getenv("SNB_OVERLAP_GRID_B") ? atoi(getenv("SNB_OVERLAP_GRID_B")) : 0;      // 0: four work-groups per CU
+    long long overlapMinTiles = getenv("SNB_OVERLAP_MIN_TILES") ? atoll(getenv("SNB_OVERLAP_MIN_TILES")) : 100000;      // below this the pair kernel is shorter than the PME chain and the fork only costs (c2, 65k tiles: +2 %)
     int numCUs = 256; DevBuf<int> dOverlap, dOverlapTrace;
     struct EvSet { hipEvent_t e[5]; bool pending = false; KernelStamps ks; };   // start, direct0, direct1(=recip0 after pair lists), recip1, end; per-kernel stamps (snb_stats.sum_kernel_ms)
     std::vector<EvSet> ring; int ringPos = 0;
@@ -1432,7 +1433,7 @@ public:
         // Opt-in (SNB_CONCURRENT_PME=1): forces-only graph steps run the reciprocal pipeline on a second stream beside the pair
         // kernel (disjoint force arrays fx.. / fpx..).  Timed (eager) steps stay serial so the per-kernel event timers stay clean.
         // overlapped step (see overlapMode above): any graph step with both halves; needs the GPU-built work list (static item order is irrelevant)
-        const bool overlap = !ev && overlapMode && includeDirect && includeRecip && isPme() && nGrids > 0 && stream2 && dOverlap.p && numWorkItems > 0;
+        const bool overlap = !ev && overlapMode && includeDirect && includeRecip && isPme() && nGrids > 0 && stream2 && dOverlap.p && numWorkItems > 0 && shardTiles >= overlapMinTiles;
         const bool fork = overlap || (!ev && !energy && includeDirect && includeRecip && isPme() && nGrids > 0 && concurrentPme && stream2);
         hipStream_t pmeStream = stream;
         if (fork) {

@@ -1101,7 +1101,7 @@ def test_overlapped_steps_match_the_oracle(method, dgrid, prec, snb):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ); e["SNB_OVERLAP"] = "1"; e.pop("SNB_NO_STEP_GRAPH", None)      # (the default since round 4; stated here so that a changed default keeps the test meaningful)
+    e = dict(os.environ); e["SNB_OVERLAP"] = "1"; e["SNB_OVERLAP_MIN_TILES"] = "0"; e.pop("SNB_NO_STEP_GRAPH", None)      # (the default since round 4; stated here so that a changed default keeps the test meaningful)
     r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _OVERLAP_SCRIPT, str(method), str(dgrid), prec], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
