@@ -9,6 +9,9 @@ src = os.path.join(root, "gpurun_out", "final"); dst = os.path.join(root, "profi
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_%s_default_bench.json" % (tag, cfg)))
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_%s_default_bench_kernel_stats.csv" % (tag, cfg)))
 shutil.copy(os.path.join(src, "pmc_sq.txt"), os.path.join(dst, "%s_%s_pmc_sq.txt" % (tag, cfg)))
+for extra, name in (("bench_serial.json", "serial_bench.json"), ("kernel_stats_overlap.csv", "overlapped_bench_kernel_stats.csv")):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, "%s_%s_%s" % (tag, cfg, name)))
 if os.path.exists(os.path.join(src, "pmc_mfma.txt")):
     shutil.copy(os.path.join(src, "pmc_mfma.txt"), os.path.join(dst, "%s_%s_pmc_mfma.txt" % (tag, cfg)))
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
