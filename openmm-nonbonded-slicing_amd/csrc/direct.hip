@@ -560,6 +560,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
         return;
     }
     const int tileBlock = p.listsLast ? (int)blockIdx.x : (int)blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
+    if (p.stepTrace && tileBlock == 0 && threadIdx.x == 0) p.stepTrace[p.traceSlot] = (long long)wall_clock64();
     double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
     __shared__ float4 s_pos[4][64];
     __shared__ float2 s_se[4][64];
@@ -708,6 +709,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     __builtin_amdgcn_wave_barrier();
     item = dyn ? wc.resolve(claimed) : item + nTileBlocks * 4;
     }   // work-item loop
+    if (p.stepTrace && threadIdx.x == 0) p.stepTrace[p.traceSlot + 1] = (long long)wall_clock64();      // (plain store: the last work-group to leave writes last)
 }
 
 

@@ -277,8 +277,9 @@ public:
     }
     DevBuf<int> pmeCells, dZIndex, dScanA, dScanB, dScanC, dAtomCell, dExtent;
     double tileCell[9] = {0};      // the cell the tile image codes refer to (the box; an enclosing cell for CutoffNonPeriodic)
-    DevBuf<long long> dNbTrace, dPmeTrace;
+    DevBuf<long long> dNbTrace, dPmeTrace, dStepTrace;      // dStepTrace: SNB_STEP_TRACE, device wall-clock stamps of the last replayed step
     bool cellsFromGather = false;   // this step's gather pass already wrote the Coulomb-mesh cells
+    bool traceThisStep = false;
     // Parameter offsets on the device (the reference: platforms/common/src/kernels/nonbondedParameters.cc:4-179).  charge/sigma/epsilon
     // and the exception arrays above hold the BASE values; effective = base + sum_k global[k] * delta is formed by k_particleParams /
     // k_exceptionParams whenever a base value, an offset or a global parameter changes -- no re-sort, no tile rebuild, no graph re-capture,
@@ -343,6 +344,7 @@ public:
         ring.resize(RING);
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0) numCUs = prop.multiProcessorCount; }
         if (overlapMode) { dOverlap.resize(SNB_OVERLAP_INTS); HIPCHECK(hipMemsetAsync(dOverlap.p, 0, sizeof(int) * SNB_OVERLAP_INTS, stream)); }
+        if (getenv("SNB_STEP_TRACE")) { dStepTrace.resize(16); HIPCHECK(hipMemsetAsync(dStepTrace.p, 0, sizeof(long long) * 16, stream)); }
         if (overlapMode && getenv("SNB_OVERLAP_DEBUG")) { dOverlapTrace.resize(SNB_CU_SLOTS * 8); HIPCHECK(hipMemsetAsync(dOverlapTrace.p, 0xff, sizeof(int) * SNB_CU_SLOTS * 8, stream)); }
         for (auto& r : ring) { for (int k = 0; k < 5; k++) HIPCHECK(hipEventCreate(&r.e[k])); for (int k = 0; k < 16; k++) { HIPCHECK(hipEventCreate(&r.ks.start[k])); HIPCHECK(hipEventCreate(&r.ks.stop[k])); } }
         charge.assign(N, 0.0); sigma.assign(N, 1.0); epsilon.assign(N, 0.0); subset.assign(N, 0);
@@ -377,6 +379,12 @@ public:
     }
     ~Engine() override {
         (void)hipStreamSynchronize(stream);
+        if (dStepTrace.p && getenv("SNB_STEP_TRACE")) {      // device wall clock (100 MHz) of the last replayed step, relative to the start of its gather pass
+            long long t[16] = {0}; (void)hipMemcpy(t, dStepTrace.p, sizeof(t), hipMemcpyDeviceToHost);
+            auto us = [&](int k) { return t[k] ? (t[k] - t[0]) / 100.0 : -1.0; };
+            fprintf(stderr, "[snb] step trace (us after the gather pass started; -1: not run): pair A %.1f .. %.1f | pair B %.1f .. %.1f | own %.1f | merge %.1f | plane %.1f | mix+z %.1f .. %.1f | interpolation %.1f .. %.1f\n",
+                    us(2), us(3), us(4), us(5), us(6), us(7), us(8), us(9), us(10), us(11), us(12));
+        }
         if (dPmeTrace.p) {
             long long g[8] = {0}; (void)hipMemcpy(g, dPmeTrace.p, 64, hipMemcpyDeviceToHost);
             if (g[7] > 0 && g[3] > 0) fprintf(stderr, "[snb] merge kernel prologue (busy flags, roots of unity, barrier): %.2f us per busy work-group\n", g[3] / 100.0 / g[7]);
@@ -1165,6 +1173,7 @@ public:
         p.d = plan.d; p.nsub = nGrids; p.natoms = Npad; p.posq = posq.p; p.sigeps = sigeps.p; p.atomSubset = atomSubset.p; p.atomGrid = atomGrid.p;
         p.cells = pmeCells.p;
         { static const bool tr = getenv("SNB_PME_TRACE") != nullptr; if (tr) { if (!dPmeTrace.p) { dPmeTrace.resize(8); HIPCHECK(hipMemset(dPmeTrace.p, 0, 64)); } p.trace = dPmeTrace.p; } }
+        p.stepTrace = (traceThisStep && plan.dispersion == (cfg.method == SNB_LJPME)) ? dStepTrace.p : nullptr;      // (the step's LAST mesh: its inverse z transform is what the second launch follows)
         p.cellsReady = (!plan.dispersion && cellsFromGather) ? 1 : 0;
         p.fixDev = dFixScale.p ? dFixScale.p + (plan.dispersion ? 2 : 0) : nullptr;      // (k_fixScale keeps it in step with the parameters)
         p.gridReal = plan.gridReal.p; p.gridCplx = plan.gridCplx.p; p.planeB = plan.gridCplxB.p; p.planeEterm = plan.planeEtermReady ? plan.planeEterm.p : nullptr; p.twx = plan.twx.p; p.twy = plan.twy.p; p.twz = plan.twz.p;
@@ -1427,6 +1436,8 @@ public:
         if (energy && Npad > 0) { gc.clearE = sliceE.p; gc.nClearE = S * 2 * SNB_SLICE_E_PARTS; }
         if (includeRecip && isPme() && dStrayCount.p) { gc.zeroInts = dStrayCount.p; gc.nZeroInts = 2; }
         if (!ev && overlapMode && dOverlap.p) { gc.zeroInts2 = dOverlap.p; gc.nZeroInts2 = SNB_OVERLAP_INTS; }
+        traceThisStep = !ev && dStepTrace.p != nullptr;      // (SNB_STEP_TRACE; replayed steps only: the stamps of the last one are printed when the engine is destroyed)
+        gc.stepTrace = traceThisStep ? dStepTrace.p : nullptr;
         launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, forceBuf.p, forceArrays(), gc, stream);
         if (energy && Npad <= 0) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2 * SNB_SLICE_E_PARTS, stream));
         const bool ew = cfg.method >= SNB_Ewald;
@@ -1491,6 +1502,7 @@ public:
             else if (cfg.method == SNB_Ewald || cfg.method == SNB_PME) mc = MC_EWALD;
             else if (cfg.method == SNB_LJPME) mc = MC_LJPME;
             static const bool noFuse = getenv("SNB_NO_FUSED_LISTS") != nullptr;
+            p.stepTrace = traceThisStep ? dStepTrace.p : nullptr; p.traceSlot = 2;
             if (overlap) {      // first launch: resident beside the reciprocal pipeline, at most overlapCuLimit work-groups per CU
                 p.workCounter = dOverlap.p; p.cuSlots = dOverlap.p + SNB_WORK_SHARDS * 32; p.cuLimit = overlapCuLimit;
                 { static const bool byCount = getenv("SNB_OVERLAP_BY_COUNT") != nullptr; p.cuBaseMax = byCount ? -1 : 0x7fffffff; }      // (0x7fffffff: the launcher fills in the kernel's own allocation)
@@ -1522,7 +1534,7 @@ public:
                 // and the last interpolation -- which also delivers the step's forces -- follows both.
                 auto beforeLastInterpolation = [&]() {
                     if (!overlap) return;
-                    directB.cuSlots = nullptr; directB.cuLimit = 0; directB.listsLast = 0; directB.gridCap = overlapGridB > 0 ? overlapGridB : 4 * numCUs;
+                    directB.cuSlots = nullptr; directB.cuLimit = 0; directB.listsLast = 0; directB.traceSlot = 4; directB.gridCap = overlapGridB > 0 ? overlapGridB : 4 * numCUs;
                     bool t = false;
                     launchDirect<Real>(directB, directMc, wrapMode, energy, nullptr, stream2, nullptr, nullptr, &t);
                     HIPCHECK(hipStreamWaitEvent(stream2, evPairA, 0));

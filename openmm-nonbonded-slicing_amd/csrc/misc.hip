@@ -13,6 +13,7 @@ __global__ void k_gatherPositions(const In* __restrict__ userPos, int stride, co
                                   const Real* __restrict__ imageOffset, typename Vec<Real>::T4* __restrict__ posq, int nPadded,
                                   Real* __restrict__ forces, int nClear, const GatherCells<Real> gc) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    SNB_TRACE_START(gc.stepTrace, 0);
     if (gc.clearE) for (int i = s; i < gc.nClearE; i += gridDim.x * blockDim.x) gc.clearE[i] = 0.0;
     if (gc.zeroInts && s < gc.nZeroInts) gc.zeroInts[s] = 0;
     if (gc.zeroInts2) for (int i = s; i < gc.nZeroInts2; i += gridDim.x * blockDim.x) gc.zeroInts2[i] = 0;

@@ -750,6 +750,7 @@ template <typename Real, bool FORWARD, int R1, int R2> __global__ __launch_bound
 // ---------------------------------------------------------------------------------------------------
 template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_spreadOwn(const PmeParams<Real> p) {
     SNB_PME_PRIO();
+    SNB_TRACE_START(p.stepTrace, 6);
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
     constexpr int NT = 512;
     using Acc = typename std::conditional<FIXED, int, double>::type;
@@ -869,6 +870,7 @@ template <typename Real, bool FIXED> __global__ __launch_bounds__(512) void k_sp
 // walked the candidates one dependent load at a time and took 101 us on c3.
 template <typename Real, bool FIXED, bool FUSEZ, int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_spreadMerge(const PmeParams<Real> p, const int chunk, const int plane) {
     SNB_PME_PRIO();
+    SNB_TRACE_START(p.stepTrace, 7);
     // NT = 256      // (a brick is ~18 complex lines: 512 threads left most of them idle in the FFT passes, and at the ~120 VGPRs of those passes 256-thread groups go four to a CU)
     using Acc = typename std::conditional<FIXED, int, double>::type;
     constexpr int CMAX = FIXED ? 4 : 2;                                    // values per 16-byte load
@@ -1470,6 +1472,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_planeEterm(con
 
 template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeXY(const PmeParams<float> p, const int NBY) {
     SNB_PME_PRIO();
+    SNB_TRACE_START(p.stepTrace, 8);
     using Real = float;
     using Splits = typename std::conditional<R1 == 0, PlaneSplitsDynamic, PlaneSplitsStatic<R1, R2>>::type;      // R1 == 0: rectangular plane, splits from the plan
     const Splits sp(p.d);
@@ -1611,6 +1614,7 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_planeX
 // the interpolation reads.  mix == 0 (sharded engines): no mix, the subsets' own potentials.
 template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_fftZInvMix(const PmeParams<float> p, const int NBY) {
     SNB_PME_PRIO();
+    SNB_TRACE_START(p.stepTrace, 9);
     using Real = float;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int nx = p.d.nx, ny = p.d.ny, nz = p.d.nz, nzc = p.d.nzc, nsub = p.nsub;
@@ -1700,6 +1704,7 @@ template <int R1, int R2, int NT> __global__ __launch_bounds__(NT) void k_fftZIn
         p.gridReal[(((size_t)(2 * m) * nx + x) * ny + (y0 + yy)) * nz + k] = z.x;
         if (2 * m + 1 < nsub) p.gridReal[(((size_t)(2 * m + 1) * nx + x) * ny + (y0 + yy)) * nz + k] = z.y;
     }
+    SNB_TRACE_END(p.stepTrace, 10);
 }
 
 // ---- launch dispatch over the instantiated (R1, R2) pairs ------------------------------------------
@@ -2058,6 +2063,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_interpolate(co
 // (occupancy note: ~100 VGPRs => one 1024-thread work-group per CU, 400 bricks = two rounds of ~20 us on c3; forcing 64 VGPRs spills
 // and measures 71 us, 512-thread groups 56 us, z slabs 70 us -- this shape, 52 us, is the best of those)
 template <typename Real, int NT> __global__ __launch_bounds__(NT) void k_interpolateBricks(const PmeParams<Real> p, const int zSlabs) {
+    SNB_TRACE_START(p.stepTrace, 11);
     extern __shared__ __align__(16) unsigned char s_brick_raw[];
     constexpr int HALO_LO = 1, EXTRA = 6;
     const int ncx = p.sortNcx, ncy = p.sortNcy, nz = p.d.nz;
@@ -2257,6 +2263,7 @@ template <typename Real, int NT> __global__ __launch_bounds__(NT) void k_interpo
         __syncthreads();
         for (int i = tid; i < nS2; i += NT) { const double v = sE[i]; if (v != 0.0) atomicAdd(&SNB_SLICE_E_PARTITION(p.sliceE, p.nsubTotal * (p.nsubTotal + 1))[i], v); }
     }
+    SNB_TRACE_END(p.stepTrace, 12);
 }
 
 template <typename Real> static bool launchInterpolateBricks(const PmeParams<Real>& p0, hipStream_t s) {

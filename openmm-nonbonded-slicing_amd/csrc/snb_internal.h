@@ -32,6 +32,10 @@
 #define SNB_SLICE_E_PARTS 64
 #define SNB_SLICE_E_PARTITION(base, stride) ((base) + (size_t)(blockIdx.x & (SNB_SLICE_E_PARTS - 1)) * (size_t)(stride))
 #define SNB_PME_ORDER 5
+// SNB_STEP_TRACE slots (100 MHz wall clock): kernel start = the stamp of its work-group 0, end = the latest work-group's exit
+#define SNB_TRACE_START(ptr, slot) do { if ((ptr) && blockIdx.x == 0 && threadIdx.x == 0) (ptr)[slot] = (long long)wall_clock64(); } while (0)
+// (a plain store: the last work-group to leave writes last, near enough; an atomic maximum from every work-group serialises at ~15 ns each on one address)
+#define SNB_TRACE_END(ptr, slot) do { if ((ptr) && threadIdx.x == 0) (ptr)[slot] = (long long)wall_clock64(); } while (0)
 
 // Degrees of the double-precision pair kernel's polynomials (forces-only steps): Chebyshev truncation error of the Ewald factor Bt on
 // [0, (cutoff + skin + 0.02)^2] at alpha = 2.6283/nm: degree 14 3.9e-10 of Bt(0), 15 4.7e-11, 16 5.6e-12, 17 6.6e-13; of the LJPME dispersion
@@ -82,6 +86,7 @@ template <typename Real> struct DirectParams {
     int cuBaseMax;            // ... chosen by position: highest VGPR_BASE (units of 8 registers) a staying wave may have; < 0: by order of arrival (direct.hip cuResident)
     int* cuTrace;             // SNB_OVERLAP_DEBUG: [SNB_CU_SLOTS][4][2] raw GPR_ALLOC / LDS_ALLOC registers of the first four arrivals per CU, or null
     int gridCap;              // work-groups to launch in the dynamic mode
+    long long* stepTrace; int traceSlot;      // SNB_STEP_TRACE: wall-clock stamps of a replayed step (start by work-group 0, latest end), see engine.hip
     int listsLast;            // the launch's pair-list work-groups (exclusion corrections, 1-4) come after its tile work-groups instead of before them
 };
 // physical CU key of a work-group: XCC_ID (3 bits) | SE_ID, SH_ID, CU_ID of HW_ID (bits 15:8)
@@ -140,6 +145,7 @@ template <typename Real> struct PmeParams {
     const int* atomSubset;    // [Npad] sorted
     const int* atomGrid;      // [Npad] grid slot of the atom's subset, or -1 (not owned / padding)
     const Real* fixDev;       // single-precision brick spreader: LDS accumulation in 32-bit fixed point: [0] scale, [1] its inverse (device: follows the parameters)
+    long long* stepTrace;     // SNB_STEP_TRACE: [16] wall-clock stamps of the step's kernels (engine.hip printStepTrace)
     long long* trace;         // SNB_PME_TRACE: [0] summed load ticks, [1] summed compute ticks, [2] work-groups (interpolation bricks; 100 MHz ticks)
     int cellsReady;           // cells[] already hold this mesh's cells (written by the position-gather pass)
     int* cells;               // [Npad] scratch: packed mesh cell per atom (k_pmeCells), brick spreader only
@@ -294,6 +300,7 @@ template <typename Real> struct GatherCells {
     const typename Vec<Real>::T4* posRef; int* flags; Real warn2, fail2;
     double* clearE; int nClearE;      // energy steps: the slice-energy partitions, zeroed by this pass (a memset of their own was a 5 us launch)
     int* zeroInts; int nZeroInts;     // small per-step counters reset by this pass (the spreader's stray-atom counts)
+    long long* stepTrace;             // SNB_STEP_TRACE
     int* zeroInts2; int nZeroInts2;   // ... and the work counter + CU table of an overlapped step's pair kernel
 };
 
