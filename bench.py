@@ -423,7 +423,7 @@ def main():
     eng.sync(); torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    eng.set_timing_interval(int(os.environ.get("SNB_BENCH_TIMING_INTERVAL", max(1, min(32, args.steps // 3)))))      # >= 4 timed (eager) steps with kernel stamps even in a short region (an eager stamped step costs ~40 us more than a replayed one)
+    eng.set_timing_interval(int(os.environ.get("SNB_BENCH_TIMING_INTERVAL", max(1, min(32, (args.steps + 2) // 3)))))      # >= 3 timed (eager, serial) steps with kernel stamps even in a short region (an eager stamped step costs ~85 us more than a replayed, overlapped one)
     # derivatives are requested for the scaling parameters of the workload: the slices whose lambda differs from 1
     deriv_slices = (np.abs(w["lam"] - 1.0).max(axis=1) > 0).astype(np.int32)
     eng.set_energy_slices(deriv_slices)
