@@ -566,7 +566,7 @@ def main():
         valu = valu_issue(kern, Tx, d_ms)
         return {"bound": "valu" if valu else "hbm", "bound_note": "VALU-issue-bound in practice (DESIGN.md 4.1); achieved / peak / frac are the HBM figures the bench contract asks for (algorithmic bytes over the launch time), valu_issue is the bound that applies",
                 "valu_issue": valu, "kernel": kern, "step": "with derivatives (energies on the tiles of the bound slices)" if derivatives else "forces only",
-                "timing": "kernel begin/end stamps of hipExtLaunchKernelGGL on the eager steps of the timed region (snb_set_timing_interval: at least 4 of them)",
+                "timing": "kernel begin/end stamps of hipExtLaunchKernelGGL on the eager steps of the timed region (snb_set_timing_interval: at least 3 of them; these steps run serially, every kernel alone)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes": int(nbytes), "tiles": Tx, "avg_launch_ms": round(d_ms, 4), "timed_launches": int(stx.n_timed)}
 
