@@ -13,7 +13,8 @@
  *   (platforms/common/src/CommonNonbondedSlicingKernels.cpp:846-1402).
  *
  * Plain pointers and sizes only: no C++ types, no torch types.  Caller owns every host array;
- * the engine owns all device memory.  One handle = one device = one HIP stream; a handle is not
+ * the engine owns all device memory.  One handle = one device = one HIP stream as far as the caller can see: all work is ordered on
+ * snb_config.stream (replayed steps fork a part of it onto an internal second stream and join it before they end); a handle is not
  * thread-safe.  Errors are status codes; snb_last_error() gives the message an adapter rethrows as
  * OpenMM::OpenMMException (INTEGRATION.md shows the adapter).
  */
