@@ -254,6 +254,7 @@ public:
     const void* devUserPos = nullptr; int posIsDouble = 1, posStride4 = 0; bool havePositions = false;
     DevBuf<unsigned char> ownedPos;
     // sorted state
+    int npadPredict = 0; long long padMispredictions = 0;      // > 0: size of the padded arrays the next GPU rebuild assumes (gpuRebuild); how often that was too small
     int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0, shardTiles = 0; bool wrapMode = false;
     std::vector<int> sortedToUser, userToSorted;
     DevBuf<T4> posq; DevBuf<T2> sigeps; DevBuf<Real> forceBuf, imageOffset, dLambdas;
@@ -559,10 +560,16 @@ public:
     static inline bool owns(int I, int J) { return ((I + J) & 1) ? (I > J) : (I < J); }
 
     void rebuild() {
+        static const bool verbose = getenv("SNB_VERBOSE") != nullptr;
+        const auto tr0 = std::chrono::steady_clock::now();
+        if (verbose) { HIPCHECK(hipStreamSynchronize(stream)); }      // (diagnostic only: separates the wait for the queued steps from the rebuild's own time)
+        const auto tr1 = std::chrono::steady_clock::now();
         dropGraph();   // buffers may move and every kernel argument block changes
         if (staticDirty) uploadStatic();
         gpuBuilt = false;
         if (cfg.host_neighbor_build || !gpuRebuild()) hostRebuild();
+        if (verbose) fprintf(stderr, "[snb] rebuild: waited %.0f us for the queued steps, then %.0f us (host) for the build itself; device time %.0f us\n",
+                             std::chrono::duration<double, std::micro>(tr1 - tr0).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr1).count(), stats.last_rebuild_ms * 1e3);
         pmeCells.resize(Npad);   // per-slot scratch is sized here: nothing may allocate while a step is being captured into a graph
         if (isPme()) { if (!dStrayCount.p) { dStrayCount.resize(2); HIPCHECK(hipMemsetAsync(dStrayCount.p, 0, 2 * sizeof(int), stream)); } planOwnSpread(pme); if (cfg.method == SNB_LJPME) planOwnSpread(dpme); planPlaneTable(pme); if (cfg.method == SNB_LJPME) planPlaneTable(dpme); }
         posRef.resize(Npad);
@@ -981,6 +988,7 @@ public:
         dSlotOfSubset.upload(slot, stream);
         HIPCHECK(hipStreamSynchronize(stream));
         staticDirty = false;
+        npadPredict = 0;      // (subsets or exclusions may have changed: the next rebuild waits for its padded count again)
     }
 
     // ------------------------------------------------------------------------------------------
@@ -1088,11 +1096,21 @@ public:
             if (!replayed) launchNeighborSort<Real>(p, devUserPos, posIsDouble, posStride4, dSortTemp.p, tempBytes, stream);
         }
         HIPCHECK(hipEventRecord(evRebuild[2], stream));
-        int npadDev = 0;
-        HIPCHECK(hipMemcpyAsync(&npadDev, dCounters.p + 7, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIPCHECK(hipStreamSynchronize(stream));
-        if (npadDev < N || (npadDev & 31)) throw HipError{"neighbour build: inconsistent padded atom count"};
-        Npad = npadDev; numBlocks = Npad / 32;
+        // The padded atom count depends on where the sorted order jumps, i.e. it is known on the device only.  Round 4: from the second
+        // rebuild on the arrays are sized by the previous count plus a margin (a few spare all-padding blocks at the end) and the build
+        // goes on without waiting; the exact count comes back with the tile counters below, and an overflow (k_nbScatter counts the
+        // atoms that did not fit) repeats the rebuild with the exact count.  Saves one host round trip (~75 us) per rebuild.
+        static const bool noPredict = getenv("SNB_NB_SYNC_PADDED") != nullptr;      // test switch: wait for the count, as before round 4
+        const bool predicted = npadPredict > 0 && !noPredict;
+        if (predicted) Npad = npadPredict;
+        else {
+            int npadDev = 0;
+            HIPCHECK(hipMemcpyAsync(&npadDev, dCounters.p + 7, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHECK(hipStreamSynchronize(stream));
+            if (npadDev < N || (npadDev & 31)) throw HipError{"neighbour build: inconsistent padded atom count"};
+            Npad = npadDev;
+        }
+        numBlocks = Npad / 32;
         if (Npad >= (1 << SNB_JSHIFT_BITS) - 1) throw HipError{"too many atoms for the 25-bit tile index"};
         // outputs / scratch sized by the padded count
         posq.resize(Npad); sigeps.resize(Npad); imageOffset.resize((size_t)3 * Npad);
@@ -1102,7 +1120,7 @@ public:
         if (tileCap < (size_t)numBlocks * 40) tileCap = (size_t)numBlocks * 40;
         if (tileCap < 64 * 128) tileCap = 64 * 128;      // 64 allocation partitions, each with room for a few blocks' worth of tiles
         float sortMs = 0;
-        HIPCHECK(hipEventElapsedTime(&sortMs, evRebuild[0], evRebuild[2]));
+        if (!predicted) HIPCHECK(hipEventElapsedTime(&sortMs, evRebuild[0], evRebuild[2]));      // (predicted: the sort is part of the span measured below)
         for (int attempt = 0; attempt < 3; attempt++) {
             tileJ.resize(tileCap * 32); tileInfo.resize(tileCap); masks.resize(tileCap * 32); workItems.resize(2 * (tileCap / 4 + 2 * numBlocks + 64)); workItemsStage.resize(tileCap / 4 + 2 * numBlocks + 64); workItemsPartial.resize(tileCap / 4 + 2 * numBlocks + 64);
             p.nPadded = Npad; p.nBlocks = numBlocks; p.blockSubset = blockSubset.p;
@@ -1117,12 +1135,18 @@ public:
             if (nbTrace) { dNbTrace.resize((size_t)4 * numBlocks); p.dbgOut = dNbTrace.p; }
             p.tileJ = tileJ.p; p.tileInfo = tileInfo.p; p.masks = masks.p; p.workItems = workItems.p; p.workItemsStage = workItemsStage.p; p.workItemsPartial = workItemsPartial.p; p.counters = dCounters.p;
             p.tileCapacity = (int)tileCap; p.workCapacity = (int)(tileCap / 4 + 2 * numBlocks + 64); p.maskCapacity = (int)tileCap;
-            HIPCHECK(hipEventRecord(evRebuild[0], stream));
+            if (!predicted || attempt > 0) HIPCHECK(hipEventRecord(evRebuild[0], stream));
             launchNeighborBuild<Real>(p, stream);
             HIPCHECK(hipEventRecord(evRebuild[1], stream));
             int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(h), hipMemcpyDeviceToHost, stream));
             HIPCHECK(hipStreamSynchronize(stream));
+            if (predicted && (h[7] > Npad || h[7] < N || (h[7] & 31))) {      // the prediction was too small (or the count is inconsistent): once more, waiting for the exact count
+                if (h[7] < N || (h[7] & 31)) throw HipError{"neighbour build: inconsistent padded atom count"};
+                npadPredict = 0; padMispredictions++;
+                { static const bool verbose = getenv("SNB_VERBOSE") != nullptr; if (verbose) fprintf(stderr, "[snb] rebuild: padded count %d exceeded the predicted %d, repeating with the exact count (%lld so far)\n", h[7], Npad, (long long)padMispredictions); }
+                return gpuRebuild();
+            }
             if (nbTrace && h[3] == 0) {
                 std::vector<long long> tr((size_t)4 * numBlocks);
                 HIPCHECK(hipMemcpy(tr.data(), dNbTrace.p, sizeof(long long) * tr.size(), hipMemcpyDeviceToHost));
@@ -1151,6 +1175,11 @@ public:
                     fprintf(stderr, "\n");
                 }
                 shardTiles = numTiles;      // the builder only emitted the blocks this engine owns
+                // next rebuild's array size: this count + 0.4 % + 8 blocks (c3: 300 k atoms move its count by a few blocks between rebuilds); never shrinking,
+                // so that the buffers -- and the step graph's arguments -- stay where they are
+                npadPredict = std::max(npadPredict, ((int)(h[7] * 1.004) + 256 + 31) / 32 * 32);
+                { static const int shortBy = getenv("SNB_NB_PREDICT_SHORT") ? atoi(getenv("SNB_NB_PREDICT_SHORT")) : 0;      // test switch: predict this many blocks too FEW (exercises the repeat path)
+                  if (shortBy > 0) npadPredict = std::max(32, h[7] - 32 * shortBy); }
                 gpuBuilt = true;
                 needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;
                 stats.n_rebuilds++;
@@ -1353,7 +1382,15 @@ public:
                   if (verbose) fprintf(stderr, "[snb] step graph: capture %.0f us, %s %.0f us (host)\n", std::chrono::duration<double, std::micro>(tc1 - tc0).count(), updated ? "update" : "instantiate",
                                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc1).count()); }
             }
-            HIPCHECK(hipGraphLaunch(graphExec, stream));
+            { static const bool verbose = getenv("SNB_VERBOSE") != nullptr;
+              if (verbose && rebuilding) {
+                  const auto tl0 = std::chrono::steady_clock::now();
+                  HIPCHECK(hipGraphLaunch(graphExec, stream));
+                  const auto tl1 = std::chrono::steady_clock::now();
+                  HIPCHECK(hipStreamSynchronize(stream));
+                  fprintf(stderr, "[snb] rebuild step: graph launch %.0f us (host), step done after %.0f us\n", std::chrono::duration<double, std::micro>(tl1 - tl0).count(),
+                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl0).count());
+              } else HIPCHECK(hipGraphLaunch(graphExec, stream)); }
             if (overlapMode && dOverlap.p) { static int dbg = getenv("SNB_OVERLAP_DEBUG") ? 3 : 0; if (dbg > 0) { dbg--; dumpOverlapTable(); } }
         }
         if (autoMode && cfg.neighbor_padding > 0) {

@@ -130,6 +130,9 @@ template <typename Real> __global__ void k_nbScatter(const NbParams<Real> p) {
     const int serp = (int)((key >> 20) & ((1u << p.colBits) - 1u));
     const int si0 = t + p.padBefore[t];           // padded index in sorted order
     const int si = si0;
+    // (round 4: the engine sizes the padded arrays from the PREVIOUS rebuild's count plus a margin instead of waiting for this one's;
+    // an atom that would land beyond them raises the overflow count, the engine then repeats the rebuild with the exact count)
+    if (si0 >= p.nPadded) { atomicAdd(&p.counters[3], 1); return; }
     if ((si0 & 31) == 0) p.blockSubset[si0 >> 5] = s;
     p.sortedToUser[si] = u; p.userToSorted[u] = si;
     typename Vec<Real>::T4 v; v.x = p.wrapped[3 * (size_t)u]; v.y = p.wrapped[3 * (size_t)u + 1]; v.z = p.wrapped[3 * (size_t)u + 2]; v.w = p.uCharge[u];
@@ -190,6 +193,7 @@ template <typename Real> __global__ void k_nbPad(const NbParams<Real> p) {
         typename Vec<Real>::T2 z; z.x = 0; z.y = 0; p.sigeps[s] = z;
         p.atomSubset[s] = -1; p.atomGrid[s] = -1; p.atomCell[s] = 1 | (1 << 2) | (1 << 4);
         p.imageOffset[3 * (size_t)s] = 0; p.imageOffset[3 * (size_t)s + 1] = 0; p.imageOffset[3 * (size_t)s + 2] = 0;
+        if ((s & 31) == 0) p.blockSubset[s >> 5] = 0;      // a block that STARTS with a padding slot is all padding (the spare blocks behind the last segment): any valid subset
     }
 }
 
@@ -279,6 +283,7 @@ template <typename Real> __global__ __launch_bounds__(256, 4) void k_nbBuildTile
     const float hx = p.blockHalf[3 * I], hy = p.blockHalf[3 * I + 1], hz = p.blockHalf[3 * I + 2];
     const int il = lane & 31, half = lane >> 5;
     const int uI = p.sortedToUser[I * 32 + il];
+    if (__shfl(uI, 0, 64) < 0) return;      // a block that starts with a padding slot is all padding (the spare blocks behind the last segment): no tiles
     bool failed = false;
 
     // Masks (diagonal rule, padding, exclusions) for the `count` entries gathered so far, then publication of those

@@ -1113,3 +1113,57 @@ def test_overlapped_steps_match_the_oracle(method, dgrid, prec, snb):
             assert rec["eerr"] < tol, (step, rec)
     if prec == "mixed":
         assert res["bitwise_equal"], res
+
+
+_PREDICT_SCRIPT = r'''
+import sys, json, hashlib
+import numpy as np, torch, importlib
+sys.path[:0] = [ROOT, ROOT + "/tests", ROOT + "/oracle"]
+import bench
+snb = importlib.import_module("openmm-nonbonded-slicing_amd")
+w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+n = len(w["q"])
+eng = bench.Engine(snb, w, 4, 54, 0, "mixed", 0, 0, 1, 0.1, 3)       # a rebuild every third step
+rng = np.random.default_rng(11)
+pos = w["pos"].copy()
+forces = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+h = hashlib.sha1(); worst = 0.0
+for step in range(8):
+    pos = pos + rng.uniform(-0.01, 0.01, pos.shape)
+    pt = torch.tensor(pos, dtype=torch.float32, device="cuda")
+    eng.set_positions_device(pt.data_ptr(), False); eng.execute(False); eng.forces_to(forces.data_ptr(), False); eng.sync()
+    h.update(forces.cpu().numpy().tobytes())
+    if step in (0, 7):
+        w2 = dict(w); w2["pos"] = np.ascontiguousarray(pt.double().cpu().numpy())
+        fo, so, _, _ = bench.oracle_eval(w2, 4, 54, 0)
+        f = forces.double().cpu().numpy()
+        worst = max(worst, float(np.max(np.linalg.norm(f - fo, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0))))
+st = eng.stats()
+print("RESULT " + json.dumps(dict(sha=h.hexdigest(), tiles=int(st.n_tiles), padded=int(st.n_padded_atoms), rebuilds=int(st.n_rebuilds), host_rebuilds=int(st.n_host_rebuilds), ferr=worst)))
+'''
+
+
+def test_predicted_padded_count_and_its_repeat_path(snb):
+    """Round 4: from the second rebuild on the GPU neighbour build sizes the padded arrays from the previous rebuild's count plus a margin and
+    does not wait for this rebuild's count (engine.hip gpuRebuild; the reference's counterpart is OpenMM's findBlocksWithInteractions, which
+    keeps its buffers and re-runs on overflow).  Three child processes: waiting for the count as before (SNB_NB_SYNC_PADDED=1), predicting
+    (default), and predicting two blocks too FEW (SNB_NB_PREDICT_SHORT=2: every predicted rebuild overflows and is repeated with the exact
+    count).  All three must meet the oracle; in mixed precision (integer force sums) the forces of all eight steps must be bit-for-bit
+    identical between the three, spare padding blocks or not."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for tag, env in (("sync", {"SNB_NB_SYNC_PADDED": "1"}), ("predicted", {}), ("short", {"SNB_NB_PREDICT_SHORT": "2", "SNB_VERBOSE": "1"})):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _PREDICT_SCRIPT], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        if tag == "short":
+            assert "repeating with the exact count" in r.stderr, r.stderr[-1500:]      # the overflow was seen and the rebuild repeated
+        got[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+        assert got[tag]["host_rebuilds"] == 0 and got[tag]["ferr"] < 1e-3, (tag, got[tag])
+    assert got["sync"]["sha"] == got["predicted"]["sha"] == got["short"]["sha"], got
+    assert got["sync"]["tiles"] == got["predicted"]["tiles"] == got["short"]["tiles"], got
+    assert got["predicted"]["padded"] >= got["sync"]["padded"], got

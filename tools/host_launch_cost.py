@@ -21,7 +21,7 @@ walk = torch.tensor(np.random.default_rng(1).normal(0.0, 0.0015, (len(w["q"]), 3
 eng.set_energy_slices(np.ones(nsub * (nsub + 1) // 2, dtype=np.int32))
 if mode in ("rebuild", "all"):
     eng.close()
-    eng = bench.Engine(pkg, w, method, grid, dgrid, precision, 0, 0, 1, 0.1, 20, stream=torch.cuda.current_stream().cuda_stream)
+    eng = bench.Engine(pkg, w, method, grid, dgrid, precision, 0, 0, 1, 0.1, int(os.environ.get("REBUILD_EVERY", "20")), stream=torch.cuda.current_stream().cuda_stream)
     eng.set_force_output(forces.data_ptr(), False); eng.set_positions_device(pos.data_ptr(), False); eng.set_timing_interval(0)
     eng.set_energy_slices(np.ones(nsub * (nsub + 1) // 2, dtype=np.int32))
     for _ in range(50):
