@@ -175,7 +175,7 @@ template <typename Real> struct PmePlan {
     DevBuf<Real> gridReal;
     DevBuf<typename Vec<Real>::T2> gridCplx, gridCplxB, twx, twy, twz;      // (gridCplxB: second complex mesh of the plane path, single precision)
     DevBuf<Real> modx, mody, modz;
-    DevBuf<Real> planeEterm; bool planeEtermReady = false;      // plane path: kernel-value table, refilled at every rebuild (box, alpha)
+    DevBuf<Real> planeEterm; bool planeEtermReady = false, planeEtermFilled = false; double planeEtermKey[10] = {0};      // plane path: kernel-value table, refilled at a rebuild when the box or alpha changed
     // own-atoms spreader (pme.hip k_spreadOwn / k_spreadMerge): geometry and buffers, sized at rebuild time
     int ownSlabs = 0, ownMargin = 1; DevBuf<unsigned char> ownPartial; DevBuf<int> ownBusy; DevBuf<int2> strays;
     void init(const int g[3], int nGrids, hipStream_t s) {
@@ -254,6 +254,7 @@ public:
     const void* devUserPos = nullptr; int posIsDouble = 1, posStride4 = 0; bool havePositions = false;
     DevBuf<unsigned char> ownedPos;
     // sorted state
+    int* hNbPub = nullptr; int* dNbPub = nullptr; int nbPubSeq = 0;      // the rebuild's totals in mapped host memory + sequence number (gpuRebuild)
     int npadPredict = 0; long long padMispredictions = 0;      // > 0: size of the padded arrays the next GPU rebuild assumes (gpuRebuild); how often that was too small
     int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0, shardTiles = 0; bool wrapMode = false;
     std::vector<int> sortedToUser, userToSorted;
@@ -362,6 +363,9 @@ public:
         HIPCHECK(hipHostMalloc((void**)&hDispFlags, 64, hipHostMallocMapped));
         hDispFlags[0] = hDispFlags[1] = 0;
         HIPCHECK(hipHostGetDevicePointer((void**)&dDispFlags, hDispFlags, 0));
+        HIPCHECK(hipHostMalloc((void**)&hNbPub, 64, hipHostMallocMapped));
+        std::memset(hNbPub, 0, 64);
+        HIPCHECK(hipHostGetDevicePointer((void**)&dNbPub, hNbPub, 0));
         for (int s = 0; s < nsub; s++) if (s % cfg.shard_count == cfg.shard_rank) ownedSubsets.push_back(s);
         nGrids = cfg.shard_count == 1 ? nsub : (int)ownedSubsets.size();
         if (isPme()) {
@@ -398,6 +402,7 @@ public:
         for (int k = 0; k < 3; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
         for (int k = 0; k < 2; k++) if (evStepDone[k]) (void)hipEventDestroy(evStepDone[k]);
         if (hDispFlags) (void)hipHostFree(hDispFlags);
+        if (hNbPub) (void)hipHostFree(hNbPub);
         if (stream2) { (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); (void)hipEventDestroy(evPairA); (void)hipStreamDestroy(stream2); }
         if (ownStream) (void)hipStreamDestroy(stream);
     }
@@ -1139,8 +1144,22 @@ public:
             launchNeighborBuild<Real>(p, stream);
             HIPCHECK(hipEventRecord(evRebuild[1], stream));
             int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(h), hipMemcpyDeviceToHost, stream));
-            HIPCHECK(hipStreamSynchronize(stream));
+            // the totals come back through mapped host memory and a sequence number the host spins on (a sleeping hipStreamSynchronize wakes
+            // up 30-45 us after the kernel has ended, with the GPU idle); the synchronisation behind it then returns at once
+            static const bool noSpin = getenv("SNB_NB_NO_SPIN") != nullptr;
+            if (hNbPub && dNbPub && !noSpin) {
+                const int seq = ++nbPubSeq;
+                launchNeighborPublish(dCounters.p, dNbPub, seq, stream);
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+                volatile int* pub = hNbPub;
+                while (pub[8] != seq && std::chrono::steady_clock::now() < deadline) { __builtin_ia32_pause(); }
+                if (pub[8] == seq) { for (int k = 0; k < 8; k++) h[k] = pub[k]; }
+                else { HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(h), hipMemcpyDeviceToHost, stream)); }
+                HIPCHECK(hipStreamSynchronize(stream));      // (the events below are read next; nothing is running any more)
+            } else {
+                HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+                HIPCHECK(hipStreamSynchronize(stream));
+            }
             if (predicted && (h[7] > Npad || h[7] < N || (h[7] & 31))) {      // the prediction was too small (or the count is inconsistent): once more, waiting for the exact count
                 if (h[7] < N || (h[7] & 31)) throw HipError{"neighbour build: inconsistent padded atom count"};
                 npadPredict = 0; padMispredictions++;
@@ -1246,11 +1265,15 @@ public:
     // bring a work-group's LDS region under 40 KB (four work-groups per CU), at least two.
     // Plane path (pme.hip k_planeXY): its table of reciprocal-space kernel values follows the box and alpha, both fixed between rebuilds.
     void planPlaneTable(PmePlan<Real>& plan) {
+        if (!plan.planeEterm.p || !plan.gridCplxB.p || nGrids <= 0) { plan.planeEtermReady = false; return; }
+        // (the table depends on the box, alpha and the mesh only: a rebuild with the same box keeps it -- 11 us of kernel + a launch per rebuild)
+        double key[10]; for (int i = 0; i < 9; i++) key[i] = box[i]; key[9] = plan.alpha;
+        if (plan.planeEtermReady && plan.planeEtermFilled && std::memcmp(key, plan.planeEtermKey, sizeof(key)) == 0) return;
+        std::memcpy(plan.planeEtermKey, key, sizeof(key));
         plan.planeEtermReady = false;
-        if (!plan.planeEterm.p || !plan.gridCplxB.p || nGrids <= 0) return;
         PmeParams<Real> pp; std::memset(&pp, 0, sizeof(pp));
         fillPme(pp, plan, false);
-        launchPlaneEterm<Real>(pp, plan.planeEterm.p, stream);
+        plan.planeEtermFilled = launchPlaneEterm<Real>(pp, plan.planeEterm.p, stream);
         plan.planeEtermReady = true;
     }
     void planOwnSpread(PmePlan<Real>& plan) {

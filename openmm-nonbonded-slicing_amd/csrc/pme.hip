@@ -1809,14 +1809,15 @@ static void launchFftZInvMix(const PmeParams<float>& p, hipStream_t s) {
     SNB_STAMPED_LAUNCH(stampSlot(p, 6), (k_fftZInvMix<0, 0, 256>), grid, dim3(256), lds, s, p, NBY);
 }
 // Rebuild time: the kernel-value table of the plane path (no-op when the mesh does not qualify).
-template <typename Real> void launchPlaneEterm(const PmeParams<Real>& p, Real* table, hipStream_t s) {
+template <typename Real> bool launchPlaneEterm(const PmeParams<Real>& p, Real* table, hipStream_t s) {      // true: the table was (re)filled
     PmeParams<Real> q = p; q.planeEterm = table;
-    if (!table || !planePathOK<Real>(q)) return;
+    if (!table || !planePathOK<Real>(q)) return false;
     const size_t n = (size_t)p.d.nzc * p.d.nx * p.d.ny;
     hipLaunchKernelGGL((k_planeEterm<Real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, table);
+    return true;
 }
-template void launchPlaneEterm<float>(const PmeParams<float>&, float*, hipStream_t);
-template void launchPlaneEterm<double>(const PmeParams<double>&, double*, hipStream_t);
+template bool launchPlaneEterm<float>(const PmeParams<float>&, float*, hipStream_t);
+template bool launchPlaneEterm<double>(const PmeParams<double>&, double*, hipStream_t);
 // The middle of the pipeline on the plane path (after a spreader that returned 2): convolution + x / y transforms per plane, then mix + inverse z.
 template <typename Real> void launchPmePlanePath(const PmeParams<Real>& p, hipStream_t s) {
     if constexpr (std::is_same<Real, float>::value) {

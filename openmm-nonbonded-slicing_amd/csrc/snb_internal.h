@@ -238,13 +238,14 @@ void launchExtent(const void* userPos, int isDouble, int stride4, int n, int* ex
 template <typename Real> size_t nbSortTempBytes(int n);
 template <typename Real> void launchNeighborSort(const NbParams<Real>& p, const void* userPos, int isDouble, int stride4, void* sortTemp, size_t sortTempBytes, hipStream_t s);
 template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipStream_t s);
+void launchNeighborPublish(const int* counters, int* hostMapped, int seq, hipStream_t s);   // counters[0..7] + sequence number into mapped host memory (the host spins on it)
 
 // ---- launchers implemented in the .hip translation units -------------------------------------
 template <typename Real> bool launchDirect(const DirectParams<Real>& p, int methodClass, bool wrap, bool energy, const PairListParams<Real>* lists, hipStream_t s,
                                           hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, bool* timed = nullptr);   // true: lists ran inside the launch
 template <typename Real> void launchPairLists(const PairListParams<Real>& p, bool energy, hipStream_t s);
 template <typename Real> int launchPmeSpread(const PmeParams<Real>& p, hipStream_t s);   // 1: forward z FFT already done; 2: ... and the spectrum is plane-major (plane path)
-template <typename Real> void launchPlaneEterm(const PmeParams<Real>& p, Real* table, hipStream_t s);   // rebuild time: fills the plane path's kernel-value table
+template <typename Real> bool launchPlaneEterm(const PmeParams<Real>& p, Real* table, hipStream_t s);   // rebuild time: fills the plane path's kernel-value table
 template <typename Real> void launchPmePlanePath(const PmeParams<Real>& p, hipStream_t s);   // after a spreader that returned 2: k_planeXY + k_fftZInvMix instead of forward FFT, convolution, inverse FFT
 template <typename Real> void launchPmeForwardFFT(const PmeParams<Real>& p, hipStream_t s, bool zDone);
 template <typename Real> void launchPmeConvolution(const PmeParams<Real>& p, hipStream_t s);   // fused x-FFT, energy, convolution, inverse x-FFT
