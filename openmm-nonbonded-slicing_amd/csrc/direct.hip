@@ -123,9 +123,8 @@ struct WorkClaim {
         if (lane < SNB_WORK_SHARDS) left = (numWork - lane + SNB_WORK_SHARDS - 1) / SNB_WORK_SHARDS - __hip_atomic_load(&ctr[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return __ballot(left > 0) != 0;
     }
-    __device__ int resolve(int v) { return resolveIndex(__builtin_amdgcn_readfirstlane(v)); }
-    __device__ int resolveIndex(int claimedIndex) {      // item index of a claim issued on `shard` (its value, uniform), moving on to other counters when that one has run out; numWork: no items left
-        int idx = shard + SNB_WORK_SHARDS * claimedIndex;
+    __device__ int resolve(int v) {      // item index of a claim issued on `shard`, moving on to other counters when that one has run out; numWork: no items left
+        int idx = shard + SNB_WORK_SHARDS * __builtin_amdgcn_readfirstlane(v);
         while (idx >= numWork) {
             int left = 0;
             if (lane < SNB_WORK_SHARDS) left = (numWork - lane + SNB_WORK_SHARDS - 1) / SNB_WORK_SHARDS - __hip_atomic_load(&ctr[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -328,7 +327,6 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
     const T4 pi = p.posq[I * 32 + il];
     const T2 sei = p.sigeps[I * 32 + il];
     const Real qi = pi.w * p.k4pe;
-    const int claimedS = __builtin_amdgcn_readfirstlane(claimed);      // (returned with the loads above: scalar from here on, as in k_directPacked)
     Real c6i = 0;
     if (MC == MC_LJPME) c6i = Real(8) * sei.x * sei.x * sei.x * sei.y;
     Real fix = 0, fiy = 0, fiz = 0;
@@ -428,7 +426,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
         if (lane == 0) { atomicAdd(&sliceE[2 * curSlice], a); atomicAdd(&sliceE[2 * curSlice + 1], b); }
     }
     __builtin_amdgcn_wave_barrier();
-    item = dyn ? wc.resolveIndex(claimedS) : item + nTileBlocks * 4;
+    item = dyn ? wc.resolve(claimed) : item + nTileBlocks * 4;
     }   // work-item loop
 }
 
@@ -598,8 +596,6 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     const v2f qi = {pa.w * p.k4pe, pb.w * p.k4pe}, sigi = {sa.x, sb.x}, epsi = {sa.y, sb.y};
     v2f fix = {0.f, 0.f}, fiy = {0.f, 0.f}, fiz = {0.f, 0.f};
     const v2f c6i = {8.0f * sa.x * sa.x * sa.x * sa.y, 8.0f * sb.x * sb.x * sb.x * sb.y};      // LJPME: c6 of the two i-atoms
-    // (the claim was issued before the loads above, so it has returned with them: into a scalar register now, no vector register across the item)
-    const int claimedS = __builtin_amdgcn_readfirstlane(claimed);
     v2f ecl = {0.f, 0.f}, elj = {0.f, 0.f};
     int curSlice = -1; bool curNeeded = false;
     auto flushEnergy = [&]() {   // raw energies of the slice just finished: wave sum in double, one atomic per term
@@ -711,7 +707,7 @@ __global__ __launch_bounds__(256, 4) void k_directPacked(const DirectParams<floa
     if (row == 1) { fAddT<FIXED>(p, p.fx, (I * 32 + 16 + c), ux); fAddT<FIXED>(p, p.fy, (I * 32 + 16 + c), uy); fAddT<FIXED>(p, p.fz, (I * 32 + 16 + c), uz); }
     if (ENERGY) { if (curNeeded) flushEnergy(); curSlice = -1; curNeeded = false; }
     __builtin_amdgcn_wave_barrier();
-    item = dyn ? wc.resolveIndex(claimedS) : item + nTileBlocks * 4;
+    item = dyn ? wc.resolve(claimed) : item + nTileBlocks * 4;
     }   // work-item loop
     if (p.stepTrace && threadIdx.x == 0) p.stepTrace[p.traceSlot + 1] = (long long)wall_clock64();      // (plain store: the last work-group to leave writes last)
 }
