@@ -16,9 +16,10 @@ eng.set_timing_interval(0)
 for _ in range(50):
     eng.execute(False)
 eng.sync()
-mode = sys.argv[2] if len(sys.argv) > 2 else "plain"      # plain | move (a torch kernel per step) | deriv (derivative steps) | rebuild (a rebuild every 20 steps) | all
+mode = sys.argv[2] if len(sys.argv) > 2 else "plain"      # plain | move (a torch kernel per step) | deriv (derivative steps, all slices) | derivsel (the bench's slices) | rebuild (a rebuild every 20 steps) | all
 walk = torch.tensor(np.random.default_rng(1).normal(0.0, 0.0015, (len(w["q"]), 3)), dtype=torch.float32, device="cuda")
-eng.set_energy_slices(np.ones(nsub * (nsub + 1) // 2, dtype=np.int32))
+sel = (np.abs(w["lam"] - 1.0).max(axis=1) > 0).astype(np.int32) if mode.endswith("sel") else np.ones(nsub * (nsub + 1) // 2, dtype=np.int32)      # (…sel: the slices bench.py asks derivatives for)
+eng.set_energy_slices(sel)
 if mode in ("rebuild", "all"):
     eng.close()
     eng = bench.Engine(pkg, w, method, grid, dgrid, precision, 0, 0, 1, 0.1, int(os.environ.get("REBUILD_EVERY", "20")), stream=torch.cuda.current_stream().cuda_stream)
@@ -34,7 +35,7 @@ for rep in range(3):
         a = time.perf_counter()
         if mode in ("move", "all"):
             pos.add_(walk, alpha=1.0 if i % 2 else -1.0); eng.set_positions_device(pos.data_ptr(), False)
-        if mode in ("deriv", "all"):
+        if mode in ("deriv", "derivsel", "all"):
             eng.execute(2, fetch=False)
         else:
             eng.execute(False)
