@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
         return;
     }
     const int tileBlock = p.listsLast ? (int)blockIdx.x : (int)blockIdx.x - nListBlocks, nTileBlocks = gridDim.x - nListBlocks;
+    if (p.stepTrace && tileBlock == 0 && threadIdx.x == 0) p.stepTrace[p.traceSlot] = (long long)wall_clock64();
     double* const sliceE = SNB_SLICE_E_PARTITION(p.sliceE, p.nsub * (p.nsub + 1));
     using T4 = typename Vec<Real>::T4;
     using T2 = typename Vec<Real>::T2;
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(256, (sizeof(Real) == 8 ? SNB_DIRECT_F64_WAVES : 4)
     __builtin_amdgcn_wave_barrier();
     item = dyn ? wc.resolve(claimed) : item + nTileBlocks * 4;
     }   // work-item loop
+    if (p.stepTrace && threadIdx.x == 0) p.stepTrace[p.traceSlot + 1] = (long long)wall_clock64();
 }
 
 // ---- single-precision forces-only tile kernel with packed math ---------------------------------------
