@@ -255,6 +255,17 @@ public:
     DevBuf<unsigned char> ownedPos;
     // sorted state
     int* hNbPub = nullptr; int* dNbPub = nullptr; int nbPubSeq = 0;      // the rebuild's totals in mapped host memory + sequence number (gpuRebuild)
+    // Rebuild BESIDE the steps (fixed rebuild interval; startSideBuild / finishSideBuild): `sideLead` steps before a rebuild falls due the
+    // positions are copied aside and the whole GPU build runs on a stream of its own into the second set of list buffers (`shadow`), while the
+    // steps go on with the list in use; when the rebuild falls due the two sets change places.  The build's small latency-bound kernels fill
+    // gaps of the steps instead of standing between them (measured with a second engine as the builder, tools/async_rebuild_probe.py: 24 us
+    // per step for a rebuild every 20 steps, against 38-40 in line).
+    struct ListShadow {
+        DevBuf<int> dUserToSorted, dSortedToUser, atomSubset, atomGrid, blockSubset, tileJ; DevBuf<int2> colRange; DevBuf<T4> posq, posRef; DevBuf<T2> sigeps;
+        DevBuf<Real> imageOffset; DevBuf<int4> tileInfo, workItems; DevBuf<unsigned> masks;
+    } shadow;
+    hipStream_t streamBuild = nullptr; hipEvent_t evSnap = nullptr, evBuilt = nullptr; DevBuf<unsigned char> posSnap;
+    bool sideMode = true, sideBuilding = false, sidePending = false; int sideLead = 3, sideSeq = 0; long long sideBuilds = 0, sideDiscarded = 0;
     int npadPredict = 0; long long padMispredictions = 0;      // > 0: size of the padded arrays the next GPU rebuild assumes (gpuRebuild); how often that was too small
     int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0, shardTiles = 0; bool wrapMode = false;
     std::vector<int> sortedToUser, userToSorted;
@@ -329,7 +340,8 @@ public:
     static constexpr size_t MAX_GRAPHS = 4;
     int timingInterval = 32; long long stampCounter = 0;
     void setTimingInterval(int n) override { timingInterval = n; execCount = 0; }
-    hipGraphExec_t sortGraphExec = nullptr; std::vector<unsigned char> sortGraphKey; bool sortGraphBroken = false;      // phase A of the neighbour rebuild
+    struct SortGraph { std::vector<unsigned char> key; hipGraphExec_t exec; };
+    std::vector<SortGraph> sortGraphs; size_t sortGraphVictim = 0; bool sortGraphBroken = false;      // phase A of the neighbour rebuild (one per buffer set / position source: up to 4)
     // A rebuild (or a changed 1-4 list, box, dispersion table) changes kernel arguments, not the step's kernels: the executable graphs are kept
     // and refreshed with hipGraphExecUpdate from a new capture.  Instantiating the forked graph of an overlapped step anew costs the host
     // ~0.7 ms (a linear one 10 us), i.e. 0.3 ms of idle GPU after every rebuild; an update that fails falls back to a new instantiation.
@@ -345,6 +357,8 @@ public:
         if (c.stream) stream = (hipStream_t)c.stream; else { HIPCHECK(hipStreamCreate(&stream)); ownStream = true; }
         ring.resize(RING);
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0) numCUs = prop.multiProcessorCount; }
+        if (const char* e = getenv("SNB_SIDE_REBUILD")) sideMode = atoi(e) != 0;
+        if (const char* e = getenv("SNB_SIDE_LEAD")) sideLead = std::max(1, atoi(e));
         if (overlapMode) { dOverlap.resize(SNB_OVERLAP_INTS); HIPCHECK(hipMemsetAsync(dOverlap.p, 0, sizeof(int) * SNB_OVERLAP_INTS, stream)); }
         if (getenv("SNB_STEP_TRACE")) { dStepTrace.resize(16); HIPCHECK(hipMemsetAsync(dStepTrace.p, 0, sizeof(long long) * 16, stream)); }
         if (overlapMode && getenv("SNB_OVERLAP_DEBUG")) { dOverlapTrace.resize(SNB_CU_SLOTS * 8); HIPCHECK(hipMemsetAsync(dOverlapTrace.p, 0xff, sizeof(int) * SNB_CU_SLOTS * 8, stream)); }
@@ -384,6 +398,7 @@ public:
     }
     ~Engine() override {
         (void)hipStreamSynchronize(stream);
+        if (getenv("SNB_VERBOSE") && stats.n_rebuilds > 0) fprintf(stderr, "[snb] rebuilds: %lld, of them %lld built beside the steps; %lld side builds discarded\n", (long long)stats.n_rebuilds, sideBuilds, sideDiscarded);
         if (dStepTrace.p && getenv("SNB_STEP_TRACE")) {      // device wall clock (100 MHz) of the last replayed step, relative to the start of its gather pass
             long long t[16] = {0}; (void)hipMemcpy(t, dStepTrace.p, sizeof(t), hipMemcpyDeviceToHost);
             auto us = [&](int k) { return t[k] ? (t[k] - t[0]) / 100.0 : -1.0; };
@@ -397,7 +412,9 @@ public:
         }
         if (dPmeTrace.p) { long long h[4] = {0, 0, 0, 0}; (void)hipMemcpy(h, dPmeTrace.p, 32, hipMemcpyDeviceToHost); if (h[2] > 0) fprintf(stderr, "[snb] interpolation bricks: mean load %.2f us, mean compute %.2f us per work-group (%lld work-groups)\n", h[0] / 100.0 / h[2], h[1] / 100.0 / h[2], h[2]); }
         destroyGraphs();
-        if (sortGraphExec) { (void)hipGraphExecDestroy(sortGraphExec); sortGraphExec = nullptr; }
+        if (streamBuild) { (void)hipStreamSynchronize(streamBuild); (void)hipStreamDestroy(streamBuild); if (evSnap) (void)hipEventDestroy(evSnap); if (evBuilt) (void)hipEventDestroy(evBuilt); }
+        for (auto& g : sortGraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        sortGraphs.clear();
         for (auto& r : ring) { for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]); for (int k = 0; k < 16; k++) { (void)hipEventDestroy(r.ks.start[k]); (void)hipEventDestroy(r.ks.stop[k]); } }
         for (int k = 0; k < 3; k++) if (evRebuild[k]) (void)hipEventDestroy(evRebuild[k]);
         for (int k = 0; k < 2; k++) if (evStepDone[k]) (void)hipEventDestroy(evStepDone[k]);
@@ -1000,8 +1017,114 @@ public:
     // GPU neighbour build (neighbor.hip): rectangular periodic boxes with cutoff.  Returns false when the
     // host builder must take over (per-pair-wrap regime, gather-capacity overflow).
     // ------------------------------------------------------------------------------------------
+    // the totals of a build through mapped host memory: spins on the sequence number k_nbPublish writes last (falls back to a copy after 2 s)
+    void waitForTotals(int seq, int* h) {
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+        volatile int* pub = hNbPub;
+        while (pub[8] != seq && std::chrono::steady_clock::now() < deadline) { __builtin_ia32_pause(); }
+        if (pub[8] == seq) { for (int k = 0; k < 8; k++) h[k] = pub[k]; }
+        else { HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(int) * 8, hipMemcpyDeviceToHost, stream)); HIPCHECK(hipStreamSynchronize(stream)); }
+    }
+    // a build whose totals are in: host-side counts, the next prediction, statistics
+    void acceptBuild(const int* h, float sortMs) {
+        numTiles = h[0]; numWorkItems = h[1] + h[4]; numMaskTiles = h[2]; wrapMode = false;
+        if (getenv("SNB_DEBUG_WORK")) {      // consistency of the work list: the items must cover every tile exactly once
+            std::vector<int4> hw(numWorkItems);
+            HIPCHECK(hipMemcpy(hw.data(), workItems.p, sizeof(int4) * numWorkItems, hipMemcpyDeviceToHost));
+            long long sumZ = 0; int hist[9] = {0};
+            for (auto& w : hw) { sumZ += w.z; hist[std::min(std::max(w.z, 0), 8)]++; }
+            fprintf(stderr, "[snb] work list: %d items (%d full + %d partial), tiles %d, sum of item sizes %lld, sizes 1..8:", numWorkItems, h[1], h[4], (int)numTiles, sumZ);
+            for (int k = 1; k <= 8; k++) fprintf(stderr, " %d", hist[k]);
+            fprintf(stderr, "\n");
+        }
+        shardTiles = numTiles;      // the builder only emitted the blocks this engine owns
+        // next rebuild's array size: this count + 0.4 % + 8 blocks (c3: 300 k atoms move its count by a few blocks between rebuilds); never shrinking,
+        // so that the buffers -- and the step graph's arguments -- stay where they are
+        npadPredict = std::max(npadPredict, ((int)(h[7] * 1.004) + 256 + 31) / 32 * 32);
+        { static const int shortBy = getenv("SNB_NB_PREDICT_SHORT") ? atoi(getenv("SNB_NB_PREDICT_SHORT")) : 0;      // test switch: predict this many blocks too FEW (exercises the repeat path)
+          if (shortBy > 0) npadPredict = std::max(32, h[7] - 32 * shortBy); }
+        stats.n_rebuilds++;
+        float gpuMs = 0;   // device time of the build (the host clock would also count the queued steps this call waited for)
+        HIPCHECK(hipEventElapsedTime(&gpuMs, evRebuild[0], evRebuild[1]));
+        stats.last_rebuild_ms = gpuMs + sortMs;
+    }
+
+    // ---- the rebuild beside the steps ----
+    void swapListSets() {
+        auto sw = [](auto& a, auto& b) { std::swap(a.p, b.p); std::swap(a.n, b.n); };
+        sw(dUserToSorted, shadow.dUserToSorted); sw(dSortedToUser, shadow.dSortedToUser); sw(atomSubset, shadow.atomSubset); sw(atomGrid, shadow.atomGrid);
+        sw(blockSubset, shadow.blockSubset); sw(tileJ, shadow.tileJ); sw(colRange, shadow.colRange); sw(posq, shadow.posq); sw(posRef, shadow.posRef);
+        sw(sigeps, shadow.sigeps); sw(imageOffset, shadow.imageOffset); sw(tileInfo, shadow.tileInfo); sw(workItems, shadow.workItems); sw(masks, shadow.masks);
+    }
+    // whether the rebuild that falls due `sideLead` executes from now may be built beside the steps: a list built on the GPU with a predicted
+    // padded count is in use, nothing but the positions has changed since, fixed interval
+    bool sideBuildPossible() const {
+        return sideMode && !sidePending && gpuBuilt && cfg.rebuild_interval > sideLead + 1 && cfg.neighbor_padding > 0 && isPeriodic() && !cfg.host_neighbor_build && !cfg.disable_graph
+               && !needRebuild && !paramsDirty && !staticDirty && !valuesDirty && !excValuesDirty && npadPredict > 0 && npadPredict == Npad && hNbPub && dNbPub && devUserPos;
+    }
+    // Copies the positions aside (in stream order: the positions of the step just enqueued) and enqueues the whole build on streamBuild, into
+    // the shadow buffers.  Nothing the steps use is touched; the host does not wait.
+    void startSideBuild() {
+        if (!streamBuild) {
+            int lo = 0, hi = 0;
+            HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            // (normal priority: at the lowest the build crawls and the steps end up waiting for it, at the highest its kernels push the tile kernel aside)
+            HIPCHECK(hipStreamCreateWithPriority(&streamBuild, hipStreamNonBlocking, getenv("SNB_SIDE_PRIO_HIGH") ? hi : (getenv("SNB_SIDE_PRIO_LOW") ? lo : (lo + hi) / 2)));
+            HIPCHECK(hipEventCreateWithFlags(&evSnap, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&evBuilt, hipEventDisableTiming));
+        }
+        const size_t bytes = (size_t)N * (posStride4 ? 4 : 3) * (posIsDouble ? 8 : 4);
+        posSnap.resize(bytes);
+        HIPCHECK(hipMemcpyAsync(posSnap.p, devUserPos, bytes, hipMemcpyDeviceToDevice, stream));
+        HIPCHECK(hipEventRecord(evSnap, stream));
+        HIPCHECK(hipStreamWaitEvent(streamBuild, evSnap, 0));
+        const hipStream_t liveStream = stream; const void* livePos = devUserPos;
+        const int liveCells[2] = {colCells[0], colCells[1]};
+        swapListSets(); stream = streamBuild; devUserPos = posSnap.p; sideBuilding = true;
+        bool ok = false;
+        try {
+            ok = gpuRebuild();
+            if (ok) { posRef.resize(Npad); HIPCHECK(hipMemcpyAsync(posRef.p, posq.p, sizeof(T4) * (size_t)Npad, hipMemcpyDeviceToDevice, stream)); }
+            HIPCHECK(hipEventRecord(evBuilt, stream));
+        } catch (...) { sideBuilding = false; stream = liveStream; devUserPos = livePos; swapListSets(); colCells[0] = liveCells[0]; colCells[1] = liveCells[1]; throw; }
+        sideBuilding = false; stream = liveStream; devUserPos = livePos; swapListSets();
+        if (!ok) { colCells[0] = liveCells[0]; colCells[1] = liveCells[1]; HIPCHECK(hipEventSynchronize(evBuilt)); }      // (whatever was enqueued has finished with the scratch arrays)
+        sidePending = ok;
+    }
+    // drops a pending side build (its result will not be used): waits until it has finished with the scratch arrays
+    void cancelSideBuild() {
+        if (!sidePending) return;
+        HIPCHECK(hipEventSynchronize(evBuilt));
+        sidePending = false; sideDiscarded++;
+    }
+    // The rebuild has fallen due and a side build is pending: true = its list is now the one in use (nothing else to do); false = it failed
+    // (padded count or a partition over its capacity) and the caller rebuilds in line.
+    bool finishSideBuild() {
+        sidePending = false;
+        int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        waitForTotals(sideSeq, h);
+        HIPCHECK(hipEventSynchronize(evBuilt));      // (returns at once: the totals are the build's last kernel but one)
+        static const bool verbose = getenv("SNB_VERBOSE") != nullptr;
+        static const bool reject = getenv("SNB_SIDE_REJECT") != nullptr;      // test switch: every side build is discarded and the rebuild repeated in line
+        if (h[7] < N || (h[7] & 31) || h[7] > Npad || h[3] != 0 || reject) {
+            if (verbose) fprintf(stderr, "[snb] side rebuild discarded (padded count %d of %d, overflow flag %d): rebuilding in line\n", h[7], Npad, h[3]);
+            if (h[7] > Npad) { npadPredict = 0; padMispredictions++; }
+            sideDiscarded++;
+            return false;
+        }
+        HIPCHECK(hipStreamWaitEvent(stream, evBuilt, 0));      // stream order for the steps that follow
+        dropGraph();      // every kernel argument block changes
+        swapListSets();
+        acceptBuild(h, 0.f);
+        wrapMode = false; gpuBuilt = true; needRebuild = false; stepsSinceRebuild = 0;
+        if (hDispFlags[1]) listOverruns++;
+        hDispFlags[0] = hDispFlags[1] = 0;
+        sideBuilds++;
+        return true;
+    }
+
     bool gpuRebuild() {
         if (cfg.method == SNB_NoCutoff || N < 64) return false;
+        if (sideBuilding && !(npadPredict > 0 && npadPredict == Npad && getenv("SNB_NB_SYNC_PADDED") == nullptr)) return false;
         static const bool hostTriclinic = getenv("SNB_HOST_TRICLINIC") != nullptr;      // testing aid: old behaviour
         if (hostTriclinic && (!isPeriodic() || !(box[3] == 0 && box[6] == 0 && box[7] == 0))) return false;
         const double R = cfg.cutoff + cfg.neighbor_padding;
@@ -1081,8 +1204,9 @@ public:
             static const bool noSortGraph = getenv("SNB_NO_SORT_GRAPH") != nullptr;
             bool replayed = false;
             if (!noSortGraph && !sortGraphBroken && !cfg.disable_graph) {
-                if (!sortGraphExec || sortGraphKey.size() != sizeof(key) || std::memcmp(sortGraphKey.data(), &key, sizeof(key)) != 0) {
-                    if (sortGraphExec) { (void)hipGraphExecDestroy(sortGraphExec); sortGraphExec = nullptr; }
+                hipGraphExec_t sortGraphExec = nullptr;
+                for (auto& g : sortGraphs) if (g.key.size() == sizeof(key) && std::memcmp(g.key.data(), &key, sizeof(key)) == 0) sortGraphExec = g.exec;
+                if (!sortGraphExec) {
                     hipGraph_t graph = nullptr;
                     if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                         bool threw = false;
@@ -1091,7 +1215,9 @@ public:
                         hipError_t endErr = hipStreamEndCapture(stream, &graph);
                         if (threw) { endErr = hipErrorUnknown; (void)hipGetLastError(); }
                         if (endErr == hipSuccess && graph && hipGraphInstantiate(&sortGraphExec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                            sortGraphKey.assign(reinterpret_cast<const unsigned char*>(&key), reinterpret_cast<const unsigned char*>(&key) + sizeof(key));
+                            SortGraph g; g.key.assign(reinterpret_cast<const unsigned char*>(&key), reinterpret_cast<const unsigned char*>(&key) + sizeof(key)); g.exec = sortGraphExec;
+                            if (sortGraphs.size() < 4) sortGraphs.push_back(g);
+                            else { (void)hipGraphExecDestroy(sortGraphs[sortGraphVictim].exec); sortGraphs[sortGraphVictim] = g; sortGraphVictim = (sortGraphVictim + 1) % 4; }
                         } else { sortGraphExec = nullptr; sortGraphBroken = true; (void)hipGetLastError(); }
                         if (graph) (void)hipGraphDestroy(graph);
                     } else { sortGraphBroken = true; (void)hipGetLastError(); }
@@ -1143,6 +1269,11 @@ public:
             if (!predicted || attempt > 0) HIPCHECK(hipEventRecord(evRebuild[0], stream));
             launchNeighborBuild<Real>(p, stream);
             HIPCHECK(hipEventRecord(evRebuild[1], stream));
+            if (sideBuilding) {      // build beside the steps: publish the totals and leave; finishSideBuild reads them when the rebuild falls due
+                sideSeq = ++nbPubSeq;
+                launchNeighborPublish(dCounters.p, dNbPub, sideSeq, stream);
+                return true;
+            }
             int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             // the totals come back through mapped host memory and a sequence number the host spins on (a sleeping hipStreamSynchronize wakes
             // up 30-45 us after the kernel has ended, with the GPU idle); the synchronisation behind it then returns at once
@@ -1150,11 +1281,7 @@ public:
             if (hNbPub && dNbPub && !noSpin) {
                 const int seq = ++nbPubSeq;
                 launchNeighborPublish(dCounters.p, dNbPub, seq, stream);
-                const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
-                volatile int* pub = hNbPub;
-                while (pub[8] != seq && std::chrono::steady_clock::now() < deadline) { __builtin_ia32_pause(); }
-                if (pub[8] == seq) { for (int k = 0; k < 8; k++) h[k] = pub[k]; }
-                else { HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(h), hipMemcpyDeviceToHost, stream)); }
+                waitForTotals(seq, h);
                 HIPCHECK(hipStreamSynchronize(stream));      // (the events below are read next; nothing is running any more)
             } else {
                 HIPCHECK(hipMemcpyAsync(h, dCounters.p, sizeof(h), hipMemcpyDeviceToHost, stream));
@@ -1182,32 +1309,7 @@ public:
                 long long lastStart = 0; for (int b = 0; b < numBlocks; b++) lastStart = std::max(lastStart, tr[2 * b] - t0min);
                 fprintf(stderr, "[snb] nb trace: last block start %.1f us after the first\n", lastStart / 100.0);
             }
-            if (h[3] == 0) {
-                numTiles = h[0]; numWorkItems = h[1] + h[4]; numMaskTiles = h[2]; wrapMode = false;
-                if (getenv("SNB_DEBUG_WORK")) {      // consistency of the work list: the items must cover every tile exactly once
-                    std::vector<int4> hw(numWorkItems);
-                    HIPCHECK(hipMemcpy(hw.data(), workItems.p, sizeof(int4) * numWorkItems, hipMemcpyDeviceToHost));
-                    long long sumZ = 0; int hist[9] = {0};
-                    for (auto& w : hw) { sumZ += w.z; hist[std::min(std::max(w.z, 0), 8)]++; }
-                    fprintf(stderr, "[snb] work list: %d items (%d full + %d partial), tiles %d, sum of item sizes %lld, sizes 1..8:", numWorkItems, h[1], h[4], (int)numTiles, sumZ);
-                    for (int k = 1; k <= 8; k++) fprintf(stderr, " %d", hist[k]);
-                    fprintf(stderr, "\n");
-                }
-                shardTiles = numTiles;      // the builder only emitted the blocks this engine owns
-                // next rebuild's array size: this count + 0.4 % + 8 blocks (c3: 300 k atoms move its count by a few blocks between rebuilds); never shrinking,
-                // so that the buffers -- and the step graph's arguments -- stay where they are
-                npadPredict = std::max(npadPredict, ((int)(h[7] * 1.004) + 256 + 31) / 32 * 32);
-                { static const int shortBy = getenv("SNB_NB_PREDICT_SHORT") ? atoi(getenv("SNB_NB_PREDICT_SHORT")) : 0;      // test switch: predict this many blocks too FEW (exercises the repeat path)
-                  if (shortBy > 0) npadPredict = std::max(32, h[7] - 32 * shortBy); }
-                gpuBuilt = true;
-                needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0;
-                stats.n_rebuilds++;
-                float gpuMs = 0;   // device time of the build (the host clock would also count the queued steps this call waited for)
-                HIPCHECK(hipEventElapsedTime(&gpuMs, evRebuild[0], evRebuild[1]));
-                stats.last_rebuild_ms = gpuMs + sortMs;
-                (void)t0;
-                return true;
-            }
+            if (h[3] == 0) { acceptBuild(h, sortMs); gpuBuilt = true; needRebuild = false; paramsDirty = false; stepsSinceRebuild = 0; (void)t0; return true; }
             if (getenv("SNB_VERBOSE")) fprintf(stderr, "[snb] gpu neighbour build attempt %d: tiles %d work %d masks %d overflow %d partial %d maxPartTiles %d maxPartWork %d (cap %zu, region %zu / %zu)\n", attempt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], tileCap, tileCap / 64, (tileCap / 4 + 2 * numBlocks + 64) / 64);
             // capacity: a partition (1/64 of the arrays) ran out of tiles, masks or work items -> grow and retry
             if ((size_t)h[5] > tileCap / 64 || (size_t)h[6] > (tileCap / 4 + 2 * numBlocks + 64) / 64) { tileCap = std::max((size_t)h[5] * 64 * 5 / 4, tileCap * 3 / 2) + 4096; continue; }
@@ -1339,7 +1441,12 @@ public:
             if (ev) HIPCHECK(hipEventSynchronize(ev));
         }
         const bool due = autoMode ? (hDispFlags[0] != 0 || stepsSinceRebuild >= -cfg.rebuild_interval) : (cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval);
-        const bool rebuilding = needRebuild || paramsDirty || due || cfg.neighbor_padding <= 0;
+        bool rebuilding = needRebuild || paramsDirty || due || cfg.neighbor_padding <= 0;
+        if (sidePending) {
+            // anything but the positions changed since the side build started: its list is of no use
+            if (needRebuild || paramsDirty || staticDirty || valuesDirty || excValuesDirty || cfg.neighbor_padding <= 0) cancelSideBuild();
+            else if (rebuilding && finishSideBuild()) rebuilding = false;
+        }
         if ((valuesDirty || excValuesDirty) && !staticDirty && !rebuilding) refreshValues();
         if (rebuilding) { if (valuesDirty || excValuesDirty) { staticDirty = true; valuesDirty = excValuesDirty = false; } rebuild(); }
         stepsSinceRebuild++;
@@ -1362,7 +1469,7 @@ public:
         bool haveGraph = false;
         for (auto& g : graphs) if (g.key == stepKey && g.exec) haveGraph = true;
         static const bool eagerRebuildSteps = getenv("SNB_EAGER_REBUILD_STEP") != nullptr;      // test switch: the rebuild step as plain launches (rounds 1-3)
-        const bool eager = cfg.disable_graph || noStepGraph || (rebuilding && (!haveGraph || eagerRebuildSteps)) || (timingInterval > 0 && execCount++ % timingInterval == 0);
+        const bool eager = cfg.disable_graph || noStepGraph || (rebuilding && (!haveGraph || eagerRebuildSteps)) || (timingInterval > 0 && !sidePending && execCount++ % timingInterval == 0);      // (no timed step while a list is being built beside it: the kernel timers are for kernels running alone)
         if (eager) {
             EvSet& ev = ring[ringPos]; ringPos = (ringPos + 1) % RING;
             if (ev.pending) harvest(ev);
@@ -1422,6 +1529,8 @@ public:
             HIPCHECK(hipEventRecord(ev, stream));
         }
         stepCounter++;
+        // the rebuild that falls due sideLead executes from now starts here, beside the steps, from the positions of the step just enqueued
+        if (!autoMode && stepsSinceRebuild == cfg.rebuild_interval - sideLead && sideBuildPossible()) startSideBuild();
         if (energy) {
             energyPending = true;
             if (energyOut) { fetchSliceEnergies(); double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }      // (synchronises)

@@ -628,6 +628,7 @@ template <typename Real> __global__ __launch_bounds__(256) void k_nbCompactWork(
     const int4* src = (which ? p.workItemsPartial : p.workItemsStage) + (size_t)q * workRegion;
     int4* dst = p.workItems + (which ? s_off[0][NB_PARTS] : 0) + s_off[which][q];
     if (n > workRegion) return;      // overflowed partition: the host retries with larger regions
+    if ((size_t)(dst - p.workItems) + (size_t)n > (size_t)2 * p.workCapacity) return;      // (behind an overflowed partition the offsets are meaningless: nothing may be written past the array)
     for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 

@@ -1143,6 +1143,78 @@ print("RESULT " + json.dumps(dict(sha=h.hexdigest(), tiles=int(st.n_tiles), padd
 '''
 
 
+_SIDE_SCRIPT = r'''
+import sys, json
+import numpy as np, torch, importlib
+sys.path[:0] = [ROOT, ROOT + "/tests", ROOT + "/oracle"]
+import bench
+snb = importlib.import_module("openmm-nonbonded-slicing_amd")
+w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+n = len(w["q"])
+eng = bench.Engine(snb, w, 4, 54, 0, "mixed", 0, 0, 1, 0.1, 6)       # a rebuild every sixth step
+eng.set_timing_interval(0)
+rng = np.random.default_rng(11)
+pos = w["pos"].copy()
+forces = torch.full((n, 3), 7.0, dtype=torch.float32, device="cuda")
+pt = torch.tensor(pos, dtype=torch.float32, device="cuda")
+eng.set_force_output(forces.data_ptr(), False); eng.set_positions_device(pt.data_ptr(), False)
+worst = 0.0; worstE = 0.0
+for step in range(20):
+    pos = pos + rng.uniform(-0.004, 0.004, pos.shape)
+    pt.copy_(torch.tensor(pos, dtype=torch.float32))      # (the same buffer every step: the side build must have copied the positions it started from)
+    if step in (12, 19):
+        eng.execute(True, fetch=False)
+    else:
+        eng.execute(False)
+    eng.sync()
+    if step in (11, 12, 13, 18, 19):      # 12, 18: the steps at which a rebuild falls due; 11: the last step on an old list while the next is being built
+        w2 = dict(w); w2["pos"] = np.ascontiguousarray(pt.double().cpu().numpy())
+        fo, so, _, _ = bench.oracle_eval(w2, 4, 54, 0)
+        f = forces.double().cpu().numpy()
+        worst = max(worst, float(np.max(np.linalg.norm(f - fo, axis=1) / np.maximum(np.linalg.norm(fo, axis=1), 1.0))))
+        if step in (12, 19):
+            se = eng.slice_energies(10)
+            worstE = max(worstE, float(np.max(np.abs(se - so)) / np.max(np.abs(so))))
+st = eng.stats()
+print("RESULT " + json.dumps(dict(tiles=int(st.n_tiles), padded=int(st.n_padded_atoms), rebuilds=int(st.n_rebuilds), host_rebuilds=int(st.n_host_rebuilds), overruns=int(st.n_list_overruns), ferr=worst, eerr=worstE)))
+eng.close()
+'''
+
+
+def test_rebuild_beside_the_steps(snb):
+    """Round 4 (VERDICT r03 item 8): with a fixed rebuild interval the list for the next interval is built BESIDE the steps -- positions copied
+    aside three steps before the rebuild falls due, the whole GPU build on a stream of its own into a second set of list buffers, the sets
+    exchanged when it falls due (engine.hip startSideBuild / finishSideBuild; the reference rebuilds in line, in
+    `CommonCalcSlicedNonbondedForceKernel::execute` -> OpenMM `NonbondedUtilities::prepareInteractions`).  Child processes on the 24k workload,
+    a rebuild every sixth step, positions rewritten in the SAME device buffer every step: in line (SNB_SIDE_REBUILD=0), beside (default), beside
+    with a lead of one step, beside with every side build discarded (the in-line repeat), and beside under the overlapped step.  Forces against
+    the oracle on the last step of an old list, on the steps where the sets change places and on the steps after; slice energies on two
+    (one of them a step at which the sets change places)."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    cases = (("inline", {"SNB_SIDE_REBUILD": "0"}), ("beside", {}), ("lead1", {"SNB_SIDE_LEAD": "1"}), ("rejected", {"SNB_SIDE_REJECT": "1"}),
+             ("overlapped", {"SNB_OVERLAP": "1", "SNB_OVERLAP_MIN_TILES": "0"}))
+    for tag, env in cases:
+        e = dict(os.environ); e.update(env); e["SNB_VERBOSE"] = "1"
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _SIDE_SCRIPT], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+        m = re.search(r"rebuilds: (\d+), of them (\d+) built beside the steps; (\d+) side builds discarded", r.stderr)
+        assert m, r.stderr[-1500:]
+        got[tag]["side"], got[tag]["discarded"] = int(m.group(2)), int(m.group(3))
+        assert got[tag]["host_rebuilds"] == 0 and got[tag]["overruns"] == 0 and got[tag]["ferr"] < 1e-3 and got[tag]["eerr"] < 1e-3, (tag, got[tag])
+        assert got[tag]["rebuilds"] == 4, (tag, got[tag])      # steps 0, 6, 12, 18
+    assert got["inline"]["side"] == 0 and got["inline"]["discarded"] == 0, got
+    for tag in ("beside", "lead1", "overlapped"):
+        assert got[tag]["side"] == 2 and got[tag]["discarded"] == 0, (tag, got[tag])      # (the first two rebuilds fix the padded size; 12 and 18 are built beside)
+    assert got["rejected"]["side"] == 0 and got["rejected"]["discarded"] == 2, got
+
+
 def test_predicted_padded_count_and_its_repeat_path(snb):
     """Round 4: from the second rebuild on the GPU neighbour build sizes the padded arrays from the previous rebuild's count plus a margin and
     does not wait for this rebuild's count (engine.hip gpuRebuild; the reference's counterpart is OpenMM's findBlocksWithInteractions, which
