@@ -643,6 +643,8 @@ def main():
                    # replayed steps run the PME chain beside a CU-limited resident launch of the pair kernel (engine.hip overlapMode; the eager stamped
                    # steps behind `roofline` stay serial, so every kernel is still timed alone): the engine's own rule, restated
                    "overlap": os.environ.get("SNB_OVERLAP", "1") != "0" and T >= int(os.environ.get("SNB_OVERLAP_MIN_TILES", "100000")),
+                   # the list of the next interval is built on a stream of its own while the last steps of this one run (engine.hip startSideBuild): restated rule
+                   "rebuild_beside_steps": os.environ.get("SNB_SIDE_REBUILD", "1") != "0" and args.rebuild_interval > int(os.environ.get("SNB_SIDE_LEAD", "3")) + 1 and args.padding > 0,
                    "parallelism": ("subset-grid + i-block sharding x%d, RCCL all-reduce of forces" % world) if world > 1 else "1 GPU"},
         "roofline": roof,
         "roofline_other_step": roof_plain if headline_deriv else roof_deriv,
