@@ -3,7 +3,7 @@
 # HBM-side traffic of every kernel of the bench step, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in
 # SEPARATE --pmc passes (they do not fit one pass), only --kernel-trace beside them.  Summary -> gpurun_out/<tag>_hbm.json
 tag=$1; shift
-export SNB_OVERLAP=0      # kernels alone: one pair-kernel launch per step, counters per launch = per step
+export SNB_OVERLAP=0 SNB_SIDE_REBUILD=0      # kernels alone: one pair-kernel launch per step, counters per launch = per step
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_$c -- python3 bench.py --no-cpu-baseline --no-double "$@" > gpurun_out/${tag}_$c.log 2>&1 || exit 1
