@@ -264,7 +264,8 @@ public:
         DevBuf<int> dUserToSorted, dSortedToUser, atomSubset, atomGrid, blockSubset, tileJ; DevBuf<int2> colRange; DevBuf<T4> posq, posRef; DevBuf<T2> sigeps;
         DevBuf<Real> imageOffset; DevBuf<int4> tileInfo, workItems; DevBuf<unsigned> masks;
     } shadow;
-    hipStream_t streamBuild = nullptr; hipEvent_t evSnap = nullptr, evBuilt = nullptr; DevBuf<unsigned char> posSnap;
+    hipStream_t streamBuild = nullptr; hipEvent_t evSnap = nullptr, evBuilt = nullptr, evFlagsReset = nullptr; bool flagsResetPending = false; DevBuf<unsigned char> posSnap;
+    int autoPredict = 0;      // displacement-triggered rebuilds: the interval the next side build is timed for (0: none yet), see execute()
     bool sideMode = true, sideBuilding = false, sidePending = false; int sideLead = 3, sideSeq = 0; long long sideBuilds = 0, sideDiscarded = 0;
     int npadPredict = 0; long long padMispredictions = 0;      // > 0: size of the padded arrays the next GPU rebuild assumes (gpuRebuild); how often that was too small
     int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0, shardTiles = 0; bool wrapMode = false;
@@ -375,7 +376,7 @@ public:
         // analytic erfc is already cheap) and leaves the kernel time unchanged, so the analytic form stays the default.
         if (cfg.method >= SNB_Ewald) buildEwaldPoly();
         HIPCHECK(hipHostMalloc((void**)&hDispFlags, 64, hipHostMallocMapped));
-        hDispFlags[0] = hDispFlags[1] = 0;
+        std::memset(hDispFlags, 0, 64);      // [0] warn, [1] overrun, [4] overruns counted on the device (k_dispFlagsReset)
         HIPCHECK(hipHostGetDevicePointer((void**)&dDispFlags, hDispFlags, 0));
         HIPCHECK(hipHostMalloc((void**)&hNbPub, 64, hipHostMallocMapped));
         std::memset(hNbPub, 0, 64);
@@ -412,7 +413,7 @@ public:
         }
         if (dPmeTrace.p) { long long h[4] = {0, 0, 0, 0}; (void)hipMemcpy(h, dPmeTrace.p, 32, hipMemcpyDeviceToHost); if (h[2] > 0) fprintf(stderr, "[snb] interpolation bricks: mean load %.2f us, mean compute %.2f us per work-group (%lld work-groups)\n", h[0] / 100.0 / h[2], h[1] / 100.0 / h[2], h[2]); }
         destroyGraphs();
-        if (streamBuild) { (void)hipStreamSynchronize(streamBuild); (void)hipStreamDestroy(streamBuild); if (evSnap) (void)hipEventDestroy(evSnap); if (evBuilt) (void)hipEventDestroy(evBuilt); }
+        if (streamBuild) { (void)hipStreamSynchronize(streamBuild); (void)hipStreamDestroy(streamBuild); if (evSnap) (void)hipEventDestroy(evSnap); if (evBuilt) (void)hipEventDestroy(evBuilt); if (evFlagsReset) (void)hipEventDestroy(evFlagsReset); }
         for (auto& g : sortGraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
         sortGraphs.clear();
         for (auto& r : ring) { for (int k = 0; k < 5; k++) (void)hipEventDestroy(r.e[k]); for (int k = 0; k < 16; k++) { (void)hipEventDestroy(r.ks.start[k]); (void)hipEventDestroy(r.ks.stop[k]); } }
@@ -598,6 +599,7 @@ public:
         HIPCHECK(hipMemcpyAsync(posRef.p, posq.p, sizeof(T4) * (size_t)Npad, hipMemcpyDeviceToDevice, stream));
         if (hDispFlags[1]) listOverruns++;      // an atom had moved more than skin/2 before this rebuild came
         hDispFlags[0] = hDispFlags[1] = 0;
+        flagsResetPending = false;      // (the queue has been drained: a reset enqueued at an earlier exchange has run)
     }
 
     void hostRebuild() {
@@ -1057,9 +1059,10 @@ public:
         sw(sigeps, shadow.sigeps); sw(imageOffset, shadow.imageOffset); sw(tileInfo, shadow.tileInfo); sw(workItems, shadow.workItems); sw(masks, shadow.masks);
     }
     // whether the rebuild that falls due `sideLead` executes from now may be built beside the steps: a list built on the GPU with a predicted
-    // padded count is in use, nothing but the positions has changed since, fixed interval
+    // padded count is in use, nothing but the positions has changed since; a fixed interval, or displacement-triggered rebuilds that come
+    // at least 4 * sideLead steps apart (a side-built list comes into use sideLead steps old: a quarter of its life at most)
     bool sideBuildPossible() const {
-        return sideMode && !sidePending && gpuBuilt && cfg.rebuild_interval > sideLead + 1 && cfg.neighbor_padding > 0 && isPeriodic() && !cfg.host_neighbor_build && !cfg.disable_graph
+        return sideMode && !sidePending && gpuBuilt && (cfg.rebuild_interval < 0 ? autoPredict >= 4 * sideLead : cfg.rebuild_interval > sideLead + 1) && cfg.neighbor_padding > 0 && isPeriodic() && !cfg.host_neighbor_build && !cfg.disable_graph
                && !needRebuild && !paramsDirty && !staticDirty && !valuesDirty && !excValuesDirty && npadPredict > 0 && npadPredict == Npad && hNbPub && dNbPub && devUserPos;
     }
     // Copies the positions aside (in stream order: the positions of the step just enqueued) and enqueues the whole build on streamBuild, into
@@ -1070,7 +1073,7 @@ public:
             HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
             // (normal priority: at the lowest the build crawls and the steps end up waiting for it, at the highest its kernels push the tile kernel aside)
             HIPCHECK(hipStreamCreateWithPriority(&streamBuild, hipStreamNonBlocking, getenv("SNB_SIDE_PRIO_HIGH") ? hi : (getenv("SNB_SIDE_PRIO_LOW") ? lo : (lo + hi) / 2)));
-            HIPCHECK(hipEventCreateWithFlags(&evSnap, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&evBuilt, hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&evSnap, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&evBuilt, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&evFlagsReset, hipEventDisableTiming));
         }
         const size_t bytes = (size_t)N * (posStride4 ? 4 : 3) * (posIsDouble ? 8 : 4);
         posSnap.resize(bytes);
@@ -1116,8 +1119,8 @@ public:
         swapListSets();
         acceptBuild(h, 0.f);
         wrapMode = false; gpuBuilt = true; needRebuild = false; stepsSinceRebuild = 0;
-        if (hDispFlags[1]) listOverruns++;
-        hDispFlags[0] = hDispFlags[1] = 0;
+        launchDispFlagsReset(dDispFlags, stream);      // (in stream order: steps on the old list may still be queued, and their flags belong to it)
+        HIPCHECK(hipEventRecord(evFlagsReset, stream)); flagsResetPending = true;      // (until then the host copy still shows the old list's flags)
         sideBuilds++;
         return true;
     }
@@ -1440,8 +1443,20 @@ public:
             hipEvent_t& ev = evStepDone[stepCounter & 1];
             if (ev) HIPCHECK(hipEventSynchronize(ev));
         }
-        const bool due = autoMode ? (hDispFlags[0] != 0 || stepsSinceRebuild >= -cfg.rebuild_interval) : (cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval);
-        bool rebuilding = needRebuild || paramsDirty || due || cfg.neighbor_padding <= 0;
+        if (flagsResetPending && hipEventQuery(evFlagsReset) == hipSuccess) flagsResetPending = false;
+        const bool due = autoMode ? ((hDispFlags[0] != 0 && !flagsResetPending) || stepsSinceRebuild >= -cfg.rebuild_interval) : (cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval);
+        // Displacement-triggered rebuilds have no schedule to start a side build from, so the engine keeps a guess: one step less than the
+        // last interval the watch ended by itself (autoPredict), one more each time its guess was not contradicted.  The side build starts
+        // sideLead steps before the guess; its list comes into use at the guess -- or earlier, when the watch asks for a rebuild meanwhile
+        // (the list is then a few steps old, as with a fixed interval).  A watch that fires before a side build was started rebuilds in line.
+        const bool speculative = autoMode && sidePending && !due && stepsSinceRebuild >= autoPredict;
+        if (autoMode && (due || speculative) && !needRebuild && !paramsDirty) {
+            static const bool verbose = getenv("SNB_VERBOSE") != nullptr;
+            const int was = autoPredict;
+            autoPredict = due ? std::max(stepsSinceRebuild - 1, 0) : std::min(autoPredict + 1, -cfg.rebuild_interval);
+            if (verbose) fprintf(stderr, "[snb] automatic rebuild after %d steps (%s); next side build timed for %d (was %d)\n", stepsSinceRebuild, due ? "the watch" : "the guess", autoPredict, was);
+        }
+        bool rebuilding = needRebuild || paramsDirty || due || speculative || cfg.neighbor_padding <= 0;
         if (sidePending) {
             // anything but the positions changed since the side build started: its list is of no use
             if (needRebuild || paramsDirty || staticDirty || valuesDirty || excValuesDirty || cfg.neighbor_padding <= 0) cancelSideBuild();
@@ -1530,7 +1545,7 @@ public:
         }
         stepCounter++;
         // the rebuild that falls due sideLead executes from now starts here, beside the steps, from the positions of the step just enqueued
-        if (!autoMode && stepsSinceRebuild == cfg.rebuild_interval - sideLead && sideBuildPossible()) startSideBuild();
+        if (stepsSinceRebuild == (autoMode ? autoPredict : cfg.rebuild_interval) - sideLead && sideBuildPossible()) startSideBuild();
         if (energy) {
             energyPending = true;
             if (energyOut) { fetchSliceEnergies(); double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }      // (synchronises)
@@ -1813,7 +1828,7 @@ public:
         HIPCHECK(hipStreamSynchronize(stream));
         stats.n_tiles = 0;
         // tiles processed by this shard
-        stats.n_list_overruns = listOverruns + (hDispFlags && hDispFlags[1] ? 1 : 0);
+        stats.n_list_overruns = listOverruns + (hDispFlags ? hDispFlags[4] + (hDispFlags[1] ? 1 : 0) : 0);
         stats.n_tiles = shardTiles; stats.n_blocks = numBlocks; stats.n_padded_atoms = Npad; stats.n_exclusion_tiles = numMaskTiles;
         for (int d = 0; d < 3; d++) { stats.grid[d] = isPme() ? pme.d.nx * (d == 0) + pme.d.ny * (d == 1) + pme.d.nz * (d == 2) : 0; stats.dgrid[d] = cfg.method == SNB_LJPME ? dpme.d.nx * (d == 0) + dpme.d.ny * (d == 1) + dpme.d.nz * (d == 2) : 0; }
         for (int k = 0; k < RING; k++) { EvSet& r = ring[(ringPos + k) % RING]; if (r.pending) harvest(r); }

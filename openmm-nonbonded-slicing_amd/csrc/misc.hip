@@ -262,6 +262,14 @@ void launchFinishSliceEnergies(const double* parts, double* out, int n, const Sl
     if (n > 0) hipLaunchKernelGGL(k_finishSliceEnergies, dim3((n + 63) / 64), dim3(64), 0, s, parts, out, n, f);
 }
 
+// The displacement watch's flags (mapped host memory) cleared IN STREAM ORDER -- behind every step that used the old list, in front of the
+// first one on the new list (a list exchanged without draining the queue: engine.hip finishSideBuild); an overrun seen by a step that was
+// still queued when the host exchanged the lists is counted in flags[4] instead of being lost.
+__global__ void k_dispFlagsReset(volatile int* flags) {
+    if (threadIdx.x == 0) { if (flags[1]) flags[4] = flags[4] + 1; flags[0] = 0; flags[1] = 0; __threadfence_system(); }
+}
+void launchDispFlagsReset(int* flags, hipStream_t s) { hipLaunchKernelGGL(k_dispFlagsReset, dim3(1), dim3(64), 0, s, (volatile int*)flags); }
+
 template void launchGatherPositions<float>(const void*, int, int, const int*, const float*, Vec<float>::T4*, int, float*, int, const GatherCells<float>&, hipStream_t);
 template void launchGatherPositions<double>(const void*, int, int, const int*, const double*, Vec<double>::T4*, int, double*, int, const GatherCells<double>&, hipStream_t);
 template void launchFinishForces<float>(const float*, const float*, const float*, int, int, const float*, const float*, const float*, const int*, int, void*, int, int, hipStream_t);

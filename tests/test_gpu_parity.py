@@ -1215,6 +1215,64 @@ def test_rebuild_beside_the_steps(snb):
     assert got["rejected"]["side"] == 0 and got["rejected"]["discarded"] == 2, got
 
 
+_SIDE_AUTO_SCRIPT = r'''
+import sys, json
+import numpy as np, torch, importlib
+sys.path[:0] = [ROOT, ROOT + "/tests", ROOT + "/oracle"]
+import bench
+snb = importlib.import_module("openmm-nonbonded-slicing_amd")
+w = bench.build_workload(24000, 6.2145, 4, np.random.default_rng(bench.SEED))
+n = len(w["q"])
+auto = bench.Engine(snb, w, 4, 54, 0, "single", 0, 0, 1, 0.1, -200)
+ref = bench.Engine(snb, w, 4, 54, 0, "single", 0, 0, 1, 0.1, 1)
+auto.set_timing_interval(0)
+pos = torch.tensor(w["pos"], dtype=torch.float32, device="cuda")
+fa = torch.zeros((n, 3), dtype=torch.float32, device="cuda"); fr = torch.zeros_like(fa)
+auto.set_force_output(fa.data_ptr(), False); ref.set_force_output(fr.data_ptr(), False)
+auto.set_positions_device(pos.data_ptr(), False); ref.set_positions_device(pos.data_ptr(), False)
+g = torch.Generator(device="cuda"); g.manual_seed(9)
+worst = 0.0
+for step in range(160):
+    auto.execute(False); ref.execute(False); auto.sync(); ref.sync()
+    a, b = fr.double().cpu().numpy(), fa.double().cpu().numpy()
+    worst = max(worst, float((np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(a, axis=1), 1.0)).max()))
+    pos.add_(torch.randn(pos.shape, generator=g, device="cuda") * 0.002)      # (in place: the engines keep reading the same buffer)
+st = auto.stats()
+print("RESULT " + json.dumps(dict(rebuilds=int(st.n_rebuilds), host_rebuilds=int(st.n_host_rebuilds), overruns=int(st.n_list_overruns), ferr=worst)))
+auto.close(); ref.close()
+'''
+
+
+def test_side_builds_with_displacement_triggered_rebuilds(snb):
+    """rebuild_interval < 0 (what the plugin adapter of INTEGRATION.md uses): once the displacement watch's rebuilds come at least 12 steps
+    apart the engine times a side build for one step less than the last interval the watch ended by itself, and brings its list into use at
+    that guess, or when the watch fires meanwhile (engine.hip execute, autoPredict).  A random walk of 160 steps: every step against an
+    engine that rebuilds every step, no overrun, side builds in use; with SNB_SIDE_REBUILD=0 the same walk rebuilds in line at the watch's
+    own pace."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for tag, env in (("inline", {"SNB_SIDE_REBUILD": "0"}), ("beside", {})):
+        e = dict(os.environ); e.update(env); e["SNB_VERBOSE"] = "1"
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _SIDE_AUTO_SCRIPT], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+        m = re.findall(r"rebuilds: (\d+), of them (\d+) built beside the steps; (\d+) side builds discarded", r.stderr)
+        sides = [int(x[1]) for x in m if int(x[0]) < 150]      # (the reference engine rebuilds 160 times, in line)
+        assert len(sides) == 1, r.stderr[-1500:]
+        got[tag]["side"] = sides[0]
+        got[tag]["by_watch"] = len(re.findall(r"automatic rebuild after \d+ steps \(the watch\)", r.stderr))
+        got[tag]["by_guess"] = len(re.findall(r"automatic rebuild after \d+ steps \(the guess\)", r.stderr))
+        assert got[tag]["host_rebuilds"] == 0 and got[tag]["overruns"] == 0 and got[tag]["ferr"] < 2e-3, (tag, got[tag])
+    assert got["inline"]["side"] == 0 and got["inline"]["by_guess"] == 0 and got["inline"]["rebuilds"] >= 4, got
+    assert got["beside"]["side"] >= 2 and got["beside"]["by_guess"] >= 1, got
+    assert got["beside"]["rebuilds"] <= 2 * got["inline"]["rebuilds"], got      # (the guess costs a few extra rebuilds, not a different regime)
+
+
 def test_predicted_padded_count_and_its_repeat_path(snb):
     """Round 4: from the second rebuild on the GPU neighbour build sizes the padded arrays from the previous rebuild's count plus a margin and
     does not wait for this rebuild's count (engine.hip gpuRebuild; the reference's counterpart is OpenMM's findBlocksWithInteractions, which
