@@ -1650,7 +1650,7 @@ public:
             q.pairs = pairs14.p; q.params = params14.p; q.n = n14;
             q.nExclAtoms = (ew && nExcl > 0) ? Npad : 0;
         }
-        bool listsDone = !haveLists, kernelTimed = false, finished = false;
+        bool listsDone = !haveLists, kernelTimed = false, finished = false, energyFinished = false;
         DirectParams<Real> directB; int directMc = 0;      // overlapped step: the second launch of the tile kernel
         std::memset(&directB, 0, sizeof(directB));
         if (includeDirect) {
@@ -1709,8 +1709,11 @@ public:
                 static const bool noFuse = getenv("SNB_NO_FUSED_FINISH") != nullptr;
                 // (an overlapped step keeps the fused finish: its last interpolation waits for both launches of the tile kernel)
                 const bool canFinish = outPtr && (!fork || overlap) && !noFuse && cfg.shard_count == 1;
+                static const bool noFusedE = getenv("SNB_NO_FUSED_ENERGY_FINISH") != nullptr;      // test switch: k_finishSliceEnergies as a kernel of its own
                 auto withOutput = [&](PmeParams<Real>& q, bool last) {
                     q.outForces = (canFinish && last) ? outPtr : nullptr; q.outIsDouble = outIsDouble; q.outAccumulate = outAccumulate;
+                    q.finOut = nullptr;
+                    if (canFinish && last && energy && q.mix && !noFusedE) { q.finParts = sliceE.p; q.finOut = sliceTotal.p; q.finN = 2 * S; q.fin = makeSliceFinish(includeDirect, includeRecip); }
                     q.dfx = fx.p; q.dfy = fy.p; q.dfz = fz.p; q.dfs = fstride; q.dfixed = fixedForces(); q.sortedToUser = dSortedToUser.p;
                 };
                 // Overlapped step: everything up to the last mesh's inverse transform runs beside the resident first launch of the tile kernel;
@@ -1727,11 +1730,13 @@ public:
                 runPmeFront(pp, pmeStream);
                 if (cfg.method != SNB_LJPME) beforeLastInterpolation();
                 finished = launchPmeInterpolate<Real>(pp, pmeStream);
+                energyFinished = finished && pp.finOut != nullptr;
                 if (cfg.method == SNB_LJPME) {
                     fillPme(pp, dpme, energy); withOutput(pp, true);
                     runPmeFront(pp, pmeStream);
                     beforeLastInterpolation();
                     finished = launchPmeInterpolate<Real>(pp, pmeStream);
+                    energyFinished = finished && pp.finOut != nullptr;
                 }
             }
         }
@@ -1742,22 +1747,28 @@ public:
             launchFinishForces<Real>(fx.p, fy.p, fz.p, fstride, fixedForces(), recipDone ? fpx.p : nullptr, fpy.p, fpz.p, dUserToSorted.p, N, outPtr, outIsDouble, outAccumulate, stream);
         }
         if (energy) {
-            // closed-form terms on the device (rank 0 only when sharded), as the reference GPU path keeps them next to its kernels
-            // (CommonNonbondedSlicingKernels.cpp:618-638, 1129-1139)
-            SliceFinish f; std::memset(&f, 0, sizeof(f));
-            if (cfg.shard_rank == 0) {
-                const double volume = box[0] * box[4] * box[8];
-                if (includeRecip && cfg.method >= SNB_Ewald) {
-                    f.sums = dParamSums.p;
-                    f.selfCoulomb = -SNB_ONE_4PI_EPS0 * cfg.alpha / std::sqrt(SNB_PI);
-                    f.selfDispersion = cfg.method == SNB_LJPME ? std::pow(cfg.alpha_d, 6.0) / 12.0 : 0.0;
-                    f.background = (-1.0 / (4 * cfg.alpha * cfg.alpha)) / (2 * SNB_EPSILON0 * volume);
-                }
-                if (includeDirect && (cfg.method == SNB_CutoffPeriodic || cfg.method == SNB_Ewald || cfg.method == SNB_PME)) { f.dispCoef = dDispCoef.p; f.invVolume = 1.0 / volume; }
-            }
+            const SliceFinish f = makeSliceFinish(includeDirect, includeRecip);
+            if (!(finished && energyFinished))
             launchFinishSliceEnergies(sliceE.p, sliceTotal.p, 2 * S, f, stream);
         }
         if (ev) HIPCHECK(hipEventRecord(ev->e[4], stream));
+    }
+
+    // closed-form terms of the slice energies, added on the device (rank 0 only when sharded), as the reference GPU path keeps them next to its
+    // kernels (CommonNonbondedSlicingKernels.cpp:618-638, 1129-1139)
+    SliceFinish makeSliceFinish(bool includeDirect, bool includeRecip) const {
+        SliceFinish f; std::memset(&f, 0, sizeof(f));
+        if (cfg.shard_rank == 0) {
+            const double volume = box[0] * box[4] * box[8];
+            if (includeRecip && cfg.method >= SNB_Ewald) {
+                f.sums = dParamSums.p;
+                f.selfCoulomb = -SNB_ONE_4PI_EPS0 * cfg.alpha / std::sqrt(SNB_PI);
+                f.selfDispersion = cfg.method == SNB_LJPME ? std::pow(cfg.alpha_d, 6.0) / 12.0 : 0.0;
+                f.background = (-1.0 / (4 * cfg.alpha * cfg.alpha)) / (2 * SNB_EPSILON0 * volume);
+            }
+            if (includeDirect && (cfg.method == SNB_CutoffPeriodic || cfg.method == SNB_Ewald || cfg.method == SNB_PME)) { f.dispCoef = dDispCoef.p; f.invVolume = 1.0 / volume; }
+        }
+        return f;
     }
 
     // classic Ewald: half-space k-vectors in the reference's enumeration order (ReferenceSlicedLJCoulombIxn.cpp:288-355)

@@ -245,17 +245,7 @@ __global__ void k_finishSliceEnergies(const double* __restrict__ parts, double* 
     if (i >= n) return;
     double acc = 0;
     for (int part = 0; part < SNB_SLICE_E_PARTS; part++) acc += parts[(size_t)part * n + i];
-    const int slice = i >> 1, term = i & 1;
-    int a = 0;
-    while ((a + 1) * (a + 2) / 2 <= slice) a++;      // slice = a (a + 1) / 2 + b, b <= a
-    const int b = slice - a * (a + 1) / 2;
-    if (f.sums) {
-        if (term == 0) {
-            if (a == b) acc += f.selfCoulomb * f.sums[3 * a + 1];
-            acc += (a == b ? 1.0 : 2.0) * f.sums[3 * a] * f.sums[3 * b] * f.background;
-        } else if (a == b) acc += f.selfDispersion * f.sums[3 * a + 2];
-    }
-    if (term == 1 && f.dispCoef) acc += f.dispCoef[slice] * f.invVolume;
+    acc += sliceFinishClosedForm(f, i);
     out[i] = acc;
 }
 void launchFinishSliceEnergies(const double* parts, double* out, int n, const SliceFinish& f, hipStream_t s) {

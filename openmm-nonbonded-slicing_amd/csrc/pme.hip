@@ -2082,6 +2082,20 @@ template <typename Real, int NT> __global__ __launch_bounds__(NT) void k_interpo
     const int x0 = Bx * cx, y0 = By * cy;
     const int bx = cx + EXTRA, by = cy + EXTRA;
     const int tid = threadIdx.x;
+    // energy / derivative steps whose last kernel this is: the last work-group also sums the 64 partitions of the raw slice energies and adds
+    // the closed-form terms (k_finishSliceEnergies, ~4 us + a launch gap as a kernel of its own).  Every contribution is complete by now: the
+    // tile kernel's launches and the pair lists precede this kernel, the reciprocal sums were made by the plane / x kernels, and an
+    // unsharded interpolation adds none.  One wave per entry, one lane per partition.
+    if (p.finOut != nullptr && blockIdx.x == gridDim.x - 1) {
+        const int lane = tid & 63;
+        for (int i = tid >> 6; i < p.finN; i += NT / 64) {
+            double acc = 0;
+            for (int part = lane; part < SNB_SLICE_E_PARTS; part += 64) acc += p.finParts[(size_t)part * p.finN + i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (lane == 0) p.finOut[i] = acc + sliceFinishClosedForm(p.fin, i);
+        }
+    }
     Real* brick = reinterpret_cast<Real*>(s_brick_raw);
     double* sE = reinterpret_cast<double*>(s_brick_raw + ((sizeof(Real) * (size_t)bx * by * bz + 15) & ~(size_t)15));   // [2*S] on energy steps
     const bool wantE = p.wantEnergy != 0 && !p.mix;            // unsharded energies come from the k-space Gram sums (k_convolveX)

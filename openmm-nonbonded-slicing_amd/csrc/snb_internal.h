@@ -136,6 +136,30 @@ extern thread_local KernelStamps* g_stamps;
         if (ks_ && slot_ >= 0 && slot_ < 16 && ks_->start[slot_] && !ks_->used[slot_]) { ks_->used[slot_] = true; hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ks_->start[slot_], ks_->stop[slot_], 0, __VA_ARGS__); } \
         else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__); } while (0)
 
+struct SliceFinish {
+    const double* sums;       // [3 nsub] per-subset sum q, sum q^2, sum c6^2 (k_paramSums), or null
+    const double* dispCoef;   // [S] dispersion-correction coefficients, or null
+    double selfCoulomb;       // -ONE_4PI_EPS0 alpha / sqrt(pi)          (x sum q^2, diagonal slices)
+    double selfDispersion;    // alpha_d^6 / 12                           (x sum c6^2, LJPME)
+    double background;        // -1 / (4 alpha^2) / (2 eps0 V)            (x Q_a Q_b, x 2 off the diagonal)
+    double invVolume;         // 1 / V                                    (x dispersion coefficient)
+};
+// closed-form terms of raw slice-energy entry i = 2 * slice + term (term 0: Coulomb, 1: dispersion), added to the sum of its partitions
+__device__ inline double sliceFinishClosedForm(const SliceFinish& f, int i) {
+    const int slice = i >> 1, term = i & 1;
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= slice) a++;      // slice = a (a + 1) / 2 + b, b <= a
+    const int b = slice - a * (a + 1) / 2;
+    double acc = 0;
+    if (f.sums) {
+        if (term == 0) {
+            if (a == b) acc += f.selfCoulomb * f.sums[3 * a + 1];
+            acc += (a == b ? 1.0 : 2.0) * f.sums[3 * a] * f.sums[3 * b] * f.background;
+        } else if (a == b) acc += f.selfDispersion * f.sums[3 * a + 2];
+    }
+    if (term == 1 && f.dispCoef) acc += f.dispCoef[slice] * f.invVolume;
+    return acc;
+}
 template <typename Real> struct PmeParams {
     PmePlanDims d;
     int nsub;                 // grids held (all subsets, or this shard's)
@@ -183,6 +207,7 @@ template <typename Real> struct PmeParams {
     // brick interpolation of the step's LAST mesh, unsharded: the atom's thread also writes the step's user-order force,
     // direct-space accumulator + reciprocal force, into the caller's buffer (what k_finishForces does as a launch of its own)
     void* outForces; int outIsDouble, outAccumulate;      // [N][3] in the caller's type, or null
+    const double* finParts; double* finOut; int finN; SliceFinish fin;      // finOut != null: one work-group of the interpolation also sums the slice-energy partitions (the fused k_finishSliceEnergies)
     const Real* dfx; const Real* dfy; const Real* dfz; int dfs, dfixed;   // direct-space accumulators (component bases, atom stride, 64-bit fixed point)
     const int* sortedToUser;
 };
@@ -314,14 +339,6 @@ template <typename Real> void launchFinishForces(const Real* fx, const Real* fy,
                                                  const int* userToSorted, int nAtoms, void* out, int isDouble, int accumulate, hipStream_t s);
 
 // closed-form terms of the raw slice energies (k_finishSliceEnergies); a null pointer / zero factor switches a term off
-struct SliceFinish {
-    const double* sums;       // [3 nsub] per-subset sum q, sum q^2, sum c6^2 (k_paramSums), or null
-    const double* dispCoef;   // [S] dispersion-correction coefficients, or null
-    double selfCoulomb;       // -ONE_4PI_EPS0 alpha / sqrt(pi)          (x sum q^2, diagonal slices)
-    double selfDispersion;    // alpha_d^6 / 12                           (x sum c6^2, LJPME)
-    double background;        // -1 / (4 alpha^2) / (2 eps0 V)            (x Q_a Q_b, x 2 off the diagonal)
-    double invVolume;         // 1 / V                                    (x dispersion coefficient)
-};
 void launchFinishSliceEnergies(const double* parts, double* out, int n, const SliceFinish& f, hipStream_t s);
 #define SNB_PARAM_SUM_ROWS 256      // work-groups of k_paramSums, each leaving one row of partial sums
 template <typename Real>
