@@ -502,9 +502,11 @@ template <typename Real> __global__ __launch_bounds__(256, 4) void k_nbBuildTile
                     int k = 0;     // last run whose exclusive prefix is <= v (empty runs are never queued)
 #pragma unroll
                     for (int st = 32; st > 0; st >>= 1) if (k + st < 64 && cmbPrefix[k + st] <= v) k += st;
-                    j = cmbStart[k] + (v - cmbPrefix[k]); code = cmbCode[k];
-                    const int J = j >> 5;
-                    ok = (J != I) && ownsPair(I, J);
+                    // the run is stored in the COMPACT index space of the blocks this i-block owns (every other block on either side of it,
+                    // ownsPair): position g of that space is atom (g & 31) of the (g >> 5)-th block of parity pi
+                    const int g = cmbStart[k] + (v - cmbPrefix[k]), cc = cmbCode[k];
+                    code = cc & 255;
+                    j = ((((g >> 5) << 1) | (cc >> 8)) << 5) | (g & 31);
                 }
                 if (ok) {
                     // `code` names the lattice image (kx, ky, kz in -1..1) of the WRAPPED j position; the stored position may already sit in
@@ -575,11 +577,24 @@ template <typename Real> __global__ __launch_bounds__(256, 4) void k_nbBuildTile
                         }
                     }
                 }
-                const unsigned long long mq = __ballot(cLen > 0);
-                const int nQ = __popcll(mq);
-                if (nCmb + nQ > 64) runCandidates();
-                if (cLen > 0) { const int o = nCmb + lanePrefix(mq); cmbStart[o] = cStart; cmbPrefix[o] = cLen; cmbCode[o] = code; }
-                nCmb += nQ;
+                // Only the blocks this i-block owns are enumerated (round 4: half of every run used to be walked for nothing): the part of the
+                // run below the block's own atoms holds owned blocks of parity (I & 1) ^ 1, the part above it of parity I & 1.  Each part is
+                // queued as an interval of that parity's compact index space: f(x) = 32 * (owned blocks below block x >> 5) + (x & 31 if block
+                // x >> 5 is owned), so that the walk below visits owned atoms only, in the order it always has.
+#pragma unroll
+                for (int part = 0; part < 2; part++) {
+                    const int pi = part == 0 ? ((I & 1) ^ 1) : (I & 1);
+                    int a = cStart, b = cStart + cLen;
+                    if (part == 0) b = b < I * 32 ? b : I * 32; else a = a > (I + 1) * 32 ? a : (I + 1) * 32;
+                    auto compact = [pi](int x) { const int B = x >> 5; return (((B + 1 - pi) >> 1) << 5) + (((B & 1) == pi) ? (x & 31) : 0); };
+                    const int g0 = b > a ? compact(a) : 0, gLen = b > a ? compact(b) - g0 : 0;
+                    const unsigned long long mq = __ballot(gLen > 0);
+                    const int nQ = __popcll(mq);
+                    if (nQ == 0) continue;      // (uniform)
+                    if (nCmb + nQ > 64) runCandidates();
+                    if (gLen > 0) { const int o = nCmb + lanePrefix(mq); cmbStart[o] = g0; cmbPrefix[o] = gLen; cmbCode[o] = code | (pi << 8); }
+                    nCmb += nQ;
+                }
             }
         }
         if (nCmb > 0 && !failed) runCandidates();
