@@ -306,6 +306,7 @@ def main():
     ap.add_argument("--rebuild-interval", type=int, default=20, help="re-sort atoms and rebuild the tile lists every this many steps (inside the timed region)")
     ap.add_argument("--precision", default=None, choices=["single", "mixed", "double"], help="override the config's precision (mixed: single-precision arithmetic, 64-bit fixed-point force accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-auto-leg", action="store_true", help="skip the leg with displacement-triggered rebuilds (the `displacement_triggered_rebuilds` object of the JSON line)")
     ap.add_argument("--no-balance", action="store_true", help="N > 1: keep the even i-block split instead of balancing direct-space work against the ranks' reciprocal work")
     ap.add_argument("--check", action="store_true", help="also compare forces/energies with the CPU oracle (slow at full size)")
     ap.add_argument("--no-double", action="store_true", help="skip the double-precision leg (the `double_precision` object of the JSON line)")
@@ -669,6 +670,32 @@ def main():
     if world > 1:
         out["one_gpu_same_workload"] = one_gpu_same
         out["distributed"] = world_facts
+    if rank == 0 and world == 1 and not args.no_auto_leg:
+        # For the record (never `value`): the same workload, walk and step kind with DISPLACEMENT-TRIGGERED rebuilds (rebuild_interval < 0: the mode
+        # the plugin adapter of INTEGRATION.md runs the engine in -- the reference relies on OpenMM's padded list doing the same).  The engine
+        # times its side builds by a guess of the watch's next interval.
+        e2 = Engine(pkg, w, method, grid, dgrid, precision, local, 0, 1, args.padding, -100, stream=torch.cuda.current_stream().cuda_stream)
+        p2 = pos0.clone(); f2 = torch.zeros((N, 3), dtype=tdtype, device=dev)
+        e2.set_force_output(f2.data_ptr(), is_double); e2.set_energy_slices(deriv_slices); e2.set_positions_device(p2.data_ptr(), is_double); e2.set_timing_interval(0)
+
+        def step2(i):
+            p2.add_(walk[i % 16], alpha=float(walk_sign[i % len(walk_sign)]))
+            e2.execute(2, fetch=False) if headline_deriv else e2.execute(False)
+        for i in range(110):
+            step2(i)
+        e2.sync(); torch.cuda.synchronize()
+        before2 = int(e2.stats().n_rebuilds)
+        n2 = max(40, min(args.steps, 200))
+        t2 = time.perf_counter()
+        for i in range(n2):
+            step2(110 + i)
+        e2.sync(); torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t2) * 1e3 / n2
+        st2 = e2.stats()
+        out["displacement_triggered_rebuilds"] = {"ms_per_step": round(ms2, 4), "value": round(86.4 * 2.0 / ms2, 3), "unit": "ns/day", "steps": n2, "rebuilds": int(st2.n_rebuilds) - before2,
+                                                  "list_overruns": int(st2.n_list_overruns), "padded_atoms": int(st2.n_padded_atoms), "step": "with derivatives" if headline_deriv else "forces only",
+                                                  "note": "snb_config.rebuild_interval = -100: rebuild when an atom has moved 0.8 * skin / 2; same atoms, walk and step kind as `value`"}
+        e2.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # The CPU oracle on the FULL workload (round 4: its pair list and pair loops are threaded, one evaluation of c3 takes seconds, so
         # nothing is scaled any more): one evaluation to size the sample, then as many as fit ~20 s, at least 2, at most 6.
