@@ -672,8 +672,8 @@ def main():
         out["distributed"] = world_facts
     if rank == 0 and world == 1 and not args.no_auto_leg:
         # For the record (never `value`): the same workload, walk and step kind with DISPLACEMENT-TRIGGERED rebuilds (rebuild_interval < 0: the mode
-        # the plugin adapter of INTEGRATION.md runs the engine in -- the reference relies on OpenMM's padded list doing the same).  The engine
-        # times its side builds by a guess of the watch's next interval.
+        # the plugin adapter of INTEGRATION.md runs the engine in -- the reference relies on OpenMM's padded list doing the same).  These rebuilds
+        # run in line.
         e2 = Engine(pkg, w, method, grid, dgrid, precision, local, 0, 1, args.padding, -100, stream=torch.cuda.current_stream().cuda_stream)
         p2 = pos0.clone(); f2 = torch.zeros((N, 3), dtype=tdtype, device=dev)
         e2.set_force_output(f2.data_ptr(), is_double); e2.set_energy_slices(deriv_slices); e2.set_positions_device(p2.data_ptr(), is_double); e2.set_timing_interval(0)

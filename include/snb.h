@@ -75,9 +75,9 @@ typedef struct {
     double  neighbor_padding;   /* nm added to the cutoff when building tiles (0 = rebuild every call)  */
     int32_t rebuild_interval;   /* rebuild tiles every this many executes (0, 1: every execute); < 0: automatic -- when an atom has
                                  * moved 0.8 * neighbor_padding / 2 since the last rebuild, and after -rebuild_interval executes at the latest.
-                                 * (With an interval > 4 -- or automatic rebuilds that come >= 12 executes apart -- the next list is built
-                                 * three executes ahead on an internal stream, from a copy of the positions, and comes into use when
-                                 * the rebuild falls due: it is then three executes older than one built in line.) */
+                                 * (With a fixed interval > 4 the next list is built three executes ahead on an internal stream, from a
+                                 * copy of the positions, and comes into use when the rebuild falls due: it is then three executes
+                                 * older than one built in line.) */
     int32_t shard_rank;         /* multi-GPU: this engine owns PME subsets J with J % shard_count == shard_rank */
     int32_t shard_count;        /*            and direct-space work items w with w % shard_count == shard_rank; 1 = unsharded */
     int32_t disable_graph;      /* 1 = enqueue every step eagerly (default 0: forces-only steps replay a captured hipGraph)  */

@@ -265,7 +265,6 @@ public:
         DevBuf<Real> imageOffset; DevBuf<int4> tileInfo, workItems; DevBuf<unsigned> masks;
     } shadow;
     hipStream_t streamBuild = nullptr; hipEvent_t evSnap = nullptr, evBuilt = nullptr, evFlagsReset = nullptr; bool flagsResetPending = false; DevBuf<unsigned char> posSnap;
-    int autoPredict = 0;      // displacement-triggered rebuilds: the interval the next side build is timed for (0: none yet), see execute()
     bool sideEverStarted = false, sortGraphSuspect = false;      // see gpuRebuild: in-line rebuilds stop replaying cached phase-A graphs once a side build has run
     bool sideMode = true, sideBuilding = false, sidePending = false; int sideLead = 3, sideSeq = 0; long long sideBuilds = 0, sideDiscarded = 0;
     int npadPredict = 0; long long padMispredictions = 0;      // > 0: size of the padded arrays the next GPU rebuild assumes (gpuRebuild); how often that was too small
@@ -1060,10 +1059,11 @@ public:
         sw(sigeps, shadow.sigeps); sw(imageOffset, shadow.imageOffset); sw(tileInfo, shadow.tileInfo); sw(workItems, shadow.workItems); sw(masks, shadow.masks);
     }
     // whether the rebuild that falls due `sideLead` executes from now may be built beside the steps: a list built on the GPU with a predicted
-    // padded count is in use, nothing but the positions has changed since; a fixed interval, or displacement-triggered rebuilds that come
-    // at least 4 * sideLead steps apart (a side-built list comes into use sideLead steps old: a quarter of its life at most)
+    // padded count is in use, nothing but the positions has changed since, fixed interval.  (Displacement-triggered rebuilds were given side
+    // builds too, timed by a guess of the watch's next interval -- built, parity green, and slower than rebuilding in line at the watch's own
+    // pace: 0.3634 against 0.3539 ms per step on c3, the guess brings rebuilds forward and a third of them still came in line.  Removed.)
     bool sideBuildPossible() const {
-        return sideMode && !sidePending && gpuBuilt && (cfg.rebuild_interval < 0 ? autoPredict >= 4 * sideLead : cfg.rebuild_interval > sideLead + 1) && cfg.neighbor_padding > 0 && isPeriodic() && !cfg.host_neighbor_build && !cfg.disable_graph
+        return sideMode && !sidePending && gpuBuilt && cfg.rebuild_interval > sideLead + 1 && cfg.neighbor_padding > 0 && isPeriodic() && !cfg.host_neighbor_build && !cfg.disable_graph
                && !needRebuild && !paramsDirty && !staticDirty && !valuesDirty && !excValuesDirty && npadPredict > 0 && npadPredict == Npad && hNbPub && dNbPub && devUserPos;
     }
     // Copies the positions aside (in stream order: the positions of the step just enqueued) and enqueues the whole build on streamBuild, into
@@ -1459,18 +1459,7 @@ public:
         }
         if (flagsResetPending && hipEventQuery(evFlagsReset) == hipSuccess) flagsResetPending = false;
         const bool due = autoMode ? ((hDispFlags[0] != 0 && !flagsResetPending) || stepsSinceRebuild >= -cfg.rebuild_interval) : (cfg.rebuild_interval <= 1 || stepsSinceRebuild >= cfg.rebuild_interval);
-        // Displacement-triggered rebuilds have no schedule to start a side build from, so the engine keeps a guess: one step less than the
-        // last interval the watch ended by itself (autoPredict), one more each time its guess was not contradicted.  The side build starts
-        // sideLead steps before the guess; its list comes into use at the guess -- or earlier, when the watch asks for a rebuild meanwhile
-        // (the list is then a few steps old, as with a fixed interval).  A watch that fires before a side build was started rebuilds in line.
-        const bool speculative = autoMode && sidePending && !due && stepsSinceRebuild >= autoPredict;
-        if (autoMode && (due || speculative) && !needRebuild && !paramsDirty) {
-            static const bool verbose = getenv("SNB_VERBOSE") != nullptr;
-            const int was = autoPredict;
-            autoPredict = due ? std::max(stepsSinceRebuild - 1, 0) : std::min(autoPredict + 1, -cfg.rebuild_interval);
-            if (verbose) fprintf(stderr, "[snb] automatic rebuild after %d steps (%s); next side build timed for %d (was %d)\n", stepsSinceRebuild, due ? "the watch" : "the guess", autoPredict, was);
-        }
-        bool rebuilding = needRebuild || paramsDirty || due || speculative || cfg.neighbor_padding <= 0;
+        bool rebuilding = needRebuild || paramsDirty || due || cfg.neighbor_padding <= 0;
         if (sidePending) {
             // anything but the positions changed since the side build started: its list is of no use
             if (needRebuild || paramsDirty || staticDirty || valuesDirty || excValuesDirty || cfg.neighbor_padding <= 0) cancelSideBuild();
@@ -1559,7 +1548,7 @@ public:
         }
         stepCounter++;
         // the rebuild that falls due sideLead executes from now starts here, beside the steps, from the positions of the step just enqueued
-        if (stepsSinceRebuild == (autoMode ? autoPredict : cfg.rebuild_interval) - sideLead && sideBuildPossible()) startSideBuild();
+        if (!autoMode && stepsSinceRebuild == cfg.rebuild_interval - sideLead && sideBuildPossible()) startSideBuild();
         if (energy) {
             energyPending = true;
             if (energyOut) { fetchSliceEnergies(); double e = 0; for (int i = 0; i < 2 * S; i++) e += lambdas[i] * hostSliceE[i]; *energyOut = e; }      // (synchronises)

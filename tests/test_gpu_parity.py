@@ -1243,12 +1243,11 @@ auto.close(); ref.close()
 '''
 
 
-def test_side_builds_with_displacement_triggered_rebuilds(snb):
-    """rebuild_interval < 0 (what the plugin adapter of INTEGRATION.md uses): once the displacement watch's rebuilds come at least 12 steps
-    apart the engine times a side build for one step less than the last interval the watch ended by itself, and brings its list into use at
-    that guess, or when the watch fires meanwhile (engine.hip execute, autoPredict).  A random walk of 160 steps: every step against an
-    engine that rebuilds every step, no overrun, side builds in use; with SNB_SIDE_REBUILD=0 the same walk rebuilds in line at the watch's
-    own pace."""
+def test_displacement_triggered_rebuilds_beside_a_side_building_engine(snb):
+    """rebuild_interval < 0 (what the plugin adapter of INTEGRATION.md uses) rebuilds in line, at the pace of the displacement watch: side builds
+    are for fixed intervals (a guess of the watch's next interval was built and measured slower, engine.hip sideBuildPossible).  A random walk
+    of 160 steps against an engine that rebuilds every step, with side builds switched off and on (no difference for this engine: the switch
+    must not matter), no overrun, and a sane padded count -- a stale phase-A graph once left every atom a block of its own (32 N slots)."""
     import json
     import os
     import re
@@ -1256,23 +1255,18 @@ def test_side_builds_with_displacement_triggered_rebuilds(snb):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for tag, env in (("inline", {"SNB_SIDE_REBUILD": "0"}), ("beside", {})):
+    for tag, env in (("off", {"SNB_SIDE_REBUILD": "0"}), ("on", {})):
         e = dict(os.environ); e.update(env); e["SNB_VERBOSE"] = "1"
         r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _SIDE_AUTO_SCRIPT], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         got[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
         m = re.findall(r"rebuilds: (\d+), of them (\d+) built beside the steps; (\d+) side builds discarded", r.stderr)
         sides = [int(x[1]) for x in m if int(x[0]) < 150]      # (the reference engine rebuilds 160 times, in line)
-        assert len(sides) == 1, r.stderr[-1500:]
-        got[tag]["side"] = sides[0]
-        got[tag]["by_watch"] = len(re.findall(r"automatic rebuild after \d+ steps \(the watch\)", r.stderr))
-        got[tag]["by_guess"] = len(re.findall(r"automatic rebuild after \d+ steps \(the guess\)", r.stderr))
+        assert len(sides) == 1 and sides[0] == 0, r.stderr[-1500:]
         assert got[tag]["host_rebuilds"] == 0 and got[tag]["overruns"] == 0 and got[tag]["ferr"] < 2e-3, (tag, got[tag])
-        # (a rebuild in line BETWEEN side builds once replayed a stale phase-A graph and left every atom a block of its own: 32 N padded slots)
         assert got[tag]["padded"] < 2 * got[tag]["atoms"], (tag, got[tag])
-    assert got["inline"]["side"] == 0 and got["inline"]["by_guess"] == 0 and got["inline"]["rebuilds"] >= 4, got
-    assert got["beside"]["side"] >= 2 and got["beside"]["by_guess"] >= 1, got
-    assert got["beside"]["rebuilds"] <= 2 * got["inline"]["rebuilds"], got      # (the guess costs a few extra rebuilds, not a different regime)
+        assert 4 <= got[tag]["rebuilds"] <= 40, (tag, got[tag])
+    assert got["on"]["rebuilds"] == got["off"]["rebuilds"], got
 
 
 def test_predicted_padded_count_and_its_repeat_path(snb):
