@@ -1213,7 +1213,8 @@ public:
             // every pointer and parameter of phase A -- was unchanged and the same launches issued directly, or captured afresh, gave the right
             // list; the side-build graphs themselves, replayed alternately for thousands of rebuilds, never did.  Not understood (the replay reads
             // nothing the key does not hold); in-line rebuilds are rare on such an engine and ~40 plain launches cost the host ~0.2 ms.
-            if (!noSortGraph && !sortGraphBroken && !cfg.disable_graph && !sortGraphSuspect && (sideBuilding || !sideEverStarted)) {
+            static const bool replayAlways = getenv("SNB_SORT_GRAPH_ALWAYS") != nullptr;      // test switch: in-line rebuilds replay their cached graph whatever ran in between
+            if (!noSortGraph && !sortGraphBroken && !cfg.disable_graph && !sortGraphSuspect && (sideBuilding || !sideEverStarted || replayAlways)) {
                 hipGraphExec_t sortGraphExec = nullptr;
                 for (auto& g : sortGraphs) if (g.key.size() == sizeof(key) && std::memcmp(g.key.data(), &key, sizeof(key)) == 0) sortGraphExec = g.exec;
                 if (!sortGraphExec) {
