@@ -265,7 +265,7 @@ public:
         DevBuf<Real> imageOffset; DevBuf<int4> tileInfo, workItems; DevBuf<unsigned> masks;
     } shadow;
     hipStream_t streamBuild = nullptr; hipEvent_t evSnap = nullptr, evBuilt = nullptr, evFlagsReset = nullptr; bool flagsResetPending = false; DevBuf<unsigned char> posSnap;
-    bool sideEverStarted = false, sortGraphSuspect = false;      // see gpuRebuild: in-line rebuilds stop replaying cached phase-A graphs once a side build has run
+    bool sortGraphSuspect = false;      // see gpuRebuild
     bool sideMode = true, sideBuilding = false, sidePending = false; int sideLead = 3, sideSeq = 0; long long sideBuilds = 0, sideDiscarded = 0;
     int npadPredict = 0; long long padMispredictions = 0;      // > 0: size of the padded arrays the next GPU rebuild assumes (gpuRebuild); how often that was too small
     int Npad = 0, numBlocks = 0; int64_t numTiles = 0, numMaskTiles = 0, shardTiles = 0; bool wrapMode = false;
@@ -1083,7 +1083,7 @@ public:
         HIPCHECK(hipStreamWaitEvent(streamBuild, evSnap, 0));
         const hipStream_t liveStream = stream; const void* livePos = devUserPos;
         const int liveCells[2] = {colCells[0], colCells[1]};
-        swapListSets(); stream = streamBuild; devUserPos = posSnap.p; sideBuilding = true; sideEverStarted = true;
+        swapListSets(); stream = streamBuild; devUserPos = posSnap.p; sideBuilding = true;
         bool ok = false;
         try {
             ok = gpuRebuild();
@@ -1207,14 +1207,10 @@ public:
             key.p = p; key.pos = devUserPos; key.isDouble = posIsDouble; key.stride4 = posStride4; key.temp = dSortTemp.p; key.tempBytes = tempBytes;
             static const bool noSortGraph = getenv("SNB_NO_SORT_GRAPH") != nullptr;
             bool replayed = false;
-            // Once side builds run on this engine, a rebuild IN LINE goes out as plain launches.  Measured (bench.py's leg with displacement-
-            // triggered rebuilds, two engines alive on one stream): the in-line graph captured at the engine's first rebuilds, replayed after the two
-            // side-build graphs had been instantiated and launched, left a padded count of 32 N (every atom a block of its own) although its key --
-            // every pointer and parameter of phase A -- was unchanged and the same launches issued directly, or captured afresh, gave the right
-            // list; the side-build graphs themselves, replayed alternately for thousands of rebuilds, never did.  Not understood (the replay reads
-            // nothing the key does not hold); in-line rebuilds are rare on such an engine and ~40 plain launches cost the host ~0.2 ms.
-            static const bool replayAlways = getenv("SNB_SORT_GRAPH_ALWAYS") != nullptr;      // test switch: in-line rebuilds replay their cached graph whatever ran in between
-            if (!noSortGraph && !sortGraphBroken && !cfg.disable_graph && !sortGraphSuspect && (sideBuilding || !sideEverStarted || replayAlways)) {
+            // (round 4: a replayed phase-A graph once left 32 N padded slots -- its memset node for blockWideOut had stopped zeroing after other
+            // graphs with memset nodes had been instantiated; phase A now zero-fills with a kernel, misc.hip launchZeroFill.  `sortGraphSuspect`
+            // is the insurance that caught nothing since: a padded count that doubles out of a replayed graph is built once more without it.)
+            if (!noSortGraph && !sortGraphBroken && !cfg.disable_graph && !sortGraphSuspect) {
                 hipGraphExec_t sortGraphExec = nullptr;
                 for (auto& g : sortGraphs) if (g.key.size() == sizeof(key) && std::memcmp(g.key.data(), &key, sizeof(key)) == 0) sortGraphExec = g.exec;
                 if (!sortGraphExec) {
@@ -1627,7 +1623,7 @@ public:
         traceThisStep = !ev && dStepTrace.p != nullptr;      // (SNB_STEP_TRACE; replayed steps only: the stamps of the last one are printed when the engine is destroyed)
         gc.stepTrace = traceThisStep ? dStepTrace.p : nullptr;
         launchGatherPositions<Real>(devUserPos, posIsDouble, posStride4, dSortedToUser.p, imageOffset.p, posq.p, Npad, forceBuf.p, forceArrays(), gc, stream);
-        if (energy && Npad <= 0) HIPCHECK(hipMemsetAsync(sliceE.p, 0, sizeof(double) * S * 2 * SNB_SLICE_E_PARTS, stream));
+        if (energy && Npad <= 0) launchZeroFill(sliceE.p, sizeof(double) * S * 2 * SNB_SLICE_E_PARTS, stream);      // (inside the step graph: a kernel, not a memset node)
         const bool ew = cfg.method >= SNB_Ewald;
         // Opt-in (SNB_CONCURRENT_PME=1): forces-only graph steps run the reciprocal pipeline on a second stream beside the pair
         // kernel (disjoint force arrays fx.. / fpx..).  Timed (eager) steps stay serial so the per-kernel event timers stay clean.

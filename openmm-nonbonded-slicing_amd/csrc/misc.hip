@@ -252,6 +252,23 @@ void launchFinishSliceEnergies(const double* parts, double* out, int n, const Sl
     if (n > 0) hipLaunchKernelGGL(k_finishSliceEnergies, dim3((n + 63) / 64), dim3(64), 0, s, parts, out, n, f);
 }
 
+// Zero fill as a KERNEL.  hipMemsetAsync captured into a hipGraph is a memset node, and a replayed memset node went wrong in round 4:
+// the phase-A graph of an engine's in-line rebuilds, replayed after the two side-build graphs of the same engine (same topology, memset
+// nodes of their own) had been instantiated, left `blockWideOut` full of non-zero words -- every atom then counts as a block of its own, 32 N
+// padded slots -- although the node's destination, value and size were unchanged; with this kernel in its place the same replay is right
+// (bench.py's displacement-triggered leg, docs/MEASUREMENT_LOG.md round 4 section 5).  Nothing that can be captured uses hipMemsetAsync now.
+__global__ void k_zeroFill(int4* __restrict__ a, size_t n16, unsigned char* __restrict__ tail, int nTail) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) a[i] = make_int4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && (int)threadIdx.x < nTail) tail[threadIdx.x] = 0;
+}
+void launchZeroFill(void* ptr, size_t bytes, hipStream_t s) {      // ptr 16-byte aligned (hipMalloc)
+    if (bytes == 0) return;
+    const size_t n16 = bytes / 16; const int nTail = (int)(bytes - n16 * 16);
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((n16 + 255) / 256, 2048));
+    hipLaunchKernelGGL(k_zeroFill, dim3(grid), dim3(256), 0, s, (int4*)ptr, n16, (unsigned char*)ptr + n16 * 16, nTail);
+}
+
 // The displacement watch's flags (mapped host memory) cleared IN STREAM ORDER -- behind every step that used the old list, in front of the
 // first one on the new list (a list exchanged without draining the queue: engine.hip finishSideBuild); an overrun seen by a step that was
 // still queued when the host exchanged the lists is counted in flags[4] instead of being lost.

@@ -663,12 +663,12 @@ template <typename Real> void launchNeighborSort(const NbParams<Real>& p, const 
     const int n = p.nAtoms;
     const int stride = stride4 ? 4 : 3;
     dim3 block(256), gridN((n + 255) / 256);
-    (void)hipMemsetAsync(p.counters, 0, sizeof(int) * 32 * (1 + NB_PARTS), s);
+    launchZeroFill(p.counters, sizeof(int) * 32 * (1 + NB_PARTS), s);      // (a kernel, not a memset node: misc.hip)
     if (n <= 0) return;
     if (isDouble) hipLaunchKernelGGL((k_nbKeys<Real, double>), gridN, block, 0, s, p, (const double*)userPos, stride);
     else hipLaunchKernelGGL((k_nbKeys<Real, float>), gridN, block, 0, s, p, (const float*)userPos, stride);
     (void)rocprim::radix_sort_pairs(sortTemp, sortTempBytes, p.keysIn, p.keysOut, p.valsIn, p.valsOut, (size_t)n, 0, 20 + p.colBits + p.subsetBits, s);
-    (void)hipMemsetAsync(p.blockWideOut, 0, sizeof(int) * (size_t)n, s);
+    launchZeroFill(p.blockWideOut, sizeof(int) * (size_t)n, s);
     NbParams<Real> p0 = p;
     p0.blockWide = nullptr;                                 // pass 1: subset boundaries and jumps
     for (int pass = 0; pass < 2; pass++) {

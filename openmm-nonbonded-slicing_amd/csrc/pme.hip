@@ -432,7 +432,7 @@ template <typename Real> int launchPmeSpread(const PmeParams<Real>& p, hipStream
         return fuse ? 1 : 0;
     }
     // fallback (triclinic boxes, meshes without a usable column divisor): global float atomics
-    hipMemsetAsync(p.gridReal, 0, sizeof(Real) * (size_t)p.nsub * p.d.nx * p.d.ny * p.d.nz, s);
+    launchZeroFill(p.gridReal, sizeof(Real) * (size_t)p.nsub * p.d.nx * p.d.ny * p.d.nz, s);      // (a kernel, not a memset node: misc.hip)
     if (p.natoms <= 0) return 0;
     SNB_STAMPED_LAUNCH(stampSlot(p, 1), (k_spread<Real>), dim3((p.natoms + 7) / 8), dim3(256), 0, s, p);
     return 0;

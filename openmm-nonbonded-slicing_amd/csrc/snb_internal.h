@@ -264,6 +264,7 @@ template <typename Real> size_t nbSortTempBytes(int n);
 template <typename Real> void launchNeighborSort(const NbParams<Real>& p, const void* userPos, int isDouble, int stride4, void* sortTemp, size_t sortTempBytes, hipStream_t s);
 template <typename Real> void launchNeighborBuild(const NbParams<Real>& p, hipStream_t s);
 void launchDispFlagsReset(int* flagsMapped, hipStream_t s);      // misc.hip
+void launchZeroFill(void* ptr, size_t bytes, hipStream_t s);      // misc.hip: zero fill as a kernel (never a graph memset node)
 void launchNeighborPublish(const int* counters, int* hostMapped, int seq, hipStream_t s);   // counters[0..7] + sequence number into mapped host memory (the host spins on it)
 
 // ---- launchers implemented in the .hip translation units -------------------------------------

@@ -1247,7 +1247,8 @@ def test_displacement_triggered_rebuilds_beside_a_side_building_engine(snb):
     """rebuild_interval < 0 (what the plugin adapter of INTEGRATION.md uses) rebuilds in line, at the pace of the displacement watch: side builds
     are for fixed intervals (a guess of the watch's next interval was built and measured slower, engine.hip sideBuildPossible).  A random walk
     of 160 steps against an engine that rebuilds every step, with side builds switched off and on (no difference for this engine: the switch
-    must not matter), no overrun, and a sane padded count -- a stale phase-A graph once left every atom a block of its own (32 N slots)."""
+    must not matter), no overrun, and a sane padded count -- a replayed graph memset node once left every atom a block of its own (32 N slots;
+    docs/MEASUREMENT_LOG.md round 4 section 5: zero fills inside captured graphs are kernels since)."""
     import json
     import os
     import re
