@@ -1210,7 +1210,9 @@ public:
             // (round 4: a replayed phase-A graph once left 32 N padded slots -- its memset node for blockWideOut had stopped zeroing after other
             // graphs with memset nodes had been instantiated; phase A now zero-fills with a kernel, misc.hip launchZeroFill.  `sortGraphSuspect`
             // is the insurance that caught nothing since: a padded count that doubles out of a replayed graph is built once more without it.)
-            if (!noSortGraph && !sortGraphBroken && !cfg.disable_graph && !sortGraphSuspect) {
+            // (above 2^20 keys rocprim's radix sort takes its onesweep path, which clears its histogram with hipMemsetAsync -- a memset node if
+            // captured: such systems issue phase A as plain launches)
+            if (!noSortGraph && !sortGraphBroken && !cfg.disable_graph && !sortGraphSuspect && N <= (1 << 20)) {
                 hipGraphExec_t sortGraphExec = nullptr;
                 for (auto& g : sortGraphs) if (g.key.size() == sizeof(key) && std::memcmp(g.key.data(), &key, sizeof(key)) == 0) sortGraphExec = g.exec;
                 if (!sortGraphExec) {
